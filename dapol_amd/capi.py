@@ -1,0 +1,242 @@
+"""ctypes binding of libdapol_hip.so (include/dapol_hip.h).  Plumbing only: numpy arrays in, numpy arrays out.
+
+The library is the product; this module never computes anything itself and raises if the HIP library is
+missing -- there is no CPU fallback."""
+import ctypes
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdapol_hip.so")
+
+POLICY_PADDING, POLICY_SPLITTING = 0, 1
+DIGEST_BLAKE3 = 0
+
+
+class DapolError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"dapol_hip status {code}: {msg}")
+        self.code = code
+
+
+class WorkloadStats(ctypes.Structure):
+    _fields_ = [("tree_ms", ctypes.c_double), ("prove_ms", ctypes.c_double), ("msm_ms", ctypes.c_double),
+                ("msm_launches", ctypes.c_uint64), ("proofs", ctypes.c_uint64), ("proof_bytes", ctypes.c_uint64),
+                ("checksum", ctypes.c_uint64), ("root_C", ctypes.c_uint8 * 32), ("root_H", ctypes.c_uint8 * 32)]
+
+
+_lib = None
+
+_P = ctypes.c_void_p
+_SIG = {
+    "dapol_ctx_create": (ctypes.c_int32, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(_P)]),
+    "dapol_ctx_destroy": (ctypes.c_int32, [_P]),
+    "dapol_ctx_generator": (ctypes.c_int32, [_P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P]),
+    "dapol_strerror": (ctypes.c_char_p, [ctypes.c_int32]),
+    "dapol_last_error": (ctypes.c_char_p, []),
+    "dapol_commit_hash_batch": (ctypes.c_int32, [_P, ctypes.c_size_t, _P, _P, _P, _P]),
+    "dapol_tree_build": (ctypes.c_int32, [_P, ctypes.c_int32, ctypes.c_size_t, _P, _P, _P, _P, ctypes.c_int32, ctypes.POINTER(_P)]),
+    "dapol_tree_destroy": (ctypes.c_int32, [_P]),
+    "dapol_tree_root": (ctypes.c_int32, [_P, _P, _P, _P, _P]),
+    "dapol_tree_node_count": (ctypes.c_int32, [_P, _P, _P]),
+    "dapol_tree_level_size": (ctypes.c_int32, [_P, ctypes.c_int32, _P, _P]),
+    "dapol_tree_level_nodes": (ctypes.c_int32, [_P, ctypes.c_int32, _P, _P, _P, _P, _P, _P]),
+    "dapol_tree_paths": (ctypes.c_int32, [_P, ctypes.c_size_t, _P, _P, _P, _P, _P]),
+    "dapol_range_prove_batch": (ctypes.c_int32, [_P, ctypes.c_int32, ctypes.c_int32, ctypes.c_size_t, _P, _P, _P, _P, ctypes.c_uint64, _P, _P]),
+    "dapol_range_proof_size": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32]),
+    "dapol_range_verify_batch": (ctypes.c_int32, [_P, ctypes.c_int32, ctypes.c_int32, ctypes.c_size_t, _P, _P, _P, _P]),
+    "dapol_prove_entities": (ctypes.c_int32, [_P, _P, ctypes.c_size_t, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P, _P, _P, _P]),
+    "dapol_entity_proof_size": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
+    "dapol_workload_create": (ctypes.c_int32, [_P, ctypes.c_int32, ctypes.c_size_t, _P, _P, _P, ctypes.POINTER(_P)]),
+    "dapol_workload_destroy": (ctypes.c_int32, [_P]),
+    "dapol_workload_run": (ctypes.c_int32, [_P, _P, _P, ctypes.c_int32, ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(WorkloadStats)]),
+    "dapol_workload_proofs": (ctypes.c_int32, [_P, ctypes.c_size_t, ctypes.c_size_t, _P]),
+}
+EXPORTED_SYMBOLS = sorted(_SIG)
+
+
+def lib():
+    """Loads libdapol_hip.so (built by __graft_entry__.build()).  Raises if it is missing: no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DapolError(-1, f"{LIB_PATH} not found: run `python __graft_entry__.py` (hipcc) first; there is no CPU fallback")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIG.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def _chk(code):
+    if code != 0:
+        L = lib()
+        raise DapolError(code, f"{L.dapol_strerror(code).decode()} ({L.dapol_last_error().decode()})")
+
+
+def _u64(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def _u8(a, *shape):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if shape:
+        a = a.reshape(shape)
+    return a
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(_P)
+
+
+class Context:
+    """dapol_ctx: generators + window tables on one GPU."""
+
+    def __init__(self, device=0, max_parties=32):
+        self.h = _P()
+        _chk(lib().dapol_ctx_create(device, max_parties, DIGEST_BLAKE3, ctypes.byref(self.h)))
+        self.max_parties = max_parties
+
+    def close(self):
+        if self.h:
+            lib().dapol_ctx_destroy(self.h)
+            self.h = _P()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def generator(self, which, party=0, bit=0):
+        out = np.zeros(32, np.uint8)
+        _chk(lib().dapol_ctx_generator(self.h, which, party, bit, _ptr(out)))
+        return out.tobytes()
+
+    def commit_hash_batch(self, v, r32):
+        v = _u64(v)
+        n = v.shape[0]
+        r32 = _u8(r32, n, 32)
+        C, H = np.zeros((n, 32), np.uint8), np.zeros((n, 32), np.uint8)
+        _chk(lib().dapol_commit_hash_batch(self.h, n, _ptr(v), _ptr(r32), _ptr(C), _ptr(H)))
+        return C, H
+
+    def range_prove_batch(self, n_bits, m, v, r32, nonce_seed=None, stream_id=None, slot_base=0, tape=None):
+        v = _u64(v).reshape(-1, m)
+        b = v.shape[0]
+        r32 = _u8(r32, b, m, 32)
+        ps = lib().dapol_range_proof_size(n_bits, m)
+        out = np.zeros((b, max(ps, 1)), np.uint8)
+        seed = _u8(np.frombuffer(nonce_seed, np.uint8)) if nonce_seed is not None else None
+        sid = _u64(stream_id) if stream_id is not None else None
+        tp = _u8(tape) if tape is not None else None
+        _chk(lib().dapol_range_prove_batch(self.h, n_bits, m, b, _ptr(v), _ptr(r32), _ptr(seed), _ptr(sid), slot_base, _ptr(tp), _ptr(out)))
+        return out
+
+    def range_verify_batch(self, n_bits, m, proofs, V32, verify_seed=bytes(32)):
+        proofs = _u8(proofs)
+        b = proofs.shape[0]
+        V32 = _u8(V32, b, m, 32)
+        ok = np.zeros(b, np.uint8)
+        seed = _u8(np.frombuffer(verify_seed, np.uint8))
+        _chk(lib().dapol_range_verify_batch(self.h, n_bits, m, b, _ptr(proofs), _ptr(V32), _ptr(seed), _ptr(ok)))
+        return ok
+
+
+class Tree:
+    """dapol_tree: the sparse Merkle sum tree resident in HBM."""
+
+    def __init__(self, ctx, height, leaf_idx, v, r32, pad_seed, enforce_sparsity=False):
+        self.ctx, self.height = ctx, height
+        leaf_idx, v = _u64(leaf_idx), _u64(v)
+        n = leaf_idx.shape[0]
+        r32 = _u8(r32, n, 32)
+        seed = _u8(np.frombuffer(pad_seed, np.uint8))
+        self.h = _P()
+        _chk(lib().dapol_tree_build(ctx.h, height, n, _ptr(leaf_idx), _ptr(v), _ptr(r32), _ptr(seed), int(enforce_sparsity), ctypes.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().dapol_tree_destroy(self.h)
+            self.h = _P()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def root(self):
+        C, H, r = np.zeros(32, np.uint8), np.zeros(32, np.uint8), np.zeros(32, np.uint8)
+        v = np.zeros(1, np.uint64)
+        _chk(lib().dapol_tree_root(self.h, _ptr(C), _ptr(H), _ptr(v), _ptr(r)))
+        return C.tobytes(), H.tobytes(), int(v[0]), r.tobytes()
+
+    def node_count(self):
+        a, b = np.zeros(1, np.uint64), np.zeros(1, np.uint64)
+        _chk(lib().dapol_tree_node_count(self.h, _ptr(a), _ptr(b)))
+        return int(a[0]), int(b[0])
+
+    def level_nodes(self, level):
+        a, b = np.zeros(1, np.uint64), np.zeros(1, np.uint64)
+        _chk(lib().dapol_tree_level_size(self.h, level, _ptr(a), _ptr(b)))
+        n = int(a[0] + b[0])
+        idx, v = np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+        r, C, H = (np.zeros((n, 32), np.uint8) for _ in range(3))
+        pad = np.zeros(n, np.uint8)
+        _chk(lib().dapol_tree_level_nodes(self.h, level, _ptr(idx), _ptr(v), _ptr(r), _ptr(C), _ptr(H), _ptr(pad)))
+        return idx, v, r, C, H, pad
+
+    def paths(self, leaf_idx):
+        leaf_idx = _u64(leaf_idx)
+        b, h = leaf_idx.shape[0], self.height
+        C, H, r = (np.zeros((b, h, 32), np.uint8) for _ in range(3))
+        v = np.zeros((b, h), np.uint64)
+        _chk(lib().dapol_tree_paths(self.h, b, _ptr(leaf_idx), _ptr(C), _ptr(H), _ptr(v), _ptr(r)))
+        return C, H, v, r
+
+    def prove_entities(self, leaf_idx, policy, aggregation_factor, n_bits, nonce_seed):
+        leaf_idx = _u64(leaf_idx)
+        b, h = leaf_idx.shape[0], self.height
+        es = lib().dapol_entity_proof_size(h, policy, aggregation_factor, n_bits)
+        C, H = np.zeros((b, h, 32), np.uint8), np.zeros((b, h, 32), np.uint8)
+        out = np.zeros((b, max(es, 1)), np.uint8)
+        seed = _u8(np.frombuffer(nonce_seed, np.uint8))
+        _chk(lib().dapol_prove_entities(self.ctx.h, self.h, b, _ptr(leaf_idx), policy, aggregation_factor, n_bits, _ptr(seed), _ptr(C), _ptr(H), _ptr(out)))
+        return C, H, out
+
+
+class Workload:
+    """Device-resident bench workload: leaves uploaded once, every run() = tree build + one proof per entity."""
+
+    def __init__(self, ctx, height, leaf_idx, v, r32):
+        self.ctx, self.height = ctx, height
+        leaf_idx, v = _u64(leaf_idx), _u64(v)
+        self.n = leaf_idx.shape[0]
+        r32 = _u8(r32, self.n, 32)
+        self.h = _P()
+        _chk(lib().dapol_workload_create(ctx.h, height, self.n, _ptr(leaf_idx), _ptr(v), _ptr(r32), ctypes.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().dapol_workload_destroy(self.h)
+            self.h = _P()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, pad_seed, nonce_seed, n_bits=64, first=0, count=None):
+        count = self.n - first if count is None else count
+        st = WorkloadStats()
+        ps, ns = _u8(np.frombuffer(pad_seed, np.uint8)), _u8(np.frombuffer(nonce_seed, np.uint8))
+        _chk(lib().dapol_workload_run(self.h, _ptr(ps), _ptr(ns), n_bits, first, count, ctypes.byref(st)))
+        return st
+
+    def proofs(self, first, count, proof_size):
+        out = np.zeros((count, proof_size), np.uint8)
+        _chk(lib().dapol_workload_proofs(self.h, first, count, _ptr(out)))
+        return out

@@ -1,0 +1,431 @@
+// libdapol_hip.so -- C ABI (include/dapol_hip.h) over the gfx950 kernels.  Host side only orchestrates: every
+// byte of arithmetic (generator derivation included) runs on the GPU; there is no CPU fallback.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/dapol_hip.h"
+#include "kernels_ctx_tree.h"
+#include "kernels_range.h"
+
+using namespace dapol;
+
+static thread_local std::string g_last_error;
+static int32_t fail_hip(hipError_t e, const char* what, int line) {
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s failed at dapol_hip.hip:%d: %s", what, line, hipGetErrorString(e));
+    g_last_error = buf;
+    return e == hipErrorOutOfMemory ? DAPOL_ERR_OUT_OF_MEMORY : DAPOL_ERR_HIP;
+}
+static int32_t fail(int32_t code, const char* msg) {
+    g_last_error = msg;
+    return code;
+}
+#define HIPCHK(x)                                                  \
+    do {                                                           \
+        hipError_t e_ = (x);                                       \
+        if (e_ != hipSuccess) return fail_hip(e_, #x, __LINE__);   \
+    } while (0)
+#define LAUNCH_CHECK() HIPCHK(hipGetLastError())
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; return *this; }
+    ~DevBuf() { release(); }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+    hipError_t alloc(size_t count) {
+        release();
+        n = count;
+        if (count == 0) return hipSuccess;
+        return hipMalloc((void**)&p, count * sizeof(T));
+    }
+};
+
+static inline unsigned nblk(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
+
+// ------------------------------------------------------------------------------------------------ context
+struct dapol_ctx {
+    int device = 0;
+    int max_parties = 0;
+    hipStream_t stream = nullptr;
+    DevBuf<int32_t> table;       // window tables
+    DevBuf<uint32_t> gens_comp;  // compressed base points of every row (for dapol_ctx_generator)
+    TableView tv{};
+    RangeScratch scratch;        // grown on demand by the range prover
+};
+
+const char* dapol_strerror(int32_t code) {
+    switch (code) {
+        case DAPOL_OK: return "ok";
+        case DAPOL_ERR_TREE_HEIGHT_TOO_BIG: return "DAPOL tree height must not exceed 64";
+        case DAPOL_ERR_SPARSITY_TOO_SMALL: return "tree height too small for the liability set (2^height < 2n)";
+        case DAPOL_ERR_INVALID_DIGEST_SIZE: return "digest size must be 32 bytes";
+        case DAPOL_ERR_DUPLICATED_INTERNAL_ID: return "liability set contains a duplicated internal ID";
+        case DAPOL_ERR_FAILED_TO_MAP_INDEX: return "failed to map audit ID to a tree index within 128 tries";
+        case DAPOL_ERR_BYTES_NOT_ENOUGH: return "decoding: bytes not enough";
+        case DAPOL_ERR_VALUE_DECODING: return "decoding: value decoding error";
+        case DAPOL_ERR_INVALID_ARGUMENT: return "invalid argument";
+        case DAPOL_ERR_UNKNOWN_LEAF: return "no liability at the requested leaf";
+        case DAPOL_ERR_NO_DEVICE: return "no usable HIP device (the proving path has no CPU fallback)";
+        case DAPOL_ERR_HIP: return "HIP runtime error";
+        case DAPOL_ERR_OUT_OF_MEMORY: return "out of device memory";
+        default: return "unknown status";
+    }
+}
+const char* dapol_last_error(void) { return g_last_error.c_str(); }
+
+int32_t dapol_ctx_create(int32_t device, int32_t max_parties, int32_t digest_id, dapol_ctx** out) {
+    if (!out) return fail(DAPOL_ERR_INVALID_ARGUMENT, "out is null");
+    *out = nullptr;
+    if (digest_id != DAPOL_DIGEST_BLAKE3) return fail(DAPOL_ERR_INVALID_DIGEST_SIZE, "only BLAKE3 (32-byte) node hashes on the GPU path");
+    if (max_parties < 1 || max_parties > 1024 || (max_parties & (max_parties - 1)))
+        return fail(DAPOL_ERR_INVALID_ARGUMENT, "max_parties must be a power of two in [1, 1024]");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count)
+        return fail(DAPOL_ERR_NO_DEVICE, "no usable HIP device");
+    HIPCHK(hipSetDevice(device));
+    dapol_ctx* c = new dapol_ctx();
+    c->device = device;
+    c->max_parties = max_parties;
+    struct Guard { dapol_ctx* c; ~Guard() { if (c) dapol_ctx_destroy(c); } } guard{c};
+    HIPCHK(hipStreamCreate(&c->stream));
+    const int P = max_parties;
+    TableView tv{nullptr, P};
+    const int rows = tv.n_rows();
+    DevBuf<uint32_t> uniform;
+    DevBuf<int32_t> base_pts;
+    HIPCHK(uniform.alloc((size_t)2 * P * 64 * 16));
+    HIPCHK(base_pts.alloc((size_t)rows * 40));
+    HIPCHK(c->table.alloc((size_t)rows * TBL_ROW_WORDS));
+    HIPCHK(c->gens_comp.alloc((size_t)rows * 8));
+    hipLaunchKernelGGL(k_ctx_chains, dim3(nblk(2 * P, 64)), dim3(64), 0, c->stream, uniform.p, P);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_ctx_points, dim3(nblk(128 * P, 64)), dim3(64), 0, c->stream, base_pts.p, uniform.p, P);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_ctx_pedersen, dim3(1), dim3(64), 0, c->stream, base_pts.p, P);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_ctx_table, dim3(nblk((size_t)rows * TBL_ENTRIES, 64)), dim3(64), 0, c->stream, c->table.p, base_pts.p, rows);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_ctx_compress, dim3(nblk(rows, 64)), dim3(64), 0, c->stream, c->gens_comp.p, base_pts.p, rows);
+    LAUNCH_CHECK();
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->tv = TableView{c->table.p, P};
+    guard.c = nullptr;
+    *out = c;
+    return DAPOL_OK;
+}
+
+int32_t dapol_ctx_destroy(dapol_ctx* ctx) {
+    if (!ctx) return DAPOL_OK;
+    (void)hipSetDevice(ctx->device);
+    ctx->scratch.release();
+    ctx->table.release();
+    ctx->gens_comp.release();
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return DAPOL_OK;
+}
+
+int32_t dapol_ctx_generator(dapol_ctx* ctx, int32_t which, int32_t party, int32_t bit, uint8_t out32[32]) {
+    if (!ctx || !out32) return fail(DAPOL_ERR_INVALID_ARGUMENT, "null argument");
+    int row;
+    if (which == 0) row = ctx->tv.row_B(0);
+    else if (which == 1) row = ctx->tv.row_Bb(0);
+    else if ((which == 2 || which == 3) && party >= 0 && party < ctx->max_parties && bit >= 0 && bit < 64)
+        row = which == 2 ? ctx->tv.row_G(party, bit) : ctx->tv.row_H(party, bit);
+    else return fail(DAPOL_ERR_INVALID_ARGUMENT, "bad generator selector");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemcpy(out32, ctx->gens_comp.p + (size_t)row * 8, 32, hipMemcpyDeviceToHost));
+    return DAPOL_OK;
+}
+
+// ------------------------------------------------------------------------------------------- commitments
+int32_t dapol_commit_hash_batch(dapol_ctx* ctx, size_t n, const uint64_t* v, const uint8_t* r32, uint8_t* C_out32, uint8_t* H_out32) {
+    if (!ctx || (n && (!v || !r32 || !C_out32 || !H_out32))) return fail(DAPOL_ERR_INVALID_ARGUMENT, "null argument");
+    if (n == 0) return DAPOL_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    DevBuf<uint64_t> dv;
+    DevBuf<uint32_t> dr, dC, dH;
+    HIPCHK(dv.alloc(n)); HIPCHK(dr.alloc(n * 8)); HIPCHK(dC.alloc(n * 8)); HIPCHK(dH.alloc(n * 8));
+    HIPCHK(hipMemcpyAsync(dv.p, v, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(dr.p, r32, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_commit_hash, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, ctx->tv, n, dv.p, dr.p, dC.p, dH.p, (int32_t*)nullptr);
+    LAUNCH_CHECK();
+    HIPCHK(hipMemcpyAsync(C_out32, dC.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(H_out32, dH.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return DAPOL_OK;
+}
+
+// --------------------------------------------------------------------------------------------------- tree
+struct LevelBuf {
+    size_t n = 0;
+    DevBuf<uint64_t> idx, v;
+    DevBuf<uint32_t> C, H, r, padC, padH, padr, parent;
+    DevBuf<uint8_t> has_pad;
+    hipError_t alloc(size_t count, bool own_leaf_arrays) {
+        n = count;
+        hipError_t e;
+        if (own_leaf_arrays) {
+            if ((e = idx.alloc(count)) != hipSuccess) return e;
+            if ((e = v.alloc(count)) != hipSuccess) return e;
+            if ((e = r.alloc(count * 8)) != hipSuccess) return e;
+        }
+        if ((e = C.alloc(count * 8)) != hipSuccess) return e;
+        if ((e = H.alloc(count * 8)) != hipSuccess) return e;
+        if ((e = padC.alloc(count * 8)) != hipSuccess) return e;
+        if ((e = padH.alloc(count * 8)) != hipSuccess) return e;
+        if ((e = padr.alloc(count * 8)) != hipSuccess) return e;
+        if ((e = parent.alloc(count)) != hipSuccess) return e;
+        if ((e = has_pad.alloc(count)) != hipSuccess) return e;
+        return hipMemset(has_pad.p, 0, count);
+    }
+};
+
+struct dapol_tree {
+    dapol_ctx* ctx = nullptr;
+    int height = 0;
+    std::vector<LevelBuf> levels;      // 0 = leaves .. height = root
+    // level 0 may borrow caller-resident device arrays (workload path)
+    uint64_t* leaf_idx = nullptr;
+    uint64_t* leaf_v = nullptr;
+    uint32_t* leaf_r = nullptr;
+    uint64_t n_pad = 0, n_real = 0;
+    LevelView view(int k, int32_t* ext) {
+        LevelBuf& L = levels[k];
+        LevelView lv;
+        lv.n = L.n;
+        lv.idx = k == 0 ? leaf_idx : L.idx.p;
+        lv.v = k == 0 ? leaf_v : L.v.p;
+        lv.r = k == 0 ? leaf_r : L.r.p;
+        lv.C = L.C.p; lv.H = L.H.p; lv.padC = L.padC.p; lv.padH = L.padH.p; lv.padr = L.padr.p;
+        lv.has_pad = L.has_pad.p; lv.parent = L.parent.p; lv.ext = ext;
+        return lv;
+    }
+};
+
+// Builds the tree from device-resident leaf arrays (d_idx sorted; d_r is masked in place).  own==true: the tree
+// takes ownership of nothing; leaf arrays must outlive it (they are owned by the caller-side holder below).
+static int32_t tree_build_device(dapol_ctx* ctx, int height, size_t n, uint64_t* d_idx, uint64_t* d_v, uint32_t* d_r,
+                                 const uint8_t pad_seed32[32], dapol_tree* t) {
+    hipStream_t st = ctx->stream;
+    t->ctx = ctx;
+    t->height = height;
+    t->leaf_idx = d_idx; t->leaf_v = d_v; t->leaf_r = d_r;
+    t->levels.clear();
+    t->levels.resize((size_t)height + 1);
+    t->n_pad = 0;
+    t->n_real = 0;
+    DevBuf<uint32_t> bad, seed, flag, pos, head, bsums, total;
+    HIPCHK(bad.alloc(1)); HIPCHK(seed.alloc(8)); HIPCHK(total.alloc(1));
+    HIPCHK(hipMemsetAsync(bad.p, 0, 4, st));
+    HIPCHK(hipMemcpyAsync(seed.p, pad_seed32, 32, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_tree_check_leaves, dim3(nblk(n, 256)), dim3(256), 0, st, n, d_idx, height, bad.p);
+    LAUNCH_CHECK();
+    uint32_t h_bad = 0;
+    HIPCHK(hipMemcpyAsync(&h_bad, bad.p, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (h_bad) return fail(DAPOL_ERR_INVALID_ARGUMENT, "leaf indexes must be strictly increasing and below 2^height");
+    HIPCHK(flag.alloc(n)); HIPCHK(pos.alloc(n)); HIPCHK(head.alloc(n)); HIPCHK(bsums.alloc(nblk(n, 1024) + 1));
+    DevBuf<int32_t> ext_a, ext_b;
+    HIPCHK(ext_a.alloc(n * 40)); HIPCHK(ext_b.alloc(n * 40));
+    HIPCHK(t->levels[0].alloc(n, false));
+    hipLaunchKernelGGL(k_commit_hash, dim3(nblk(n, 256)), dim3(256), 0, st, ctx->tv, n, d_v, d_r, t->levels[0].C.p, t->levels[0].H.p, ext_a.p);
+    LAUNCH_CHECK();
+    int32_t* ext_cur = ext_a.p;
+    int32_t* ext_nxt = ext_b.p;
+    size_t cur_n = n;
+    for (int k = 0; k < height; k++) {
+        LevelView cur = t->view(k, ext_cur);
+        hipLaunchKernelGGL(k_tree_flags, dim3(nblk(cur_n, 256)), dim3(256), 0, st, cur_n, cur.idx, flag.p);
+        LAUNCH_CHECK();
+        size_t nb = nblk(cur_n, 1024);
+        hipLaunchKernelGGL(k_scan_block, dim3((unsigned)nb), dim3(256), 0, st, cur_n, flag.p, pos.p, bsums.p);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(64), 0, st, nb, bsums.p, total.p);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_scan_finish, dim3(nblk(cur_n, 256)), dim3(256), 0, st, cur_n, flag.p, pos.p, bsums.p, head.p);
+        LAUNCH_CHECK();
+        uint32_t next_n = 0;
+        HIPCHK(hipMemcpyAsync(&next_n, total.p, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(t->levels[k + 1].alloc(next_n, true));
+        LevelView nxt = t->view(k + 1, k + 1 < height ? ext_nxt : nullptr);
+        hipLaunchKernelGGL(k_tree_merge, dim3(nblk(next_n, 256)), dim3(256), 0, st, ctx->tv, cur, nxt, head.p, k, seed.p);
+        LAUNCH_CHECK();
+        t->n_real += cur_n;
+        t->n_pad += 2 * (uint64_t)next_n - cur_n;
+        cur_n = next_n;
+        std::swap(ext_cur, ext_nxt);
+    }
+    t->n_real += cur_n;
+    HIPCHK(hipStreamSynchronize(st));
+    return DAPOL_OK;
+}
+
+struct OwnedLeaves {
+    DevBuf<uint64_t> idx, v;
+    DevBuf<uint32_t> r;
+};
+struct dapol_tree_owned : dapol_tree {
+    OwnedLeaves leaves;
+};
+
+int32_t dapol_tree_build(dapol_ctx* ctx, int32_t height, size_t n, const uint64_t* leaf_idx, const uint64_t* v, const uint8_t* r32,
+                         const uint8_t pad_seed32[32], int32_t enforce_sparsity, dapol_tree** out) {
+    if (!ctx || !out || !pad_seed32 || (n && (!leaf_idx || !v || !r32))) return fail(DAPOL_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (height < 0 || height > 64) return fail(DAPOL_ERR_TREE_HEIGHT_TOO_BIG, "tree height must not exceed 64");
+    if (enforce_sparsity && height < 64 && ((double)n * 2.0 > (double)(1ull << height) ))
+        return fail(DAPOL_ERR_SPARSITY_TOO_SMALL, "2^height < 2 * number of liabilities");
+    if (n == 0) return fail(DAPOL_ERR_INVALID_ARGUMENT, "empty leaf set");
+    if (n > (size_t)1 << 24) return fail(DAPOL_ERR_INVALID_ARGUMENT, "at most 2^24 leaves per GPU");
+    HIPCHK(hipSetDevice(ctx->device));
+    dapol_tree_owned* t = new dapol_tree_owned();
+    struct Guard { dapol_tree* t; ~Guard() { if (t) dapol_tree_destroy(t); } } guard{t};
+    HIPCHK(t->leaves.idx.alloc(n)); HIPCHK(t->leaves.v.alloc(n)); HIPCHK(t->leaves.r.alloc(n * 8));
+    HIPCHK(hipMemcpyAsync(t->leaves.idx.p, leaf_idx, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(t->leaves.v.p, v, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(t->leaves.r.p, r32, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    int32_t rc = tree_build_device(ctx, height, n, t->leaves.idx.p, t->leaves.v.p, t->leaves.r.p, pad_seed32, t);
+    if (rc != DAPOL_OK) return rc;
+    guard.t = nullptr;
+    *out = t;
+    return DAPOL_OK;
+}
+
+int32_t dapol_tree_destroy(dapol_tree* tree) {
+    if (!tree) return DAPOL_OK;
+    if (tree->ctx) (void)hipSetDevice(tree->ctx->device);
+    delete static_cast<dapol_tree_owned*>(tree);
+    return DAPOL_OK;
+}
+
+int32_t dapol_tree_root(dapol_tree* tree, uint8_t C32[32], uint8_t H32[32], uint64_t* v, uint8_t r32[32]) {
+    if (!tree) return fail(DAPOL_ERR_INVALID_ARGUMENT, "null tree");
+    HIPCHK(hipSetDevice(tree->ctx->device));
+    LevelView lv = tree->view(tree->height, nullptr);
+    if (C32) HIPCHK(hipMemcpy(C32, lv.C, 32, hipMemcpyDeviceToHost));
+    if (H32) HIPCHK(hipMemcpy(H32, lv.H, 32, hipMemcpyDeviceToHost));
+    if (v) HIPCHK(hipMemcpy(v, lv.v, 8, hipMemcpyDeviceToHost));
+    if (r32) HIPCHK(hipMemcpy(r32, lv.r, 32, hipMemcpyDeviceToHost));
+    return DAPOL_OK;
+}
+
+int32_t dapol_tree_node_count(dapol_tree* tree, uint64_t* real_nodes, uint64_t* padding_nodes) {
+    if (!tree) return fail(DAPOL_ERR_INVALID_ARGUMENT, "null tree");
+    if (real_nodes) *real_nodes = tree->n_real;
+    if (padding_nodes) *padding_nodes = tree->n_pad;
+    return DAPOL_OK;
+}
+
+static int32_t level_pad_flags(dapol_tree* tree, int level, std::vector<uint8_t>& hp) {
+    LevelView lv = tree->view(level, nullptr);
+    hp.resize(lv.n);
+    if (level == tree->height) { std::fill(hp.begin(), hp.end(), 0); return DAPOL_OK; }
+    HIPCHK(hipMemcpy(hp.data(), lv.has_pad, lv.n, hipMemcpyDeviceToHost));
+    return DAPOL_OK;
+}
+
+int32_t dapol_tree_level_size(dapol_tree* tree, int32_t level, uint64_t* n_real, uint64_t* n_pad) {
+    if (!tree || level < 0 || level > tree->height) return fail(DAPOL_ERR_INVALID_ARGUMENT, "bad level");
+    HIPCHK(hipSetDevice(tree->ctx->device));
+    std::vector<uint8_t> hp;
+    int32_t rc = level_pad_flags(tree, level, hp);
+    if (rc) return rc;
+    uint64_t np = 0;
+    for (uint8_t f : hp) np += f;
+    if (n_real) *n_real = hp.size();
+    if (n_pad) *n_pad = np;
+    return DAPOL_OK;
+}
+
+int32_t dapol_tree_level_nodes(dapol_tree* tree, int32_t level, uint64_t* idx, uint64_t* v, uint8_t* r32, uint8_t* C32, uint8_t* H32,
+                               uint8_t* is_pad) {
+    if (!tree || level < 0 || level > tree->height || !idx || !v || !r32 || !C32 || !H32 || !is_pad)
+        return fail(DAPOL_ERR_INVALID_ARGUMENT, "bad argument");
+    HIPCHK(hipSetDevice(tree->ctx->device));
+    LevelView lv = tree->view(level, nullptr);
+    size_t n = lv.n;
+    std::vector<uint8_t> hp;
+    int32_t rc = level_pad_flags(tree, level, hp);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(idx, lv.idx, n * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(v, lv.v, n * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(r32, lv.r, n * 32, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(C32, lv.C, n * 32, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(H32, lv.H, n * 32, hipMemcpyDeviceToHost));
+    memset(is_pad, 0, n);
+    std::vector<uint8_t> pc(n * 32), ph(n * 32), pr(n * 32);
+    if (level < tree->height) {
+        HIPCHK(hipMemcpy(pc.data(), lv.padC, n * 32, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(ph.data(), lv.padH, n * 32, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(pr.data(), lv.padr, n * 32, hipMemcpyDeviceToHost));
+    }
+    size_t o = n;
+    for (size_t i = 0; i < n; i++) {
+        if (!hp[i]) continue;
+        idx[o] = idx[i] ^ 1ull;
+        v[o] = 0;
+        memcpy(r32 + o * 32, pr.data() + i * 32, 32);
+        memcpy(C32 + o * 32, pc.data() + i * 32, 32);
+        memcpy(H32 + o * 32, ph.data() + i * 32, 32);
+        is_pad[o] = 1;
+        o++;
+    }
+    return DAPOL_OK;
+}
+
+// Gathers the siblings of b leaves into device buffers (any of which may be null).
+static int32_t tree_paths_device(dapol_tree* tree, size_t b, const uint64_t* d_leaf_idx, PathOut out, uint32_t* d_pos) {
+    hipStream_t st = tree->ctx->stream;
+    DevBuf<uint32_t> missing;
+    HIPCHK(missing.alloc(1));
+    HIPCHK(hipMemsetAsync(missing.p, 0, 4, st));
+    LevelView l0 = tree->view(0, nullptr);
+    hipLaunchKernelGGL(k_tree_find_leaves, dim3(nblk(b, 256)), dim3(256), 0, st, b, d_leaf_idx, l0.n, l0.idx, d_pos, missing.p);
+    LAUNCH_CHECK();
+    uint32_t h_missing = 0;
+    HIPCHK(hipMemcpyAsync(&h_missing, missing.p, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (h_missing) return fail(DAPOL_ERR_UNKNOWN_LEAF, "no liability at one of the requested leaves");
+    for (int k = 0; k < tree->height; k++) {
+        hipLaunchKernelGGL(k_tree_path_level, dim3(nblk(b, 256)), dim3(256), 0, st, b, d_pos, tree->view(k, nullptr), k, tree->height, out);
+        LAUNCH_CHECK();
+    }
+    return DAPOL_OK;
+}
+
+int32_t dapol_tree_paths(dapol_tree* tree, size_t b, const uint64_t* leaf_idx, uint8_t* sib_C32, uint8_t* sib_H32, uint64_t* sib_v,
+                         uint8_t* sib_r32) {
+    if (!tree || (b && !leaf_idx)) return fail(DAPOL_ERR_INVALID_ARGUMENT, "null argument");
+    if (b == 0) return DAPOL_OK;
+    HIPCHK(hipSetDevice(tree->ctx->device));
+    hipStream_t st = tree->ctx->stream;
+    size_t h = (size_t)tree->height, tot = b * h;
+    DevBuf<uint64_t> dl, dv;
+    DevBuf<uint32_t> dC, dH, dr, dpos;
+    HIPCHK(dl.alloc(b)); HIPCHK(dpos.alloc(b));
+    HIPCHK(dC.alloc(tot * 8)); HIPCHK(dH.alloc(tot * 8)); HIPCHK(dr.alloc(tot * 8)); HIPCHK(dv.alloc(tot));
+    HIPCHK(hipMemcpyAsync(dl.p, leaf_idx, b * 8, hipMemcpyHostToDevice, st));
+    PathOut po{dC.p, dH.p, dv.p, dr.p};
+    int32_t rc = tree_paths_device(tree, b, dl.p, po, dpos.p);
+    if (rc) return rc;
+    if (sib_C32) HIPCHK(hipMemcpyAsync(sib_C32, dC.p, tot * 32, hipMemcpyDeviceToHost, st));
+    if (sib_H32) HIPCHK(hipMemcpyAsync(sib_H32, dH.p, tot * 32, hipMemcpyDeviceToHost, st));
+    if (sib_v) HIPCHK(hipMemcpyAsync(sib_v, dv.p, tot * 8, hipMemcpyDeviceToHost, st));
+    if (sib_r32) HIPCHK(hipMemcpyAsync(sib_r32, dr.p, tot * 32, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return DAPOL_OK;
+}
+
+#include "host_range.inc"

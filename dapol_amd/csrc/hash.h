@@ -1,0 +1,248 @@
+// Hash primitives of the proving path: BLAKE3 compression (node hash D = blake3::Hasher, benches/dapol.rs:38,
+// and the seed-mode randomness PRF), Keccak-f[1600] with STROBE-128 / Merlin (Transcript::new(&[]) at
+// src/range/mod.rs:51,67,86,105), SHAKE256 (bulletproofs GeneratorsChain) and SHA3-512 (PedersenGens B_blinding).
+#pragma once
+#include <stdint.h>
+#include "fe.h"
+
+namespace dapol {
+
+// ------------------------------------------------------------------------------------------------ BLAKE3
+enum : uint32_t { B3_CHUNK_START = 1, B3_CHUNK_END = 2, B3_PARENT = 4, B3_ROOT = 8, B3_KEYED_HASH = 16 };
+
+DAPOL_HD uint32_t rotr32(uint32_t x, int n) {
+    return (x >> n) | (x << (32 - n));
+}
+
+#define B3_G(a, b, c, d, mx, my)      \
+    a = a + b + (mx);                 \
+    d = rotr32(d ^ a, 16);            \
+    c = c + d;                        \
+    b = rotr32(b ^ c, 12);            \
+    a = a + b + (my);                 \
+    d = rotr32(d ^ a, 8);             \
+    c = c + d;                        \
+    b = rotr32(b ^ c, 7);
+
+// One BLAKE3 compression.  out16 receives the full 16-word output (first 8 = chaining value / hash).
+DAPOL_HD void blake3_compress(uint32_t* out16, const uint32_t* cv, const uint32_t* m_in, uint64_t counter, uint32_t block_len,
+                              uint32_t flags) {
+    uint32_t s0 = cv[0], s1 = cv[1], s2 = cv[2], s3 = cv[3], s4 = cv[4], s5 = cv[5], s6 = cv[6], s7 = cv[7];
+    uint32_t s8 = 0x6A09E667u, s9 = 0xBB67AE85u, s10 = 0x3C6EF372u, s11 = 0xA54FF53Au;
+    uint32_t s12 = (uint32_t)counter, s13 = (uint32_t)(counter >> 32), s14 = block_len, s15 = flags;
+    uint32_t m[16];
+    for (int i = 0; i < 16; i++) m[i] = m_in[i];
+#pragma unroll
+    for (int r = 0; r < 7; r++) {
+        B3_G(s0, s4, s8, s12, m[0], m[1]);
+        B3_G(s1, s5, s9, s13, m[2], m[3]);
+        B3_G(s2, s6, s10, s14, m[4], m[5]);
+        B3_G(s3, s7, s11, s15, m[6], m[7]);
+        B3_G(s0, s5, s10, s15, m[8], m[9]);
+        B3_G(s1, s6, s11, s12, m[10], m[11]);
+        B3_G(s2, s7, s8, s13, m[12], m[13]);
+        B3_G(s3, s4, s9, s14, m[14], m[15]);
+        if (r < 6) {
+            uint32_t t[16] = {m[2], m[6], m[3], m[10], m[7], m[0], m[4], m[13], m[1], m[11], m[12], m[5], m[9], m[14], m[15], m[8]};
+            for (int i = 0; i < 16; i++) m[i] = t[i];
+        }
+    }
+    out16[0] = s0 ^ s8;  out16[1] = s1 ^ s9;  out16[2] = s2 ^ s10; out16[3] = s3 ^ s11;
+    out16[4] = s4 ^ s12; out16[5] = s5 ^ s13; out16[6] = s6 ^ s14; out16[7] = s7 ^ s15;
+    out16[8] = s8 ^ cv[0];   out16[9] = s9 ^ cv[1];   out16[10] = s10 ^ cv[2]; out16[11] = s11 ^ cv[3];
+    out16[12] = s12 ^ cv[4]; out16[13] = s13 ^ cv[5]; out16[14] = s14 ^ cv[6]; out16[15] = s15 ^ cv[7];
+}
+#undef B3_G
+
+DAPOL_HD void blake3_iv(uint32_t* cv) {
+    cv[0] = 0x6A09E667u; cv[1] = 0xBB67AE85u; cv[2] = 0x3C6EF372u; cv[3] = 0xA54FF53Au;
+    cv[4] = 0x510E527Fu; cv[5] = 0x9B05688Cu; cv[6] = 0x1F83D9ABu; cv[7] = 0x5BE0CD19u;
+}
+
+// Leaf node hash: BLAKE3(C) for one 32-byte compressed commitment (src/dapol/node.rs:34-36).
+DAPOL_HD void blake3_hash32(uint32_t* out8, const uint32_t* c8) {
+    uint32_t cv[8], m[16], o[16];
+    blake3_iv(cv);
+    for (int i = 0; i < 8; i++) m[i] = c8[i];
+    for (int i = 8; i < 16; i++) m[i] = 0;
+    blake3_compress(o, cv, m, 0, 32, B3_CHUNK_START | B3_CHUNK_END | B3_ROOT);
+    for (int i = 0; i < 8; i++) out8[i] = o[i];
+}
+// Parent node hash: BLAKE3(C_L || C_R || H_L || H_R), 128 bytes = two blocks of one chunk (node.rs:66-77).
+DAPOL_HD void blake3_hash128(uint32_t* out8, const uint32_t* cl, const uint32_t* cr, const uint32_t* hl, const uint32_t* hr) {
+    uint32_t cv[8], m[16], o[16];
+    blake3_iv(cv);
+    for (int i = 0; i < 8; i++) { m[i] = cl[i]; m[8 + i] = cr[i]; }
+    blake3_compress(o, cv, m, 0, 64, B3_CHUNK_START);
+    for (int i = 0; i < 8; i++) { cv[i] = o[i]; m[i] = hl[i]; m[8 + i] = hr[i]; }
+    blake3_compress(o, cv, m, 0, 64, B3_CHUNK_END | B3_ROOT);
+    for (int i = 0; i < 8; i++) out8[i] = o[i];
+}
+// Seed-mode randomness: 64 bytes = first XOF block of BLAKE3-keyed(seed, LE32 domain | LE64 a | LE64 b).
+DAPOL_HD void seed_wide(uint32_t* out16, const uint32_t* seed8, uint32_t domain, uint64_t a, uint64_t b) {
+    uint32_t m[16];
+    for (int i = 0; i < 16; i++) m[i] = 0;
+    m[0] = domain; m[1] = (uint32_t)a; m[2] = (uint32_t)(a >> 32); m[3] = (uint32_t)b; m[4] = (uint32_t)(b >> 32);
+    blake3_compress(out16, seed8, m, 0, 20, B3_KEYED_HASH | B3_CHUNK_START | B3_CHUNK_END | B3_ROOT);
+}
+
+// ------------------------------------------------------------------------------------------- Keccak-f[1600]
+DAPOL_HD uint64_t rotl64(uint64_t x, int n) {
+    return (x << n) | (x >> (64 - n));
+}
+
+DAPOL_HD_NOINLINE void keccak_f1600(uint64_t* A) {
+    const uint64_t RC[24] = {0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808Aull, 0x8000000080008000ull,
+                             0x000000000000808Bull, 0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull,
+                             0x000000000000008Aull, 0x0000000000000088ull, 0x0000000080008009ull, 0x000000008000000Aull,
+                             0x000000008000808Bull, 0x800000000000008Bull, 0x8000000000008089ull, 0x8000000000008003ull,
+                             0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800Aull, 0x800000008000000Aull,
+                             0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+    uint64_t a00 = A[0], a01 = A[1], a02 = A[2], a03 = A[3], a04 = A[4], a05 = A[5], a06 = A[6], a07 = A[7], a08 = A[8], a09 = A[9],
+             a10 = A[10], a11 = A[11], a12 = A[12], a13 = A[13], a14 = A[14], a15 = A[15], a16 = A[16], a17 = A[17], a18 = A[18],
+             a19 = A[19], a20 = A[20], a21 = A[21], a22 = A[22], a23 = A[23], a24 = A[24];
+    for (int r = 0; r < 24; r++) {
+        uint64_t c0 = a00 ^ a05 ^ a10 ^ a15 ^ a20, c1 = a01 ^ a06 ^ a11 ^ a16 ^ a21, c2 = a02 ^ a07 ^ a12 ^ a17 ^ a22,
+                 c3 = a03 ^ a08 ^ a13 ^ a18 ^ a23, c4 = a04 ^ a09 ^ a14 ^ a19 ^ a24;
+        uint64_t d0 = c4 ^ rotl64(c1, 1), d1 = c0 ^ rotl64(c2, 1), d2 = c1 ^ rotl64(c3, 1), d3 = c2 ^ rotl64(c4, 1),
+                 d4 = c3 ^ rotl64(c0, 1);
+        a00 ^= d0; a05 ^= d0; a10 ^= d0; a15 ^= d0; a20 ^= d0;
+        a01 ^= d1; a06 ^= d1; a11 ^= d1; a16 ^= d1; a21 ^= d1;
+        a02 ^= d2; a07 ^= d2; a12 ^= d2; a17 ^= d2; a22 ^= d2;
+        a03 ^= d3; a08 ^= d3; a13 ^= d3; a18 ^= d3; a23 ^= d3;
+        a04 ^= d4; a09 ^= d4; a14 ^= d4; a19 ^= d4; a24 ^= d4;
+        // rho + pi: B[y][2x+3y] = rot(A[x][y])
+        uint64_t b00 = a00, b10 = rotl64(a01, 1), b20 = rotl64(a02, 62), b05 = rotl64(a03, 28), b15 = rotl64(a04, 27);
+        uint64_t b16 = rotl64(a05, 36), b01 = rotl64(a06, 44), b11 = rotl64(a07, 6), b21 = rotl64(a08, 55), b06 = rotl64(a09, 20);
+        uint64_t b07 = rotl64(a10, 3), b17 = rotl64(a11, 10), b02 = rotl64(a12, 43), b12 = rotl64(a13, 25), b22 = rotl64(a14, 39);
+        uint64_t b23 = rotl64(a15, 41), b08 = rotl64(a16, 45), b18 = rotl64(a17, 15), b03 = rotl64(a18, 21), b13 = rotl64(a19, 8);
+        uint64_t b14 = rotl64(a20, 18), b24 = rotl64(a21, 2), b09 = rotl64(a22, 61), b19 = rotl64(a23, 56), b04 = rotl64(a24, 14);
+        a00 = b00 ^ (~b01 & b02); a01 = b01 ^ (~b02 & b03); a02 = b02 ^ (~b03 & b04); a03 = b03 ^ (~b04 & b00); a04 = b04 ^ (~b00 & b01);
+        a05 = b05 ^ (~b06 & b07); a06 = b06 ^ (~b07 & b08); a07 = b07 ^ (~b08 & b09); a08 = b08 ^ (~b09 & b05); a09 = b09 ^ (~b05 & b06);
+        a10 = b10 ^ (~b11 & b12); a11 = b11 ^ (~b12 & b13); a12 = b12 ^ (~b13 & b14); a13 = b13 ^ (~b14 & b10); a14 = b14 ^ (~b10 & b11);
+        a15 = b15 ^ (~b16 & b17); a16 = b16 ^ (~b17 & b18); a17 = b17 ^ (~b18 & b19); a18 = b18 ^ (~b19 & b15); a19 = b19 ^ (~b15 & b16);
+        a20 = b20 ^ (~b21 & b22); a21 = b21 ^ (~b22 & b23); a22 = b22 ^ (~b23 & b24); a23 = b23 ^ (~b24 & b20); a24 = b24 ^ (~b20 & b21);
+        a00 ^= RC[r];
+    }
+    A[0] = a00; A[1] = a01; A[2] = a02; A[3] = a03; A[4] = a04; A[5] = a05; A[6] = a06; A[7] = a07; A[8] = a08; A[9] = a09;
+    A[10] = a10; A[11] = a11; A[12] = a12; A[13] = a13; A[14] = a14; A[15] = a15; A[16] = a16; A[17] = a17; A[18] = a18; A[19] = a19;
+    A[20] = a20; A[21] = a21; A[22] = a22; A[23] = a23; A[24] = a24;
+}
+
+// Generic sponge on a 25-lane state (used for SHAKE256 / SHA3-512 at context creation).
+struct Sponge {
+    uint64_t s[25];
+    uint32_t pos, rate;
+};
+DAPOL_HD void sponge_init(Sponge& sp, uint32_t rate) {
+    for (int i = 0; i < 25; i++) sp.s[i] = 0;
+    sp.pos = 0;
+    sp.rate = rate;
+}
+DAPOL_HD void sponge_absorb_byte(Sponge& sp, uint8_t b) {
+    sp.s[sp.pos >> 3] ^= (uint64_t)b << (8 * (sp.pos & 7));
+    if (++sp.pos == sp.rate) {
+        keccak_f1600(sp.s);
+        sp.pos = 0;
+    }
+}
+DAPOL_HD void sponge_finish(Sponge& sp, uint8_t domain) {  // 0x1F = SHAKE, 0x06 = SHA3
+    sp.s[sp.pos >> 3] ^= (uint64_t)domain << (8 * (sp.pos & 7));
+    sp.s[(sp.rate - 1) >> 3] ^= 0x80ull << (8 * ((sp.rate - 1) & 7));
+    keccak_f1600(sp.s);
+    sp.pos = 0;
+}
+DAPOL_HD uint8_t sponge_squeeze_byte(Sponge& sp) {
+    if (sp.pos == sp.rate) {
+        keccak_f1600(sp.s);
+        sp.pos = 0;
+    }
+    uint8_t b = (uint8_t)(sp.s[sp.pos >> 3] >> (8 * (sp.pos & 7)));
+    sp.pos++;
+    return b;
+}
+
+// --------------------------------------------------------------------------------- STROBE-128 / Merlin 3.0.0
+struct Strobe {
+    uint64_t s[25];
+    uint32_t pos, pos_begin;
+};
+enum : uint8_t { SF_I = 1, SF_A = 2, SF_C = 4, SF_T = 8, SF_M = 16, SF_K = 32 };
+enum : uint32_t { STROBE_R = 166 };
+
+DAPOL_HD void strobe_run_f(Strobe& st) {
+    st.s[st.pos >> 3] ^= (uint64_t)st.pos_begin << (8 * (st.pos & 7));
+    st.s[(st.pos + 1) >> 3] ^= 0x04ull << (8 * ((st.pos + 1) & 7));
+    st.s[(STROBE_R + 1) >> 3] ^= 0x80ull << (8 * ((STROBE_R + 1) & 7));
+    keccak_f1600(st.s);
+    st.pos = 0;
+    st.pos_begin = 0;
+}
+DAPOL_HD void strobe_absorb_byte(Strobe& st, uint8_t b) {
+    st.s[st.pos >> 3] ^= (uint64_t)b << (8 * (st.pos & 7));
+    if (++st.pos == STROBE_R) strobe_run_f(st);
+}
+DAPOL_HD uint8_t strobe_squeeze_byte(Strobe& st) {
+    uint32_t sh = 8 * (st.pos & 7);
+    uint8_t b = (uint8_t)(st.s[st.pos >> 3] >> sh);
+    st.s[st.pos >> 3] &= ~(0xffull << sh);
+    if (++st.pos == STROBE_R) strobe_run_f(st);
+    return b;
+}
+DAPOL_HD void strobe_begin_op(Strobe& st, uint8_t flags) {
+    uint8_t old_begin = (uint8_t)st.pos_begin;
+    st.pos_begin = st.pos + 1;
+    strobe_absorb_byte(st, old_begin);
+    strobe_absorb_byte(st, flags);
+    if ((flags & (SF_C | SF_K)) && st.pos != 0) strobe_run_f(st);
+}
+DAPOL_HD void strobe_init(Strobe& st, const char* label, int n) {  // Strobe128::new
+    for (int i = 0; i < 25; i++) st.s[i] = 0;
+    const uint8_t hdr[18] = {1, STROBE_R + 2, 1, 0, 1, 96, 'S', 'T', 'R', 'O', 'B', 'E', 'v', '1', '.', '0', '.', '2'};
+    for (int i = 0; i < 18; i++) st.s[i >> 3] ^= (uint64_t)hdr[i] << (8 * (i & 7));
+    keccak_f1600(st.s);
+    st.pos = 0;
+    st.pos_begin = 0;
+    strobe_begin_op(st, SF_M | SF_A);
+    for (int i = 0; i < n; i++) strobe_absorb_byte(st, (uint8_t)label[i]);
+}
+
+// Merlin: label framing shared by append_message / challenge_bytes.
+DAPOL_HD void merlin_frame(Strobe& st, const char* label, int label_len, uint32_t data_len) {
+    strobe_begin_op(st, SF_M | SF_A);
+    for (int i = 0; i < label_len; i++) strobe_absorb_byte(st, (uint8_t)label[i]);
+    for (int i = 0; i < 4; i++) strobe_absorb_byte(st, (uint8_t)(data_len >> (8 * i)));   // meta_ad(len, more=true)
+}
+DAPOL_HD void merlin_init(Strobe& st, const char* app_label, int n) {  // Transcript::new(label)
+    strobe_init(st, "Merlin v1.0", 11);
+    merlin_frame(st, "dom-sep", 7, (uint32_t)n);
+    strobe_begin_op(st, SF_A);
+    for (int i = 0; i < n; i++) strobe_absorb_byte(st, (uint8_t)app_label[i]);
+}
+DAPOL_HD void merlin_append_bytes(Strobe& st, const char* label, int label_len, const char* msg, int n) {
+    merlin_frame(st, label, label_len, (uint32_t)n);
+    strobe_begin_op(st, SF_A);
+    for (int i = 0; i < n; i++) strobe_absorb_byte(st, (uint8_t)msg[i]);
+}
+DAPOL_HD void merlin_append_words(Strobe& st, const char* label, int label_len, const uint32_t* w, int nwords) {
+    merlin_frame(st, label, label_len, (uint32_t)(4 * nwords));
+    strobe_begin_op(st, SF_A);
+    for (int i = 0; i < nwords; i++)
+        for (int k = 0; k < 4; k++) strobe_absorb_byte(st, (uint8_t)(w[i] >> (8 * k)));
+}
+DAPOL_HD void merlin_append_u64(Strobe& st, const char* label, int label_len, uint64_t x) {
+    uint32_t w[2] = {(uint32_t)x, (uint32_t)(x >> 32)};
+    merlin_append_words(st, label, label_len, w, 2);
+}
+// challenge_bytes(label, 64) as sixteen little-endian words (input of Scalar::from_bytes_mod_order_wide)
+DAPOL_HD void merlin_challenge_wide(Strobe& st, const char* label, int label_len, uint32_t* w16) {
+    merlin_frame(st, label, label_len, 64);
+    strobe_begin_op(st, SF_I | SF_A | SF_C);
+    for (int i = 0; i < 16; i++) {
+        uint32_t w = 0;
+        for (int k = 0; k < 4; k++) w |= (uint32_t)strobe_squeeze_byte(st) << (8 * k);
+        w16[i] = w;
+    }
+}
+
+}  // namespace dapol

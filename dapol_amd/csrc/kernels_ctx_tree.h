@@ -1,0 +1,333 @@
+// Context-creation kernels (generators + window tables, derived on the GPU) and the sparse-Merkle tree kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "hash.h"
+#include "sc.h"
+#include "tables.h"
+
+namespace dapol {
+
+// ------------------------------------------------------------------------------------------ small helpers
+__device__ __forceinline__ void ld8(uint32_t* w, const uint32_t* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 a = q[0], b = q[1];
+    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+}
+__device__ __forceinline__ void st8(uint32_t* p, const uint32_t* w) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    q[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+__device__ __forceinline__ void ld_p3(ge_p3& p, const int32_t* src) {  // 40 words
+    const int4* q = reinterpret_cast<const int4*>(src);
+    int32_t w[40];
+    for (int i = 0; i < 10; i++) { int4 a = q[i]; w[4 * i] = a.x; w[4 * i + 1] = a.y; w[4 * i + 2] = a.z; w[4 * i + 3] = a.w; }
+    for (int i = 0; i < 10; i++) { p.X.v[i] = w[i]; p.Y.v[i] = w[10 + i]; p.Z.v[i] = w[20 + i]; p.T.v[i] = w[30 + i]; }
+}
+__device__ __forceinline__ void st_p3(int32_t* dst, const ge_p3& p) {
+    int32_t w[40];
+    for (int i = 0; i < 10; i++) { w[i] = p.X.v[i]; w[10 + i] = p.Y.v[i]; w[20 + i] = p.Z.v[i]; w[30 + i] = p.T.v[i]; }
+    int4* q = reinterpret_cast<int4*>(dst);
+    for (int i = 0; i < 10; i++) q[i] = make_int4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+
+// ----------------------------------------------------------------------------- context: generator chains
+// bulletproofs 4.0.0 GeneratorsChain: SHAKE256("GeneratorsChain" || label), label = 'G'|'H' || u32le(party);
+// successive 64-byte reads.  One lane per chain (2 * max_parties chains), 64 reads each.
+__global__ void k_ctx_chains(uint32_t* uniform /*[2P][64][16]*/, int P) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= 2 * P) return;
+    int which = c / P, party = c % P;
+    Sponge sp;
+    sponge_init(sp, 136);
+    const char dom[15] = {'G', 'e', 'n', 'e', 'r', 'a', 't', 'o', 'r', 's', 'C', 'h', 'a', 'i', 'n'};
+    for (int i = 0; i < 15; i++) sponge_absorb_byte(sp, (uint8_t)dom[i]);
+    sponge_absorb_byte(sp, which ? 'H' : 'G');
+    for (int i = 0; i < 4; i++) sponge_absorb_byte(sp, (uint8_t)((uint32_t)party >> (8 * i)));
+    sponge_finish(sp, 0x1F);
+    uint32_t* out = uniform + (size_t)c * 64 * 16;
+    for (int i = 0; i < 64 * 16; i++) {
+        uint32_t w = 0;
+        for (int k = 0; k < 4; k++) w |= (uint32_t)sponge_squeeze_byte(sp) << (8 * k);
+        out[i] = w;
+    }
+}
+// One lane per generator: RistrettoPoint::from_uniform_bytes.
+__global__ void k_ctx_points(int32_t* base_pts /*[rows][40]*/, const uint32_t* uniform, int P) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= 128 * P) return;
+    uint32_t w[16];
+    for (int i = 0; i < 16; i++) w[i] = uniform[(size_t)r * 16 + i];
+    ge_p3 p;
+    ge_from_uniform(p, w);
+    st_p3(base_pts + (size_t)r * 40, p);
+}
+// PedersenGens::default(): B = ristretto basepoint, B_blinding = hash_from_bytes::<Sha3_512>(B.compress()).
+// Lane 0 -> 256^w B_blinding rows, lane 1 -> 256^w B rows.
+__global__ void k_ctx_pedersen(int32_t* base_pts, int P) {
+    int t = threadIdx.x;
+    if (t >= 2) return;
+    ge_p3 p;
+    ge_basepoint(p);
+    if (t == 0) {
+        uint32_t c[8], w[16];
+        ge_compress(c, p);
+        Sponge sp;
+        sponge_init(sp, 72);
+        for (int i = 0; i < 8; i++)
+            for (int k = 0; k < 4; k++) sponge_absorb_byte(sp, (uint8_t)(c[i] >> (8 * k)));
+        sponge_finish(sp, 0x06);
+        for (int i = 0; i < 16; i++) {
+            uint32_t x = 0;
+            for (int k = 0; k < 4; k++) x |= (uint32_t)sponge_squeeze_byte(sp) << (8 * k);
+            w[i] = x;
+        }
+        ge_from_uniform(p, w);
+    }
+    int row0 = 128 * P + (t == 0 ? 0 : 32);
+    for (int w = 0; w < 32; w++) {
+        st_p3(base_pts + (size_t)(row0 + w) * 40, p);
+        for (int d = 0; d < 8; d++) { ge_p3 q; ge_dbl(q, p, true); p = q; }
+    }
+}
+// One lane per table entry: k * base, normalised to affine niels form.
+__global__ void k_ctx_table(int32_t* table, const int32_t* base_pts, int n_rows) {
+    size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)n_rows * TBL_ENTRIES) return;
+    int row = (int)(gid / TBL_ENTRIES), k = (int)(gid % TBL_ENTRIES);
+    ge_niels q;
+    if (k == 0) {
+        ge_niels_identity(q);
+    } else {
+        ge_p3 base, acc, t;
+        ld_p3(base, base_pts + (size_t)row * 40);
+        ge_identity(acc);
+        for (int b = 7; b >= 0; b--) {
+            ge_dbl(t, acc, true);
+            acc = t;
+            if ((k >> b) & 1) { ge_add(t, acc, base); acc = t; }
+        }
+        fe zi, x, y;
+        fe_invert(zi, acc.Z);
+        fe_mul(x, acc.X, zi);
+        fe_mul(y, acc.Y, zi);
+        ge_to_niels(q, x, y);
+    }
+    int32_t* e = table + (size_t)row * TBL_ROW_WORDS + (size_t)k * TBL_ENTRY_WORDS;
+    for (int i = 0; i < 10; i++) { e[i] = q.ypx.v[i]; e[10 + i] = q.ymx.v[i]; e[20 + i] = q.xy2d.v[i]; }
+    e[30] = 0; e[31] = 0;
+}
+__global__ void k_ctx_compress(uint32_t* comp /*[rows][8]*/, const int32_t* base_pts, int n_rows) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    ge_p3 p;
+    ld_p3(p, base_pts + (size_t)r * 40);
+    uint32_t c[8];
+    ge_compress(c, p);
+    st8(comp + (size_t)r * 8, c);
+}
+
+// ------------------------------------------------------------------------------------------- commitments
+// DapolNode::new (src/dapol/node.rs:29-45): C = v*B + r*B_blinding, h = BLAKE3(compress(C)).  One lane per node.
+// r: eight words, bit 255 ignored (Scalar::from_bits); may be >= l.
+__global__ __launch_bounds__(256) void k_commit_hash(TableView tbl, size_t n, const uint64_t* v, uint32_t* r, uint32_t* C,
+                                                     uint32_t* H, int32_t* ext) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t rw[8];
+    ld8(rw, r + i * 8);
+    if (rw[7] >> 31) {             // Scalar::from_bits clears bit 255; keep the stored copy consistent
+        rw[7] &= 0x7fffffffu;
+        r[i * 8 + 7] = rw[7];
+    }
+    ge_p3 acc;
+    ge_identity(acc);
+    tbl_fixed_mul_add_u64(acc, tbl, tbl.row_B(0), v[i]);
+    tbl_fixed_mul_add(acc, tbl, tbl.row_Bb(0), rw);
+    uint32_t c[8], h[8];
+    ge_compress(c, acc);
+    blake3_hash32(h, c);
+    st8(C + i * 8, c);
+    st8(H + i * 8, h);
+    if (ext) st_p3(ext + i * 40, acc);
+}
+
+// --------------------------------------------------------------------------------------------------- scan
+// flag[i] = 1 if node i starts a new parent (its index >> 1 differs from its predecessor's).
+__global__ void k_tree_flags(size_t n, const uint64_t* idx, uint32_t* flag) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    flag[i] = (i == 0 || (idx[i] >> 1) != (idx[i - 1] >> 1)) ? 1u : 0u;
+}
+// Block-local inclusive scan of 1024 elements per 256-thread block.
+__global__ __launch_bounds__(256) void k_scan_block(size_t n, const uint32_t* in, uint32_t* out, uint32_t* block_sums) {
+    __shared__ uint32_t wave_tot[4];
+    size_t base = (size_t)blockIdx.x * 1024 + (size_t)threadIdx.x * 4;
+    uint32_t a[4];
+    for (int k = 0; k < 4; k++) a[k] = (base + k < n) ? in[base + k] : 0u;
+    a[1] += a[0]; a[2] += a[1]; a[3] += a[2];
+    uint32_t x = a[3];
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t y = __shfl_up(x, off);
+        if (lane >= off) x += y;
+    }
+    if (lane == 63) wave_tot[wv] = x;
+    __syncthreads();
+    uint32_t add = 0;
+    for (int k = 0; k < wv; k++) add += wave_tot[k];
+    uint32_t excl = x - a[3] + add;
+    for (int k = 0; k < 4; k++)
+        if (base + k < n) out[base + k] = a[k] + excl;
+    if (threadIdx.x == 255) block_sums[blockIdx.x] = x + add;
+}
+__global__ void k_scan_sums(size_t nb, uint32_t* block_sums, uint32_t* total) {  // single thread: nb <= 16384
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    uint32_t run = 0;
+    for (size_t b = 0; b < nb; b++) { uint32_t t = block_sums[b]; block_sums[b] = run; run += t; }
+    *total = run;
+}
+// pos[i] = parent slot of node i; head[q] = first child of parent q.
+__global__ void k_scan_finish(size_t n, const uint32_t* flag, uint32_t* pos, const uint32_t* block_offs, uint32_t* head) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t p = pos[i] + block_offs[i >> 10] - 1;
+    pos[i] = p;
+    if (flag[i]) head[p] = (uint32_t)i;
+}
+
+// ------------------------------------------------------------------------------------------- tree levels
+struct LevelView {
+    size_t n;
+    uint64_t* idx;
+    uint32_t* C;
+    uint32_t* H;
+    uint64_t* v;
+    uint32_t* r;
+    uint32_t* padC;
+    uint32_t* padH;
+    uint32_t* padr;
+    uint8_t* has_pad;
+    uint32_t* parent;
+    int32_t* ext;   // extended points of this level (only alive while the next level is being built)
+};
+
+// One lane per PARENT q (smtree build restated level-synchronously): children = the real node head[q] and either
+// the adjacent real node or a padding node made on the spot (Paddable::padding, src/dapol/node.rs:86-88, with the
+// positional seed-mode blinding); parent = Mergeable::merge (node.rs:64-80).
+__global__ __launch_bounds__(256) void k_tree_merge(TableView tbl, LevelView cur, LevelView nxt, const uint32_t* head, int level,
+                                                    const uint32_t* pad_seed /*8 words*/) {
+    size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nxt.n) return;
+    size_t i = head[q];
+    uint64_t my_idx = cur.idx[i];
+    bool pair = (i + 1 < cur.n) && (cur.idx[i + 1] == (my_idx ^ 1ull));
+    uint32_t cA[8], hA[8], rA[8], cB[8], hB[8], rB[8];
+    uint64_t vA = cur.v[i], vB = 0;
+    ge_p3 pA, pB;
+    ld8(cA, cur.C + i * 8);
+    ld8(hA, cur.H + i * 8);
+    ld8(rA, cur.r + i * 8);
+    ld_p3(pA, cur.ext + i * 40);
+    if (pair) {
+        ld8(cB, cur.C + (i + 1) * 8);
+        ld8(hB, cur.H + (i + 1) * 8);
+        ld8(rB, cur.r + (i + 1) * 8);
+        vB = cur.v[i + 1];
+        ld_p3(pB, cur.ext + (i + 1) * 40);
+        cur.has_pad[i] = 0;
+        cur.has_pad[i + 1] = 0;
+        cur.parent[i + 1] = (uint32_t)q;
+    } else {
+        uint32_t seed[8], wide[16];
+        for (int k = 0; k < 8; k++) seed[k] = pad_seed[k];
+        seed_wide(wide, seed, 1u, (uint64_t)level, my_idx ^ 1ull);
+        sc rm;
+        sc_from_wide(rm, wide);
+        sc_from_mont(rB, rm);
+        ge_identity(pB);
+        tbl_fixed_mul_add(pB, tbl, tbl.row_Bb(0), rB);
+        ge_compress(cB, pB);
+        blake3_hash32(hB, cB);
+        st8(cur.padC + i * 8, cB);
+        st8(cur.padH + i * 8, hB);
+        st8(cur.padr + i * 8, rB);
+        cur.has_pad[i] = 1;
+    }
+    cur.parent[i] = (uint32_t)q;
+    bool a_is_left = pair || ((my_idx & 1ull) == 0);
+    // r = (r_L + r_R) mod l  (dalek Scalar add reduces even unreduced inputs)
+    sc ma, mb, ms;
+    sc_to_mont(ma, rA);
+    sc_to_mont(mb, rB);
+    sc_add(ms, ma, mb);
+    uint32_t rp[8], cp[8], hp[8];
+    sc_from_mont(rp, ms);
+    ge_p3 pp;
+    ge_add(pp, pA, pB);
+    ge_compress(cp, pp);
+    if (a_is_left) blake3_hash128(hp, cA, cB, hA, hB);
+    else blake3_hash128(hp, cB, cA, hB, hA);
+    nxt.idx[q] = my_idx >> 1;
+    nxt.v[q] = vA + vB;           // u64 wrap == release-mode Rust (node.rs:72)
+    st8(nxt.r + q * 8, rp);
+    st8(nxt.C + q * 8, cp);
+    st8(nxt.H + q * 8, hp);
+    if (nxt.ext) st_p3(nxt.ext + q * 40, pp);
+}
+
+// Validation of the leaf index array: strictly increasing and below 2^height (smtree panics otherwise).
+__global__ void k_tree_check_leaves(size_t n, const uint64_t* idx, int height, uint32_t* bad) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    bool b = (height < 64 && (idx[i] >> height) != 0) || (i > 0 && idx[i] <= idx[i - 1]);
+    if (b) atomicOr(bad, 1u);
+}
+
+// Leaf lookup + sibling gather, one lane per (proof, level).  Output party order: root side first.
+struct PathOut {
+    uint32_t* C;     // [b][height][8] or null
+    uint32_t* H;
+    uint64_t* v;     // [b][height]
+    uint32_t* r;     // [b][height][8]
+};
+__global__ void k_tree_find_leaves(size_t b, const uint64_t* want, size_t n, const uint64_t* idx, uint32_t* pos, uint32_t* missing) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= b) return;
+    uint64_t w = want[t];
+    size_t lo = 0, hi = n;
+    while (lo < hi) {
+        size_t mid = (lo + hi) >> 1;
+        if (idx[mid] < w) lo = mid + 1; else hi = mid;
+    }
+    if (lo < n && idx[lo] == w) pos[t] = (uint32_t)lo;
+    else { pos[t] = 0xffffffffu; atomicOr(missing, 1u); }
+}
+// Walk one level for all proofs: writes the sibling of each proof's current node and moves to the parent.
+__global__ void k_tree_path_level(size_t b, uint32_t* pos, LevelView lv, int level, int height, PathOut out) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= b) return;
+    uint32_t p = pos[t];
+    if (p == 0xffffffffu) return;
+    size_t slot = t * (size_t)height + (size_t)(height - 1 - level);
+    uint32_t c[8], h[8], r[8];
+    uint64_t v = 0;
+    if (lv.has_pad[p]) {
+        ld8(c, lv.padC + (size_t)p * 8);
+        ld8(h, lv.padH + (size_t)p * 8);
+        ld8(r, lv.padr + (size_t)p * 8);
+    } else {
+        size_t s = (lv.idx[p] & 1ull) ? (size_t)p - 1 : (size_t)p + 1;
+        ld8(c, lv.C + s * 8);
+        ld8(h, lv.H + s * 8);
+        ld8(r, lv.r + s * 8);
+        v = lv.v[s];
+    }
+    if (out.C) st8(out.C + slot * 8, c);
+    if (out.H) st8(out.H + slot * 8, h);
+    if (out.v) out.v[slot] = v;
+    if (out.r) st8(out.r + slot * 8, r);
+    pos[t] = lv.parent[p];
+}
+
+}  // namespace dapol

@@ -1,0 +1,612 @@
+// Aggregated Bulletproofs range-proof prover, batched over independent proofs (one wavefront per proof in the
+// heavy kernels, one lane per proof in the Fiat-Shamir kernels).  Restates bulletproofs 4.0.0
+// RangeProof::prove_multiple_with_rng + InnerProductProof::create as called from src/range/mod.rs:48-78, with
+// the algebra re-arranged for the GPU (same group elements, same bytes):
+//   * a single prover plays every party, so blindings are pre-summed (A = sum A_j, ...);
+//   * the generators are NEVER folded: round k's L_k / R_k are multiscalar products over the ORIGINAL shared
+//     generators G_j, H_j with per-proof scalars a_i * s_j (s_j = the running product of u^{+-1}, the same
+//     s-vector the verifier uses).  All point work is therefore fixed-base, served by the window tables
+//     (tables.h), and the only per-proof state between rounds is scalar vectors in HBM;
+//   * Q = w*B is never materialised: c_L*Q = (c_L*w)*B is one more fixed-base term.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "kernels_ctx_tree.h"
+
+namespace dapol {
+
+struct ProofState {             // per proof, lives in HBM between phase kernels
+    uint64_t strobe[25];
+    uint32_t pos, pos_begin;
+    uint32_t err, pad_;
+    sc y, z, y_inv, x, w, u, u_inv;     // Montgomery form
+    sc a_bl, s_bl, t1, t2, t1_bl, t2_bl, t_x, cL, cR;
+};
+
+struct RangeArgs {
+    int n, m, N, lgN, TP;       // bits per party, parties, n*m, log2 N, digit-row length (>= 64)
+    size_t B;                   // proofs in this chunk
+    // inputs
+    const uint64_t* vals;       // [B][m]
+    const uint32_t* blind;      // [B][m][8]   integers < 2^255 (reduced on load)
+    const uint32_t* Vc;         // [B][m][8]   compressed value commitments
+    // nonce source
+    const uint32_t* seed;       // [8] device
+    const uint64_t* stream_id;  // [B]
+    uint64_t slot_base;
+    const uint32_t* tape;       // [B][m(2n+4)][16] or null
+    // scratch
+    sc* a; sc* b; sc* s1; sc* s2;       // [B][N] each
+    int8_t* dig;                        // [B][32][TP]
+    ProofState* st;                     // [B]
+    int32_t* PA; int32_t* P0; int32_t* P1;   // [B][40] partial points
+    uint32_t* out;                      // [B][out_words]
+    int out_words;
+};
+
+__device__ __forceinline__ void tape_wide(uint32_t* w16, const RangeArgs& A, size_t b, uint32_t slot) {
+    if (A.tape) {
+        const uint4* p = reinterpret_cast<const uint4*>(A.tape + ((size_t)b * (size_t)(A.m * (2 * A.n + 4)) + slot) * 16);
+        for (int i = 0; i < 4; i++) { uint4 q = p[i]; w16[4 * i] = q.x; w16[4 * i + 1] = q.y; w16[4 * i + 2] = q.z; w16[4 * i + 3] = q.w; }
+    } else {
+        uint32_t seed[8];
+        for (int i = 0; i < 8; i++) seed[i] = A.seed[i];
+        seed_wide(w16, seed, 2u, A.stream_id[b], A.slot_base + slot);
+    }
+}
+__device__ __forceinline__ void tape_scalar(sc& r, const RangeArgs& A, size_t b, uint32_t slot) {
+    uint32_t w[16];
+    tape_wide(w, A, b, slot);
+    sc_from_wide(r, w);
+}
+__device__ __forceinline__ void ld_sc(sc& r, const sc* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 a = q[0], b = q[1];
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+}
+__device__ __forceinline__ void st_sc(sc* p, const sc& r) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
+    q[1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+}
+// digits of a Montgomery-form scalar for list position `pos` of proof b
+__device__ __forceinline__ void write_digits(const RangeArgs& A, size_t b, int pos, const sc& s_mont) {
+    uint32_t c[8];
+    sc_from_mont(c, s_mont);
+    int8_t* d = A.dig + (size_t)b * 32 * A.TP + pos;
+    int carry = 0;
+    for (int i = 0; i < 32; i++) {
+        int x = (int)((c[i >> 2] >> (8 * (i & 3))) & 0xff) + carry;
+        carry = (x > 127 && i < 31) ? 1 : 0;
+        d[(size_t)i * A.TP] = (int8_t)(x - (carry << 8));
+    }
+}
+__device__ __forceinline__ void zero_digits(const RangeArgs& A, size_t b, int pos) {
+    int8_t* d = A.dig + (size_t)b * 32 * A.TP + pos;
+    for (int i = 0; i < 32; i++) d[(size_t)i * A.TP] = 0;
+}
+
+// List position -> generator.  A digit row holds two lists of N terms each: lanes 0-31 of the MSM wave walk
+// list 0 (-> partial point P0), lanes 32-63 list 1 (-> P1); term q of a list sits at position 64*(q/32)+(q%32)
+// (+32 for list 1).  round < 0 (the S commitment): list 0 = <s_L, G>, list 1 = <s_R, H>.  round k >= 0:
+// list 0 = L_k = <a_L, G_R> + <b_R, H'_L>, list 1 = R_k = <a_R, G_L> + <b_L, H'_R>; the first N/2 terms of a
+// list are its G terms.  Returns the generator's position j in [0, N) and whether it is an H generator.
+__device__ __forceinline__ int term_generator(int round, int N, int lgN, int side, int q, bool& isH) {
+    if (round < 0) {
+        isH = side != 0;
+        return q;
+    }
+    int lgh = lgN - 1 - round;            // log2(half)
+    int half = 1 << lgh, Nh = N >> 1;
+    isH = q >= Nh;
+    int qq = isH ? q - Nh : q;
+    int blk = qq >> lgh, off = qq & (half - 1);
+    bool upper = isH ? (side != 0) : (side == 0);   // L takes G_R (upper half) and H_L (lower half)
+    return (blk << (lgh + 1)) + off + (upper ? half : 0);
+}
+__device__ __forceinline__ int gen_row(const TableView& t, int n, int j, bool isH) {
+    int party = j / n, bit = j - party * n;
+    return isH ? t.row_H(party, bit) : t.row_G(party, bit);
+}
+
+// ----------------------------------------------------------------------------------------- wave reductions
+__device__ __forceinline__ void wave_reduce_point(ge_p3& acc, int32_t* lds /*[40][64]*/, int lane, int width) {
+    for (int off = width >> 1; off >= 1; off >>= 1) {
+        for (int i = 0; i < 10; i++) {
+            lds[(i)*64 + lane] = acc.X.v[i];
+            lds[(10 + i) * 64 + lane] = acc.Y.v[i];
+            lds[(20 + i) * 64 + lane] = acc.Z.v[i];
+            lds[(30 + i) * 64 + lane] = acc.T.v[i];
+        }
+        __syncthreads();
+        if ((lane & (width - 1)) < off) {
+            ge_p3 o, r;
+            for (int i = 0; i < 10; i++) {
+                o.X.v[i] = lds[(i)*64 + lane + off];
+                o.Y.v[i] = lds[(10 + i) * 64 + lane + off];
+                o.Z.v[i] = lds[(20 + i) * 64 + lane + off];
+                o.T.v[i] = lds[(30 + i) * 64 + lane + off];
+            }
+            ge_add(r, acc, o);
+            acc = r;
+        }
+        __syncthreads();
+    }
+}
+__device__ __forceinline__ void wave_reduce_sc(sc& acc, uint32_t* lds /*[8][64]*/, int lane) {
+    for (int off = 32; off >= 1; off >>= 1) {
+        for (int i = 0; i < 8; i++) lds[i * 64 + lane] = acc.v[i];
+        __syncthreads();
+        if (lane < off) {
+            sc o, r;
+            for (int i = 0; i < 8; i++) o.v[i] = lds[i * 64 + lane + off];
+            sc_add(r, acc, o);
+            acc = r;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------- K0: nonces s_L, s_R + S digits
+// grid = B * (TP/64) blocks of 64.  Lane (side, q): draws s_L[q] (side 0) or s_R[q] (side 1) from the tape in
+// the crate's slot order, stores it (Montgomery) and writes its signed radix-256 digits for the S MSM.
+__global__ __launch_bounds__(64) void k_rp_nonces(RangeArgs A) {
+    int nch = A.TP >> 6;
+    size_t b = blockIdx.x / nch;
+    int ch = blockIdx.x % nch, l = threadIdx.x, side = l >> 5, q = 32 * ch + (l & 31), pos = 64 * ch + l;
+    if (q >= A.N) { zero_digits(A, b, pos); return; }
+    int j = q / A.n, ii = q - j * A.n;
+    uint32_t slot = (uint32_t)(j * (2 * A.n + 2) + 2 + ii + (side ? A.n : 0));
+    sc s;
+    tape_scalar(s, A, b, slot);
+    st_sc((side ? A.s2 : A.s1) + b * A.N + q, s);
+    write_digits(A, b, pos, s);
+}
+
+// ------------------------------------------------------------------------- K1: A = sum_i (bit ? G_i : -H_i)
+__global__ __launch_bounds__(64) void k_rp_A(RangeArgs A, TableView tbl) {
+    __shared__ int32_t lds[40 * 64];
+    size_t b = blockIdx.x;
+    int l = threadIdx.x;
+    ge_p3 acc;
+    ge_identity(acc);
+    for (int i = l; i < A.N; i += 64) {
+        int j = i / A.n, ii = i - j * A.n;
+        int bit = (int)((A.vals[b * A.m + j] >> ii) & 1ull);
+        tbl_madd(acc, tbl, bit ? tbl.row_G(j, ii) : tbl.row_H(j, ii), bit ? 1 : -1);
+    }
+    wave_reduce_point(acc, lds, l, 64);
+    if (l == 0) st_p3(A.PA + b * 40, acc);
+}
+
+// ------------------------------------------------------------------- K2: the fixed-base MSM (dominant kernel)
+// One wavefront per proof.  Lane l owns the terms at positions 64*i + l of the digit rows (N/32 terms), walks
+// the 32 signed 8-bit windows from the top with 8 shared doublings per window (Straus), and looks every digit up
+// in the generator's 129-entry row (one 128-byte cache line per lookup, L2 / Infinity-Cache resident).
+// Lanes 0-31 accumulate list 0, lanes 32-63 list 1; two 32-lane LDS tree reductions give P0 and P1.
+__global__ __launch_bounds__(64) void k_rp_msm(RangeArgs A, TableView tbl, int round) {
+    __shared__ int32_t lds[40 * 64];
+    size_t b = blockIdx.x;
+    int l = threadIdx.x, side = l >> 5, ql = l & 31;
+    int niter = (A.N + 31) >> 5;
+    const int8_t* dig = A.dig + b * 32 * (size_t)A.TP;
+    ge_p3 acc;
+    ge_identity(acc);
+    for (int w = 31; w >= 0; w--) {
+        if (w != 31) {
+            for (int d = 0; d < 8; d++) {
+                ge_p3 t;
+                ge_dbl(t, acc, d == 7);
+                acc = t;
+            }
+        }
+        const int8_t* dw = dig + (size_t)w * A.TP + l;
+        for (int i = 0; i < niter; i++) {
+            int q = 32 * i + ql;
+            if (q < A.N) {
+                int d = dw[64 * i];
+                bool isH;
+                int j = term_generator(round, A.N, A.lgN, side, q, isH);
+                tbl_madd(acc, tbl, gen_row(tbl, A.n, j, isH), d);
+            }
+        }
+    }
+    wave_reduce_point(acc, lds, l, 32);
+    if (ql == 0) st_p3((side ? A.P1 : A.P0) + b * 40, acc);
+}
+
+// --------------------------------------------------------------------------------------- transcript helpers
+__device__ __forceinline__ void st_load(Strobe& s, const ProofState& p) {
+    for (int i = 0; i < 25; i++) s.s[i] = p.strobe[i];
+    s.pos = p.pos;
+    s.pos_begin = p.pos_begin;
+}
+__device__ __forceinline__ void st_store(ProofState& p, const Strobe& s) {
+    for (int i = 0; i < 25; i++) p.strobe[i] = s.s[i];
+    p.pos = s.pos;
+    p.pos_begin = s.pos_begin;
+}
+__device__ __forceinline__ void challenge_scalar(sc& r, Strobe& s, const char* label, int n) {
+    uint32_t w[16];
+    merlin_challenge_wide(s, label, n, w);
+    sc_from_wide(r, w);
+}
+__device__ __forceinline__ void append_scalar(Strobe& s, const char* label, int n, const uint32_t* canon8) {
+    merlin_append_words(s, label, n, canon8, 8);
+}
+
+// --------------------------------------------------------- F1: finish A and S, transcript up to y, z (lane/proof)
+__global__ __launch_bounds__(64) void k_rp_finish1(RangeArgs A, TableView tbl) {
+    size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (b >= A.B) return;
+    ProofState& ps = A.st[b];
+    sc a_bl, s_bl, t;
+    sc_zero(a_bl);
+    sc_zero(s_bl);
+    for (int j = 0; j < A.m; j++) {
+        tape_scalar(t, A, b, (uint32_t)(j * (2 * A.n + 2)));
+        sc_add(a_bl, a_bl, t);
+        tape_scalar(t, A, b, (uint32_t)(j * (2 * A.n + 2) + 1));
+        sc_add(s_bl, s_bl, t);
+    }
+    ge_p3 pa, p0, p1, ps_;
+    uint32_t c[8], Ac[8], Sc[8];
+    ld_p3(pa, A.PA + b * 40);
+    sc_from_mont(c, a_bl);
+    tbl_fixed_mul_add(pa, tbl, tbl.row_Bb(0), c);
+    ge_compress(Ac, pa);
+    ld_p3(p0, A.P0 + b * 40);
+    ld_p3(p1, A.P1 + b * 40);
+    ge_add(ps_, p0, p1);
+    sc_from_mont(c, s_bl);
+    tbl_fixed_mul_add(ps_, tbl, tbl.row_Bb(0), c);
+    ge_compress(Sc, ps_);
+    uint32_t* out = A.out + b * A.out_words;
+    st8(out, Ac);
+    st8(out + 8, Sc);
+    Strobe s;
+    merlin_init(s, "", 0);                                       // Transcript::new(&[])  (src/range/mod.rs:51,67)
+    merlin_append_bytes(s, "dom-sep", 7, "rangeproof v1", 13);
+    merlin_append_u64(s, "n", 1, (uint64_t)A.n);
+    merlin_append_u64(s, "m", 1, (uint64_t)A.m);
+    for (int j = 0; j < A.m; j++) {
+        uint32_t v[8];
+        ld8(v, A.Vc + (b * A.m + j) * 8);
+        merlin_append_words(s, "V", 1, v, 8);
+    }
+    merlin_append_words(s, "A", 1, Ac, 8);
+    merlin_append_words(s, "S", 1, Sc, 8);
+    sc y, z, yi;
+    challenge_scalar(y, s, "y", 1);
+    challenge_scalar(z, s, "z", 1);
+    sc_invert_mont(yi, y);
+    ps.y = y; ps.z = z; ps.y_inv = yi; ps.a_bl = a_bl; ps.s_bl = s_bl;
+    ps.err = 0;
+    st_store(ps, s);
+}
+
+// ------------------------------------------------- K3: l0, l1, r0, r1 and t1, t2 (wave per proof)
+// Party::apply_challenge_with_rng restated over the concatenated vectors: position i = (party j, bit ii).
+__global__ __launch_bounds__(64) void k_rp_poly(RangeArgs A) {
+    __shared__ uint32_t lds[8 * 64];
+    size_t b = blockIdx.x;
+    int l = threadIdx.x;
+    const ProofState& ps = A.st[b];
+    sc y = ps.y, z = ps.z, one, yi, y64, t1, t2;
+    sc_one_mont(one);
+    sc_pow_mont(yi, y, (uint32_t)l);
+    sc_pow_mont(y64, y, 64u);
+    sc_zero(t1);
+    sc_zero(t2);
+    sc zm1;
+    sc_sub(zm1, z, one);
+    for (int i = l; i < A.N; i += 64) {
+        int j = i / A.n, ii = i - j * A.n;
+        int bit = (int)((A.vals[b * A.m + j] >> ii) & 1ull);
+        sc zz, two, l0, l1, sR, r0, r1, t, u;
+        sc_pow_mont(zz, z, (uint32_t)(2 + j));
+        sc_from_u64_mont(two, 1ull << ii);
+        if (bit) sc_sub(l0, one, z); else sc_neg(l0, z);          // a_L - z
+        ld_sc(l1, A.s1 + b * A.N + i);
+        ld_sc(sR, A.s2 + b * A.N + i);
+        sc_montmul(t, yi, bit ? z : zm1);                          // y^i (a_R + z)
+        sc_montmul(u, zz, two);                                    // z^(2+j) 2^ii
+        sc_add(r0, t, u);
+        sc_montmul(r1, yi, sR);
+        sc_montmul(t, l0, r1);
+        sc_add(t1, t1, t);
+        sc_montmul(t, l1, r0);
+        sc_add(t1, t1, t);
+        sc_montmul(t, l1, r1);
+        sc_add(t2, t2, t);
+        st_sc(A.b + b * A.N + i, r0);
+        st_sc(A.s2 + b * A.N + i, r1);
+        sc_montmul(yi, yi, y64);
+    }
+    wave_reduce_sc(t1, lds, l);
+    wave_reduce_sc(t2, lds, l);
+    if (l == 0) { A.st[b].t1 = t1; A.st[b].t2 = t2; }
+}
+
+// ------------------------------------------------------------- F2: T1, T2 and the challenge x (lane/proof)
+__global__ __launch_bounds__(64) void k_rp_finish2(RangeArgs A, TableView tbl) {
+    size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (b >= A.B) return;
+    ProofState& ps = A.st[b];
+    sc t1_bl, t2_bl, t;
+    sc_zero(t1_bl);
+    sc_zero(t2_bl);
+    uint32_t base = (uint32_t)(A.m * (2 * A.n + 2));
+    for (int j = 0; j < A.m; j++) {
+        tape_scalar(t, A, b, base + 2 * j);
+        sc_add(t1_bl, t1_bl, t);
+        tape_scalar(t, A, b, base + 2 * j + 1);
+        sc_add(t2_bl, t2_bl, t);
+    }
+    uint32_t c[8], T1c[8], T2c[8];
+    ge_p3 p;
+    ge_identity(p);
+    sc_from_mont(c, ps.t1);
+    tbl_fixed_mul_add(p, tbl, tbl.row_B(0), c);
+    sc_from_mont(c, t1_bl);
+    tbl_fixed_mul_add(p, tbl, tbl.row_Bb(0), c);
+    ge_compress(T1c, p);
+    ge_identity(p);
+    sc_from_mont(c, ps.t2);
+    tbl_fixed_mul_add(p, tbl, tbl.row_B(0), c);
+    sc_from_mont(c, t2_bl);
+    tbl_fixed_mul_add(p, tbl, tbl.row_Bb(0), c);
+    ge_compress(T2c, p);
+    uint32_t* out = A.out + b * A.out_words;
+    st8(out + 16, T1c);
+    st8(out + 24, T2c);
+    Strobe s;
+    st_load(s, ps);
+    merlin_append_words(s, "T_1", 3, T1c, 8);
+    merlin_append_words(s, "T_2", 3, T2c, 8);
+    sc x;
+    challenge_scalar(x, s, "x", 1);
+    if (sc_is_zero(x)) ps.err = 1;                                // ProofError::MaliciousDealer in the crate
+    ps.x = x; ps.t1_bl = t1_bl; ps.t2_bl = t2_bl;
+    st_store(ps, s);
+}
+
+// ------------------------------------- K4: l = l0 + l1 x, r = r0 + r1 x, t_x = <l, r>, s-vector init (wave/proof)
+__global__ __launch_bounds__(64) void k_rp_lr(RangeArgs A) {
+    __shared__ uint32_t lds[8 * 64];
+    size_t b = blockIdx.x;
+    int l = threadIdx.x;
+    const ProofState& ps = A.st[b];
+    sc x = ps.x, z = ps.z, yinv = ps.y_inv, one, yi, y64, tx;
+    sc_one_mont(one);
+    sc_pow_mont(yi, yinv, (uint32_t)l);
+    sc_pow_mont(y64, yinv, 64u);
+    sc_zero(tx);
+    for (int i = l; i < A.N; i += 64) {
+        int j = i / A.n, ii = i - j * A.n;
+        int bit = (int)((A.vals[b * A.m + j] >> ii) & 1ull);
+        sc l0, l1, r0, r1, lv, rv, t;
+        if (bit) sc_sub(l0, one, z); else sc_neg(l0, z);
+        ld_sc(l1, A.s1 + b * A.N + i);
+        ld_sc(r0, A.b + b * A.N + i);
+        ld_sc(r1, A.s2 + b * A.N + i);
+        sc_montmul(t, l1, x);
+        sc_add(lv, l0, t);
+        sc_montmul(t, r1, x);
+        sc_add(rv, r0, t);
+        sc_montmul(t, lv, rv);
+        sc_add(tx, tx, t);
+        st_sc(A.a + b * A.N + i, lv);
+        st_sc(A.b + b * A.N + i, rv);
+        st_sc(A.s1 + b * A.N + i, one);          // s_G[i] = 1
+        st_sc(A.s2 + b * A.N + i, yi);           // s_H[i] = y^-i   (H' = y^-i H, folded into the scalar)
+        sc_montmul(yi, yi, y64);
+    }
+    wave_reduce_sc(tx, lds, l);
+    if (l == 0) A.st[b].t_x = tx;
+}
+
+// ------------------------------- F3: t_x, tau_x, mu; challenge w; inner-product domain separator (lane/proof)
+__global__ __launch_bounds__(64) void k_rp_finish3(RangeArgs A) {
+    size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (b >= A.B) return;
+    ProofState& ps = A.st[b];
+    sc x = ps.x, z = ps.z, xx, zz, tau, mu, t, bl;
+    sc_montmul(xx, x, x);
+    sc_montmul(zz, z, z);
+    sc_zero(tau);
+    for (int j = 0; j < A.m; j++) {                               // sum_j z^(2+j) * v_blinding_j
+        uint32_t w[8];
+        ld8(w, A.blind + (b * A.m + j) * 8);
+        sc_to_mont(bl, w);
+        sc_montmul(t, zz, bl);
+        sc_add(tau, tau, t);
+        sc_montmul(zz, zz, z);
+    }
+    sc_montmul(t, ps.t1_bl, x);
+    sc_add(tau, tau, t);
+    sc_montmul(t, ps.t2_bl, xx);
+    sc_add(tau, tau, t);
+    sc_montmul(t, ps.s_bl, x);
+    sc_add(mu, ps.a_bl, t);
+    uint32_t c_tx[8], c_tau[8], c_mu[8];
+    sc_from_mont(c_tx, ps.t_x);
+    sc_from_mont(c_tau, tau);
+    sc_from_mont(c_mu, mu);
+    uint32_t* out = A.out + b * A.out_words;
+    st8(out + 32, c_tx);
+    st8(out + 40, c_tau);
+    st8(out + 48, c_mu);
+    Strobe s;
+    st_load(s, ps);
+    append_scalar(s, "t_x", 3, c_tx);
+    append_scalar(s, "t_x_blinding", 12, c_tau);
+    append_scalar(s, "e_blinding", 10, c_mu);
+    sc w;
+    challenge_scalar(w, s, "w", 1);
+    merlin_append_bytes(s, "dom-sep", 7, "ipp v1", 6);
+    merlin_append_u64(s, "n", 1, (uint64_t)A.N);
+    ps.w = w;
+    st_store(ps, s);
+}
+
+// ------------------------------------------------- K5: round-k MSM scalars -> digits (grid B * TP/64 blocks)
+__global__ __launch_bounds__(64) void k_rp_round_prep(RangeArgs A, int round) {
+    int nch = A.TP >> 6;
+    size_t b = blockIdx.x / nch;
+    int ch = blockIdx.x % nch, l = threadIdx.x, side = l >> 5, q = 32 * ch + (l & 31), pos = 64 * ch + l;
+    if (q >= A.N) { zero_digits(A, b, pos); return; }
+    bool isH;
+    int j = term_generator(round, A.N, A.lgN, side, q, isH);
+    int lgh = A.lgN - 1 - round, half = 1 << lgh;
+    int off = j & (half - 1);
+    bool upper = (j >> lgh) & 1;              // generator sits in the upper half of its block
+    // G_R pairs with a_L, G_L with a_R; H'_L pairs with b_R, H'_R with b_L
+    int vi = upper ? off : off + half;
+    sc v, s, p;
+    ld_sc(v, (isH ? A.b : A.a) + b * A.N + vi);
+    ld_sc(s, (isH ? A.s2 : A.s1) + b * A.N + j);
+    sc_montmul(p, v, s);
+    write_digits(A, b, pos, p);
+}
+// c_L = <a_L, b_R>, c_R = <a_R, b_L>  (wave per proof)
+__global__ __launch_bounds__(64) void k_rp_round_ip(RangeArgs A, int round) {
+    __shared__ uint32_t lds[8 * 64];
+    size_t b = blockIdx.x;
+    int l = threadIdx.x, half = 1 << (A.lgN - 1 - round);
+    sc cL, cR;
+    sc_zero(cL);
+    sc_zero(cR);
+    for (int i = l; i < half; i += 64) {
+        sc aL, aR, bL, bR, t;
+        ld_sc(aL, A.a + b * A.N + i);
+        ld_sc(aR, A.a + b * A.N + half + i);
+        ld_sc(bL, A.b + b * A.N + i);
+        ld_sc(bR, A.b + b * A.N + half + i);
+        sc_montmul(t, aL, bR);
+        sc_add(cL, cL, t);
+        sc_montmul(t, aR, bL);
+        sc_add(cR, cR, t);
+    }
+    wave_reduce_sc(cL, lds, l);
+    wave_reduce_sc(cR, lds, l);
+    if (l == 0) { A.st[b].cL = cL; A.st[b].cR = cR; }
+}
+
+// --------------------------------------------------------- F4: L_k, R_k, challenge u_k (lane/proof)
+__global__ __launch_bounds__(64) void k_rp_round_finish(RangeArgs A, TableView tbl, int round) {
+    size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (b >= A.B) return;
+    ProofState& ps = A.st[b];
+    ge_p3 p;
+    sc t;
+    uint32_t c[8], Lc[8], Rc[8];
+    ld_p3(p, A.P0 + b * 40);
+    sc_montmul(t, ps.cL, ps.w);
+    sc_from_mont(c, t);
+    tbl_fixed_mul_add(p, tbl, tbl.row_B(0), c);               // + c_L * Q,  Q = w * B
+    ge_compress(Lc, p);
+    ld_p3(p, A.P1 + b * 40);
+    sc_montmul(t, ps.cR, ps.w);
+    sc_from_mont(c, t);
+    tbl_fixed_mul_add(p, tbl, tbl.row_B(0), c);
+    ge_compress(Rc, p);
+    uint32_t* out = A.out + b * A.out_words + 56 + 16 * round;
+    st8(out, Lc);
+    st8(out + 8, Rc);
+    Strobe s;
+    st_load(s, ps);
+    merlin_append_words(s, "L", 1, Lc, 8);
+    merlin_append_words(s, "R", 1, Rc, 8);
+    sc u, ui;
+    challenge_scalar(u, s, "u", 1);
+    sc_invert_mont(ui, u);
+    ps.u = u; ps.u_inv = ui;
+    st_store(ps, s);
+}
+
+// --------------------------------------------- K6: fold a, b and update the s-vectors (elementwise, B * N lanes)
+__global__ __launch_bounds__(256) void k_rp_fold(RangeArgs A, int round) {
+    size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= A.B * (size_t)A.N) return;
+    size_t b = gid / A.N;
+    int j = (int)(gid - b * A.N);
+    const ProofState& ps = A.st[b];
+    sc u = ps.u, ui = ps.u_inv;
+    int lgh = A.lgN - 1 - round, half = 1 << lgh;
+    bool upper = (j >> lgh) & 1;
+    sc s, t;
+    ld_sc(s, A.s1 + b * A.N + j);                 // G' = u^-1 G_L + u G_R
+    sc_montmul(t, s, upper ? u : ui);
+    st_sc(A.s1 + b * A.N + j, t);
+    ld_sc(s, A.s2 + b * A.N + j);                 // H' = u H_L + u^-1 H_R
+    sc_montmul(t, s, upper ? ui : u);
+    st_sc(A.s2 + b * A.N + j, t);
+    if (j < half) {
+        sc lo, hi, r;
+        ld_sc(lo, A.a + b * A.N + j);
+        ld_sc(hi, A.a + b * A.N + half + j);
+        sc_montmul(lo, lo, u);
+        sc_montmul(hi, hi, ui);
+        sc_add(r, lo, hi);
+        st_sc(A.a + b * A.N + j, r);              // a' = a_L u + a_R u^-1
+        ld_sc(lo, A.b + b * A.N + j);
+        ld_sc(hi, A.b + b * A.N + half + j);
+        sc_montmul(lo, lo, ui);
+        sc_montmul(hi, hi, u);
+        sc_add(r, lo, hi);
+        st_sc(A.b + b * A.N + j, r);              // b' = b_L u^-1 + b_R u
+    }
+}
+
+// ------------------------------------------------------------------------------ F5: final a, b (lane/proof)
+__global__ __launch_bounds__(64) void k_rp_final(RangeArgs A, uint32_t* err_flag) {
+    size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (b >= A.B) return;
+    sc a, bb;
+    uint32_t c[8];
+    ld_sc(a, A.a + b * A.N);
+    ld_sc(bb, A.b + b * A.N);
+    uint32_t* out = A.out + b * A.out_words + 56 + 16 * A.lgN;
+    sc_from_mont(c, a);
+    st8(out, c);
+    sc_from_mont(c, bb);
+    st8(out + 8, c);
+    if (A.st[b].err) atomicOr(err_flag, 1u);
+}
+
+// Value commitments of the parties (Party::new: V = commit(v, v_blinding)) when the caller has none yet.
+__global__ __launch_bounds__(256) void k_rp_commit_V(TableView tbl, size_t n, const uint64_t* v, const uint32_t* r, uint32_t* Vc) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t rw[8], c[8];
+    ld8(rw, r + i * 8);
+    rw[7] &= 0x7fffffffu;
+    ge_p3 acc;
+    ge_identity(acc);
+    tbl_fixed_mul_add_u64(acc, tbl, tbl.row_B(0), v[i]);
+    tbl_fixed_mul_add(acc, tbl, tbl.row_Bb(0), rw);
+    ge_compress(c, acc);
+    st8(Vc + i * 8, c);
+}
+
+// Scratch owned by the context, grown on demand.
+struct RangeScratch {
+    void* p = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t need) {
+        if (need <= bytes) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        hipError_t e = hipMalloc(&p, need);
+        if (e == hipSuccess) bytes = need;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+}  // namespace dapol

@@ -1,0 +1,75 @@
+// Fixed-base window tables in HBM (L2 / Infinity-Cache resident) and the lookups the kernels use.
+//
+// Layout: a ROW holds the 129 multiples k*P, k = 0..128, of one base point P as 128-byte entries
+// (affine niels form: y+x, y-x, 2dxy as 3 x 10 int32 limbs, 2 words of padding -> eight 16-byte loads per lookup,
+// one cache line).  Entry 0 is the identity so a zero digit needs no branch; digits are signed (-128..128).
+//   rows [0, 64*P)            G[party][bit]      (P = max_parties)       bulletproofs BulletproofGens G chain
+//   rows [64*P, 128*P)        H[party][bit]                              ... H chain
+//   rows [128*P, 128*P+32)    256^w * B_blinding, w = 0..31             PedersenGens::default().B_blinding
+//   rows [128*P+32, 128*P+64) 256^w * B,          w = 0..31             PedersenGens::default().B
+// The per-window rows of B / B_blinding make single-base commitments doubling-free (32 mixed adds); the G/H
+// rows are used Straus-style (shared doublings across the terms a lane owns).
+#pragma once
+#include "ge.h"
+
+namespace dapol {
+
+enum { TBL_ENTRIES = 129, TBL_ENTRY_WORDS = 32, TBL_ROW_WORDS = TBL_ENTRIES * TBL_ENTRY_WORDS };
+
+struct TableView {
+    const int32_t* base;   // device pointer
+    int32_t max_parties;
+    __host__ __device__ int row_G(int party, int bit) const { return party * 64 + bit; }
+    __host__ __device__ int row_H(int party, int bit) const { return 64 * max_parties + party * 64 + bit; }
+    __host__ __device__ int row_Bb(int w) const { return 128 * max_parties + w; }
+    __host__ __device__ int row_B(int w) const { return 128 * max_parties + 32 + w; }
+    __host__ __device__ int n_rows() const { return 128 * max_parties + 64; }
+};
+
+#if defined(__HIPCC__)
+// Load entry |d| of `row`; the sign is applied by ge_madd.
+__device__ __forceinline__ void tbl_load(ge_niels& q, const TableView& t, int row, int absd) {
+    const int4* p = reinterpret_cast<const int4*>(t.base + (size_t)row * TBL_ROW_WORDS + (size_t)absd * TBL_ENTRY_WORDS);
+    int4 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3], a4 = p[4], a5 = p[5], a6 = p[6], a7 = p[7];
+    q.ypx.v[0] = a0.x; q.ypx.v[1] = a0.y; q.ypx.v[2] = a0.z; q.ypx.v[3] = a0.w;
+    q.ypx.v[4] = a1.x; q.ypx.v[5] = a1.y; q.ypx.v[6] = a1.z; q.ypx.v[7] = a1.w;
+    q.ypx.v[8] = a2.x; q.ypx.v[9] = a2.y;
+    q.ymx.v[0] = a2.z; q.ymx.v[1] = a2.w;
+    q.ymx.v[2] = a3.x; q.ymx.v[3] = a3.y; q.ymx.v[4] = a3.z; q.ymx.v[5] = a3.w;
+    q.ymx.v[6] = a4.x; q.ymx.v[7] = a4.y; q.ymx.v[8] = a4.z; q.ymx.v[9] = a4.w;
+    q.xy2d.v[0] = a5.x; q.xy2d.v[1] = a5.y; q.xy2d.v[2] = a5.z; q.xy2d.v[3] = a5.w;
+    q.xy2d.v[4] = a6.x; q.xy2d.v[5] = a6.y; q.xy2d.v[6] = a6.z; q.xy2d.v[7] = a6.w;
+    q.xy2d.v[8] = a7.x; q.xy2d.v[9] = a7.y;
+}
+
+// acc += d * (row's base point), d in [-128, 128]
+__device__ __forceinline__ void tbl_madd(ge_p3& acc, const TableView& t, int row, int d) {
+    ge_niels q;
+    int ad = d < 0 ? -d : d;
+    tbl_load(q, t, row, ad);
+    ge_p3 r;
+    ge_madd(r, acc, q, d < 0);
+    acc = r;
+}
+
+// acc += s * Base for a 255-bit integer s (eight words), using the 32 per-window rows starting at row0.
+__device__ __forceinline__ void tbl_fixed_mul_add(ge_p3& acc, const TableView& t, int row0, const uint32_t* s8) {
+    int carry = 0;
+    for (int i = 0; i < 32; i++) {
+        int b = (int)((s8[i >> 2] >> (8 * (i & 3))) & 0xff) + carry;
+        carry = (b > 127 && i < 31) ? 1 : 0;
+        tbl_madd(acc, t, row0 + i, b - (carry << 8));
+    }
+}
+// acc += v * B for a 64-bit v (nine signed windows)
+__device__ __forceinline__ void tbl_fixed_mul_add_u64(ge_p3& acc, const TableView& t, int row0, uint64_t v) {
+    int carry = 0;
+    for (int i = 0; i < 9; i++) {
+        int b = (i < 8 ? (int)((v >> (8 * i)) & 0xff) : 0) + carry;
+        carry = b > 127 ? 1 : 0;
+        tbl_madd(acc, t, row0 + i, b - (carry << 8));
+    }
+}
+#endif
+
+}  // namespace dapol

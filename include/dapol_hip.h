@@ -1,0 +1,148 @@
+/* dapol_hip.h -- C ABI of the MI355X-native DAPOL+ proving path (libdapol_hip.so).
+ *
+ * The reference crate (MystenLabs/dapol, Rust) exposes no FFI; its seams are Rust traits and generic
+ * parameters.  Each entry point below names the reference interface it replaces (paths relative to the
+ * reference root).  A Rust maintainer binds these with an `extern "C"` block (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *  - every function returns an int32 status (DAPOL_OK == 0); nothing aborts or throws across the boundary;
+ *  - all pointers are caller-owned HOST pointers unless the parameter name ends in `_dev` (device pointers,
+ *    for callers that already keep their arrays in HBM);
+ *  - byte strings are little-endian, 32-byte scalars / compressed ristretto255 points as in curve25519-dalek;
+ *  - a dapol_ctx is bound to one GPU and one HIP stream; use one ctx per host thread / GPU.
+ *
+ * Randomness ("tape") contract: the reference draws from thread_rng() (src/dapol/node.rs:87 and inside
+ * bulletproofs' prover), so its outputs differ run to run.  Here every draw is an explicit input:
+ *  - a WIDE draw is 64 bytes reduced mod l (== Scalar::random);
+ *  - seed mode: draw(domain, a, b) = first 64-byte XOF block of BLAKE3-keyed(seed, LE32 domain|LE64 a|LE64 b);
+ *    padding node at (level above leaves, index): domain 1, a = level, b = index;
+ *    range-proof nonce: domain 2, a = stream id (the leaf's tree index), b = slot;
+ *  - slot order of one aggregated proof with m parties of n bits (the crate's draw order): party j draws
+ *    a_blinding = j(2n+2), s_blinding = j(2n+2)+1, s_L[i] = j(2n+2)+2+i, s_R[i] = j(2n+2)+2+n+i; then
+ *    t1_blinding_j = m(2n+2)+2j, t2_blinding_j = m(2n+2)+2j+1.   m(2n+4) slots in total;
+ *  - tape mode: the same slots read from a caller buffer of 64-byte draws.
+ */
+#ifndef DAPOL_HIP_H
+#define DAPOL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Status codes.  1-5 mirror DapolError (src/errors.rs:6-17); 6-7 mirror smtree DecodingError as used by
+ * src/range/mod.rs:124-161 and src/proof/node.rs:81-102. */
+enum {
+    DAPOL_OK = 0,
+    DAPOL_ERR_TREE_HEIGHT_TOO_BIG = 1,   /* DapolError::TreeHeightTooBig   (src/dapol/mod.rs:104-109) */
+    DAPOL_ERR_SPARSITY_TOO_SMALL = 2,    /* DapolError::SparsityTooSmall   (src/dapol/mod.rs:110-116) */
+    DAPOL_ERR_INVALID_DIGEST_SIZE = 3,   /* DapolError::InvalidDigestSize  (src/dapol/mod.rs:101-103) */
+    DAPOL_ERR_DUPLICATED_INTERNAL_ID = 4,/* DapolError::DuplicatedInternalId (src/dapol/mod.rs:341-343) */
+    DAPOL_ERR_FAILED_TO_MAP_INDEX = 5,   /* DapolError::FailedToMapIndex   (src/dapol/mod.rs:369-370) */
+    DAPOL_ERR_BYTES_NOT_ENOUGH = 6,      /* DecodingError::BytesNotEnough */
+    DAPOL_ERR_VALUE_DECODING = 7,        /* DecodingError::ValueDecodingError */
+    DAPOL_ERR_INVALID_ARGUMENT = 8,      /* where the reference panics: unsorted/duplicate leaves (smtree build),
+                                            aggregation_factor > #siblings (src/range/padding.rs:95-98), bad n/m
+                                            (bulletproofs InvalidBitsize / InvalidAggregation) */
+    DAPOL_ERR_UNKNOWN_LEAF = 9,          /* the `None` of Dapol::generate_proof* (src/dapol/mod.rs:148-190) */
+    DAPOL_ERR_NO_DEVICE = 16,            /* no usable HIP device: the product path never falls back to the CPU */
+    DAPOL_ERR_HIP = 17,                  /* a HIP runtime call failed; see dapol_last_error() */
+    DAPOL_ERR_OUT_OF_MEMORY = 18
+};
+
+typedef struct dapol_ctx dapol_ctx;
+typedef struct dapol_tree dapol_tree;
+
+enum { DAPOL_POLICY_PADDING = 0, DAPOL_POLICY_SPLITTING = 1 };  /* RangeProofPadding / RangeProofSplitting */
+enum { DAPOL_DIGEST_BLAKE3 = 0 };                               /* D = blake3::Hasher (benches/dapol.rs:38) */
+
+/* Replaces the per-call PedersenGens::default() (src/dapol/node.rs:31, src/range/mod.rs:49,65,84,103) and
+ * BulletproofGens::new(64, m) (src/range/mod.rs:50,66,85,104): generators and their window tables are derived
+ * ONCE, on the GPU, for up to max_parties parties of 64 bits.  max_parties must be a power of two <= 1024. */
+int32_t dapol_ctx_create(int32_t device, int32_t max_parties, int32_t digest_id, dapol_ctx** out);
+int32_t dapol_ctx_destroy(dapol_ctx* ctx);
+/* Compressed generators (for cross-checks): which = 0 B, 1 B_blinding, 2 G[party][bit], 3 H[party][bit]. */
+int32_t dapol_ctx_generator(dapol_ctx* ctx, int32_t which, int32_t party, int32_t bit, uint8_t out32[32]);
+const char* dapol_strerror(int32_t code);
+const char* dapol_last_error(void);
+
+/* DapolNode::new (src/dapol/node.rs:29-45), batched: C_i = v_i*B + r_i*B_blinding (compressed), H_i = D(C_i).
+ * r may be an unreduced Scalar::from_bits value (bit 255 clear; src/dapol/mod.rs:385). */
+int32_t dapol_commit_hash_batch(dapol_ctx* ctx, size_t n, const uint64_t* v, const uint8_t* r32, uint8_t* C_out32,
+                                uint8_t* H_out32);
+
+/* Dapol::new_blank + Dapol::build (src/dapol/mod.rs:196-208 -> smtree SparseMerkleTree::build) with the leaf
+ * nodes made by DapolNode::new; also the build half of Dapol::new (src/dapol/mod.rs:100-128).
+ * leaf_idx must be strictly increasing and < 2^height (the reference panics otherwise -> INVALID_ARGUMENT);
+ * enforce_sparsity != 0 applies the 2^height >= 2n check of Dapol::new.  Padding nodes (node.rs:86-88) take
+ * their blinding from pad_seed32 (seed mode, positional). */
+int32_t dapol_tree_build(dapol_ctx* ctx, int32_t height, size_t n, const uint64_t* leaf_idx, const uint64_t* v,
+                         const uint8_t* r32, const uint8_t pad_seed32[32], int32_t enforce_sparsity, dapol_tree** out);
+int32_t dapol_tree_destroy(dapol_tree* tree);
+/* Dapol::root_raw / Dapol::root (src/dapol/mod.rs:134-141). Any out pointer may be NULL. */
+int32_t dapol_tree_root(dapol_tree* tree, uint8_t C32[32], uint8_t H32[32], uint64_t* v, uint8_t r32[32]);
+int32_t dapol_tree_node_count(dapol_tree* tree, uint64_t* real_nodes, uint64_t* padding_nodes);
+/* Every stored node of one level (0 = leaves .. height = root), real nodes first then padding nodes, for
+ * parity tests on small trees.  Arrays sized by dapol_tree_level_size. */
+int32_t dapol_tree_level_size(dapol_tree* tree, int32_t level, uint64_t* n_real, uint64_t* n_pad);
+int32_t dapol_tree_level_nodes(dapol_tree* tree, int32_t level, uint64_t* idx, uint64_t* v, uint8_t* r32, uint8_t* C32,
+                               uint8_t* H32, uint8_t* is_pad);
+/* The sibling half of Dapol::generate_proof_batch for single leaves (src/dapol/mod.rs:172-184): for each of the
+ * b leaves, its `height` siblings root side first: (C, H) = the Merkle path proof nodes, (v, r) = the secrets
+ * handed to R::generate_proof.  Unknown leaf -> DAPOL_ERR_UNKNOWN_LEAF.  Out pointers may be NULL. */
+int32_t dapol_tree_paths(dapol_tree* tree, size_t b, const uint64_t* leaf_idx, uint8_t* sib_C32, uint8_t* sib_H32,
+                         uint64_t* sib_v, uint8_t* sib_r32);
+
+/* generate_aggregated_range_proof / generate_single_range_proof (src/range/mod.rs:48-78 ->
+ * RangeProof::prove_multiple / prove_single), batched over b independent proofs of m parties x n_bits each
+ * (reference: n_bits = 64, src/range/mod.rs:16).  v[b][m], r32[b][m][32];  proofs_out[b][32*(9+2*lg(n_bits*m))].
+ * Nonces: seed mode (nonce_seed32, stream_id[b], slot_base) or tape mode (tape != NULL:
+ * tape[b][m*(2*n_bits+4)][64], slot_base ignored). */
+int32_t dapol_range_prove_batch(dapol_ctx* ctx, int32_t n_bits, int32_t m, size_t b, const uint64_t* v, const uint8_t* r32,
+                                const uint8_t nonce_seed32[32], const uint64_t* stream_id, uint64_t slot_base,
+                                const uint8_t* tape, uint8_t* proofs_out);
+size_t dapol_range_proof_size(int32_t n_bits, int32_t m);
+
+/* verify_aggregated_range_proof / verify_single_range_proof (src/range/mod.rs:83-119 -> verify_multiple), batched:
+ * proofs[b][size], V32[b][m][32] -> ok[b] (1 = verifies).  The verifier's batching scalar c (thread_rng in the
+ * crate) is derived from verify_seed32 and the proof index. */
+int32_t dapol_range_verify_batch(dapol_ctx* ctx, int32_t n_bits, int32_t m, size_t b, const uint8_t* proofs, const uint8_t* V32,
+                                 const uint8_t verify_seed32[32], uint8_t* ok);
+
+/* Dapol::generate_proof for b single leaves (src/dapol/mod.rs:167-190 + R::generate_proof,
+ * src/range/padding.rs:88-118 / src/range/splitting.rs:100-129): gathers each leaf's siblings on the GPU and
+ * proves them under `policy` with `aggregation_factor`.  Outputs, per leaf: the Merkle path proof nodes
+ * (path_C32/path_H32: [b][height][32], root side first; may be NULL) and the range proofs concatenated in
+ * generation order (aggregated proofs, then the individual 672-byte proofs): range_out[b][dapol_entity_proof_size].
+ * stream id of a leaf = its tree index. */
+int32_t dapol_prove_entities(dapol_ctx* ctx, dapol_tree* tree, size_t b, const uint64_t* leaf_idx, int32_t policy,
+                             int32_t aggregation_factor, int32_t n_bits, const uint8_t nonce_seed32[32], uint8_t* path_C32,
+                             uint8_t* path_H32, uint8_t* range_out);
+size_t dapol_entity_proof_size(int32_t height, int32_t policy, int32_t aggregation_factor, int32_t n_bits);
+
+/* Bench / roofline support: device-resident variant of build + prove-all used by bench.py so that the timed
+ * region starts with inputs already in HBM and nothing is copied back.  Handles are opaque device buffers. */
+typedef struct dapol_workload dapol_workload;
+int32_t dapol_workload_create(dapol_ctx* ctx, int32_t height, size_t n, const uint64_t* leaf_idx, const uint64_t* v,
+                              const uint8_t* r32, dapol_workload** out);
+int32_t dapol_workload_destroy(dapol_workload* w);
+/* One pass: tree build + one padding-policy inclusion range proof per entity (aggregation_factor = height).
+ * Returns device time of the two phases in milliseconds (HIP events on the ctx stream), the time and launch
+ * count of the dominant kernel (the fixed-base MSM), and a 64-bit checksum of all proof bytes + the root. */
+typedef struct {
+    double tree_ms, prove_ms, msm_ms;
+    uint64_t msm_launches, proofs, proof_bytes;
+    uint64_t checksum;
+    uint8_t root_C[32], root_H[32];
+} dapol_workload_stats;
+int32_t dapol_workload_run(dapol_workload* w, const uint8_t pad_seed32[32], const uint8_t nonce_seed32[32], int32_t n_bits,
+                           size_t first_entity, size_t n_entities, dapol_workload_stats* stats);
+/* Copies back the proofs of entities [first, first+count) of the last run (count*proof_size bytes). */
+int32_t dapol_workload_proofs(dapol_workload* w, size_t first, size_t count, uint8_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DAPOL_HIP_H */

@@ -1,0 +1,143 @@
+// Test-only shim: compiles the PRODUCT device headers (dapol_amd/csrc/*.h) for the host so that the limb
+// arithmetic, codec, scalar field and hash framing can be checked against oracle/pyref.py without a GPU.
+// Built by tests/conftest.py with g++; never linked into libdapol_hip.so.
+#include <cstring>
+#include "../dapol_amd/csrc/ge.h"
+#include "../dapol_amd/csrc/hash.h"
+#include "../dapol_amd/csrc/sc.h"
+using namespace dapol;
+
+static void ld(uint32_t* w, const uint8_t* b, int n) { memcpy(w, b, 4 * n); }
+static void st(uint8_t* b, const uint32_t* w, int n) { memcpy(b, w, 4 * n); }
+
+extern "C" {
+// op: 0 mul, 1 sq, 2 invert, 3 add-then-mul(f=a+b loose, g=b), 4 (a-b)*(a-b) via sq of tight difference
+void t_fe_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    fe x, y, r;
+    fe_frombytes(x, a);
+    fe_frombytes(y, b);
+    if (op == 0) fe_mul(r, x, y);
+    if (op == 1) fe_sq(r, x);
+    if (op == 2) fe_invert(r, x);
+    if (op == 3) { fe t; fe_add(t, x, y); fe_add(t, t, x); fe_mul(r, t, y); }
+    if (op == 4) { fe t; fe_sub(t, x, y); fe_sq(r, t); }
+    if (op == 5) { fe t; fe_sub(t, x, y); fe_sub(t, t, y); fe_neg(t, t); fe_carry(r, t); }
+    fe_tobytes(out, r);
+}
+// k*B by double-and-add over ge_dbl / ge_add, k = 256-bit little-endian integer
+static void scalarmul(ge_p3& acc, const ge_p3& base, const uint8_t* k) {
+    ge_identity(acc);
+    for (int i = 255; i >= 0; i--) {
+        ge_p3 t;
+        ge_dbl(t, acc, true);
+        acc = t;
+        if ((k[i >> 3] >> (i & 7)) & 1) { ge_add(t, acc, base); acc = t; }
+    }
+}
+void t_basemul(const uint8_t* k, uint8_t* out) {
+    ge_p3 b, acc;
+    ge_basepoint(b);
+    scalarmul(acc, b, k);
+    uint32_t w[8];
+    ge_compress(w, acc);
+    st(out, w, 8);
+}
+// k*P via madd with the affine niels form of P (P given compressed); exercises ge_to_niels + ge_madd(+/-)
+void t_maddmul(const uint8_t* pc, const uint8_t* k, int neg, uint8_t* out) {
+    uint32_t w[8];
+    ld(w, pc, 8);
+    ge_p3 p, acc, t;
+    ge_decompress(p, w);
+    ge_niels q;
+    ge_to_niels(q, p.X, p.Y);   // decompress returns Z = 1
+    ge_identity(acc);
+    for (int i = 255; i >= 0; i--) {
+        ge_dbl(t, acc, true);
+        acc = t;
+        if ((k[i >> 3] >> (i & 7)) & 1) { ge_madd(t, acc, q, neg != 0); acc = t; }
+    }
+    ge_compress(w, acc);
+    st(out, w, 8);
+}
+int t_decompress(const uint8_t* in, uint8_t* out) {
+    uint32_t w[8];
+    ld(w, in, 8);
+    ge_p3 p;
+    bool ok = ge_decompress(p, w);
+    ge_compress(w, p);
+    st(out, w, 8);
+    return ok;
+}
+void t_from_uniform(const uint8_t* in64, uint8_t* out) {
+    uint32_t w[16], o[8];
+    ld(w, in64, 16);
+    ge_p3 p;
+    ge_from_uniform(p, w);
+    ge_compress(o, p);
+    st(out, o, 8);
+}
+// scalar ops on canonical / arbitrary 32-byte inputs; op: 0 mul, 1 add, 2 sub, 3 invert(a)
+void t_sc_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    uint32_t wa[8], wb[8], o[8];
+    ld(wa, a, 8);
+    ld(wb, b, 8);
+    sc x, y, r;
+    sc_to_mont(x, wa);
+    sc_to_mont(y, wb);
+    if (op == 0) sc_montmul(r, x, y);
+    if (op == 1) sc_add(r, x, y);
+    if (op == 2) sc_sub(r, x, y);
+    if (op == 3) sc_invert_mont(r, x);
+    sc_from_mont(o, r);
+    st(out, o, 8);
+}
+void t_sc_from_wide(const uint8_t* in64, uint8_t* out) {
+    uint32_t w[16], o[8];
+    ld(w, in64, 16);
+    sc r;
+    sc_from_wide(r, w);
+    sc_from_mont(o, r);
+    st(out, o, 8);
+}
+void t_sc_recode(const uint8_t* in, int16_t* d) {
+    uint32_t w[8];
+    ld(w, in, 8);
+    sc_recode_s8(d, w);
+}
+void t_blake3_32(const uint8_t* in, uint8_t* out) {
+    uint32_t w[8], o[8];
+    ld(w, in, 8);
+    blake3_hash32(o, w);
+    st(out, o, 8);
+}
+void t_blake3_128(const uint8_t* in, uint8_t* out) {
+    uint32_t w[32], o[8];
+    ld(w, in, 32);
+    blake3_hash128(o, w, w + 8, w + 16, w + 24);
+    st(out, o, 8);
+}
+void t_seed_wide(const uint8_t* seed, uint32_t dom, uint64_t a, uint64_t b, uint8_t* out64) {
+    uint32_t s[8], o[16];
+    ld(s, seed, 8);
+    seed_wide(o, s, dom, a, b);
+    st(out64, o, 16);
+}
+// Merlin "test protocol" vector and a challenge_scalar-shaped 64-byte squeeze
+void t_merlin(const char* app, int app_len, const char* label, int ll, const char* msg, int ml, const char* cl, int cll,
+              uint8_t* out64) {
+    Strobe s;
+    merlin_init(s, app, app_len);
+    merlin_append_bytes(s, label, ll, msg, ml);
+    uint32_t w[16];
+    merlin_challenge_wide(s, cl, cll, w);
+    st(out64, w, 16);
+}
+// SHAKE256 / SHA3-512 through the generic sponge
+void t_sponge(int rate, int domain, const uint8_t* in, int n, uint8_t* out, int outlen) {
+    Sponge sp;
+    sponge_init(sp, rate);
+    for (int i = 0; i < n; i++) sponge_absorb_byte(sp, in[i]);
+    sponge_finish(sp, (uint8_t)domain);
+    for (int i = 0; i < outlen; i++) out[i] = sponge_squeeze_byte(sp);
+}
+}
