@@ -36,6 +36,8 @@ _SIG = {
     "dapol_last_error": (ctypes.c_char_p, []),
     "dapol_commit_hash_batch": (ctypes.c_int32, [_P, ctypes.c_size_t, _P, _P, _P, _P]),
     "dapol_tree_build": (ctypes.c_int32, [_P, ctypes.c_int32, ctypes.c_size_t, _P, _P, _P, _P, ctypes.c_int32, ctypes.POINTER(_P)]),
+    "dapol_tree_build_shard": (ctypes.c_int32, [_P, ctypes.c_int32, ctypes.c_int32, ctypes.c_size_t, _P, _P, _P, _P, ctypes.POINTER(_P)]),
+    "dapol_merge_batch": (ctypes.c_int32, [_P, ctypes.c_size_t] + [_P] * 12),
     "dapol_tree_destroy": (ctypes.c_int32, [_P]),
     "dapol_tree_root": (ctypes.c_int32, [_P, _P, _P, _P, _P]),
     "dapol_tree_node_count": (ctypes.c_int32, [_P, _P, _P]),
@@ -47,7 +49,14 @@ _SIG = {
     "dapol_range_verify_batch": (ctypes.c_int32, [_P, ctypes.c_int32, ctypes.c_int32, ctypes.c_size_t, _P, _P, _P, _P]),
     "dapol_prove_entities": (ctypes.c_int32, [_P, _P, ctypes.c_size_t, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P, _P, _P, _P]),
     "dapol_entity_proof_size": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
+    "dapol_prove_entities_upper": (ctypes.c_int32, [_P, _P, ctypes.c_size_t, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P, ctypes.c_int32,
+                                                    _P, _P, _P, _P, _P, _P, _P]),
     "dapol_workload_create": (ctypes.c_int32, [_P, ctypes.c_int32, ctypes.c_size_t, _P, _P, _P, ctypes.POINTER(_P)]),
+    "dapol_workload_create_shard": (ctypes.c_int32, [_P, ctypes.c_int32, ctypes.c_int32, ctypes.c_size_t, _P, _P, _P, ctypes.POINTER(_P)]),
+    "dapol_workload_build": (ctypes.c_int32, [_P, _P, _P, _P, _P, _P, ctypes.POINTER(WorkloadStats)]),
+    "dapol_workload_prove": (ctypes.c_int32, [_P, _P, ctypes.c_int32, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int32, _P, _P, _P, _P,
+                                              ctypes.POINTER(WorkloadStats)]),
+    "dapol_workload_paths": (ctypes.c_int32, [_P, ctypes.c_size_t, _P, ctypes.c_int32, _P, _P, _P, _P]),
     "dapol_workload_destroy": (ctypes.c_int32, [_P]),
     "dapol_workload_run": (ctypes.c_int32, [_P, _P, _P, ctypes.c_int32, ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(WorkloadStats)]),
     "dapol_workload_proofs": (ctypes.c_int32, [_P, ctypes.c_size_t, ctypes.c_size_t, _P]),
@@ -122,6 +131,21 @@ class Context:
         _chk(lib().dapol_commit_hash_batch(self.h, n, _ptr(v), _ptr(r32), _ptr(C), _ptr(H)))
         return C, H
 
+    def merge_batch(self, CL, HL, CR, HR, vL=None, rL=None, vR=None, rR=None):
+        """Mergeable::merge on compressed records; returns (C, H) or (C, H, v, r) when the secrets are given."""
+        CL = _u8(CL).reshape(-1, 32)
+        n = CL.shape[0]
+        HL, CR, HR = _u8(HL, n, 32), _u8(CR, n, 32), _u8(HR, n, 32)
+        C, H = np.zeros((n, 32), np.uint8), np.zeros((n, 32), np.uint8)
+        if vL is None:
+            _chk(lib().dapol_merge_batch(self.h, n, _ptr(CL), _ptr(HL), None, None, _ptr(CR), _ptr(HR), None, None, _ptr(C), _ptr(H), None, None))
+            return C, H
+        vL, vR, rL, rR = _u64(vL), _u64(vR), _u8(rL, n, 32), _u8(rR, n, 32)
+        v, r = np.zeros(n, np.uint64), np.zeros((n, 32), np.uint8)
+        _chk(lib().dapol_merge_batch(self.h, n, _ptr(CL), _ptr(HL), _ptr(vL), _ptr(rL), _ptr(CR), _ptr(HR), _ptr(vR), _ptr(rR), _ptr(C), _ptr(H),
+                                     _ptr(v), _ptr(r)))
+        return C, H, v, r
+
     def range_prove_batch(self, n_bits, m, v, r32, nonce_seed=None, stream_id=None, slot_base=0, tape=None):
         v = _u64(v).reshape(-1, m)
         b = v.shape[0]
@@ -147,14 +171,18 @@ class Context:
 class Tree:
     """dapol_tree: the sparse Merkle sum tree resident in HBM."""
 
-    def __init__(self, ctx, height, leaf_idx, v, r32, pad_seed, enforce_sparsity=False):
-        self.ctx, self.height = ctx, height
+    def __init__(self, ctx, height, leaf_idx, v, r32, pad_seed, enforce_sparsity=False, shard_bits=0):
+        """height = total tree height; shard_bits > 0 builds only the subtree holding the (global-index) leaves."""
+        self.ctx, self.height, self.shard_bits = ctx, height - shard_bits, shard_bits
         leaf_idx, v = _u64(leaf_idx), _u64(v)
         n = leaf_idx.shape[0]
         r32 = _u8(r32, n, 32)
         seed = _u8(np.frombuffer(pad_seed, np.uint8))
         self.h = _P()
-        _chk(lib().dapol_tree_build(ctx.h, height, n, _ptr(leaf_idx), _ptr(v), _ptr(r32), _ptr(seed), int(enforce_sparsity), ctypes.byref(self.h)))
+        if shard_bits:
+            _chk(lib().dapol_tree_build_shard(ctx.h, height, shard_bits, n, _ptr(leaf_idx), _ptr(v), _ptr(r32), _ptr(seed), ctypes.byref(self.h)))
+        else:
+            _chk(lib().dapol_tree_build(ctx.h, height, n, _ptr(leaf_idx), _ptr(v), _ptr(r32), _ptr(seed), int(enforce_sparsity), ctypes.byref(self.h)))
 
     def close(self):
         if self.h:
@@ -196,27 +224,35 @@ class Tree:
         _chk(lib().dapol_tree_paths(self.h, b, _ptr(leaf_idx), _ptr(C), _ptr(H), _ptr(v), _ptr(r)))
         return C, H, v, r
 
-    def prove_entities(self, leaf_idx, policy, aggregation_factor, n_bits, nonce_seed):
+    def prove_entities(self, leaf_idx, policy, aggregation_factor, n_bits, nonce_seed, upper=None):
+        """upper = (C[u,32], H[u,32], v[u], r[u,32]) siblings above a shard root, root side first."""
         leaf_idx = _u64(leaf_idx)
-        b, h = leaf_idx.shape[0], self.height
+        nu = 0 if upper is None else len(upper[2])
+        b, h = leaf_idx.shape[0], self.height + nu
         es = lib().dapol_entity_proof_size(h, policy, aggregation_factor, n_bits)
         C, H = np.zeros((b, h, 32), np.uint8), np.zeros((b, h, 32), np.uint8)
         out = np.zeros((b, max(es, 1)), np.uint8)
         seed = _u8(np.frombuffer(nonce_seed, np.uint8))
-        _chk(lib().dapol_prove_entities(self.ctx.h, self.h, b, _ptr(leaf_idx), policy, aggregation_factor, n_bits, _ptr(seed), _ptr(C), _ptr(H), _ptr(out)))
+        if nu:
+            uC, uH, uv, ur = _u8(upper[0], nu, 32), _u8(upper[1], nu, 32), _u64(upper[2]), _u8(upper[3], nu, 32)
+            _chk(lib().dapol_prove_entities_upper(self.ctx.h, self.h, b, _ptr(leaf_idx), policy, aggregation_factor, n_bits, _ptr(seed), nu,
+                                                  _ptr(uC), _ptr(uH), _ptr(uv), _ptr(ur), _ptr(C), _ptr(H), _ptr(out)))
+        else:
+            _chk(lib().dapol_prove_entities(self.ctx.h, self.h, b, _ptr(leaf_idx), policy, aggregation_factor, n_bits, _ptr(seed), _ptr(C), _ptr(H), _ptr(out)))
         return C, H, out
 
 
 class Workload:
-    """Device-resident bench workload: leaves uploaded once, every run() = tree build + one proof per entity."""
+    """Device-resident bench workload: leaves uploaded once; build() = tree (or shard subtree) build, prove() = one
+    padding-policy proof per entity with aggregation_factor = total height."""
 
-    def __init__(self, ctx, height, leaf_idx, v, r32):
-        self.ctx, self.height = ctx, height
+    def __init__(self, ctx, height, leaf_idx, v, r32, shard_bits=0):
+        self.ctx, self.height, self.shard_bits = ctx, height, shard_bits
         leaf_idx, v = _u64(leaf_idx), _u64(v)
         self.n = leaf_idx.shape[0]
         r32 = _u8(r32, self.n, 32)
         self.h = _P()
-        _chk(lib().dapol_workload_create(ctx.h, height, self.n, _ptr(leaf_idx), _ptr(v), _ptr(r32), ctypes.byref(self.h)))
+        _chk(lib().dapol_workload_create_shard(ctx.h, height, shard_bits, self.n, _ptr(leaf_idx), _ptr(v), _ptr(r32), ctypes.byref(self.h)))
 
     def close(self):
         if self.h:
@@ -229,12 +265,38 @@ class Workload:
         except Exception:
             pass
 
-    def run(self, pad_seed, nonce_seed, n_bits=64, first=0, count=None):
+    def build(self, pad_seed, stats=None):
+        st = stats if stats is not None else WorkloadStats()
+        ps = _u8(np.frombuffer(pad_seed, np.uint8))
+        C, H, r, v = np.zeros(32, np.uint8), np.zeros(32, np.uint8), np.zeros(32, np.uint8), np.zeros(1, np.uint64)
+        _chk(lib().dapol_workload_build(self.h, _ptr(ps), _ptr(C), _ptr(H), _ptr(v), _ptr(r), ctypes.byref(st)))
+        return (C.tobytes(), H.tobytes(), int(v[0]), r.tobytes()), st
+
+    def prove(self, nonce_seed, n_bits=64, first=0, count=None, upper=None, stats=None):
+        st = stats if stats is not None else WorkloadStats()
         count = self.n - first if count is None else count
-        st = WorkloadStats()
-        ps, ns = _u8(np.frombuffer(pad_seed, np.uint8)), _u8(np.frombuffer(nonce_seed, np.uint8))
-        _chk(lib().dapol_workload_run(self.h, _ptr(ps), _ptr(ns), n_bits, first, count, ctypes.byref(st)))
+        ns = _u8(np.frombuffer(nonce_seed, np.uint8))
+        if upper is None or len(upper[2]) == 0:
+            _chk(lib().dapol_workload_prove(self.h, _ptr(ns), n_bits, first, count, 0, None, None, None, None, ctypes.byref(st)))
+        else:
+            nu = len(upper[2])
+            uC, uH, uv, ur = _u8(upper[0], nu, 32), _u8(upper[1], nu, 32), _u64(upper[2]), _u8(upper[3], nu, 32)
+            _chk(lib().dapol_workload_prove(self.h, _ptr(ns), n_bits, first, count, nu, _ptr(uC), _ptr(uH), _ptr(uv), _ptr(ur), ctypes.byref(st)))
         return st
+
+    def run(self, pad_seed, nonce_seed, n_bits=64, first=0, count=None):
+        _, st = self.build(pad_seed)
+        return self.prove(nonce_seed, n_bits, first, count, stats=st)
+
+    def paths(self, leaf_idx, upper=None):
+        leaf_idx = _u64(leaf_idx)
+        b = leaf_idx.shape[0]
+        nu = 0 if upper is None else len(upper[2])
+        sv, sr = np.zeros((b, self.height), np.uint64), np.zeros((b, self.height, 32), np.uint8)
+        uv = _u64(upper[2]) if nu else None
+        ur = _u8(upper[3], nu, 32) if nu else None
+        _chk(lib().dapol_workload_paths(self.h, b, _ptr(leaf_idx), nu, _ptr(uv), _ptr(ur), _ptr(sv), _ptr(sr)))
+        return sv, sr
 
     def proofs(self, first, count, proof_size):
         out = np.zeros((count, proof_size), np.uint8)

@@ -215,9 +215,10 @@ struct dapol_tree {
 
 // Builds the tree from device-resident leaf arrays (d_idx sorted; d_r is masked in place).  own==true: the tree
 // takes ownership of nothing; leaf arrays must outlive it (they are owned by the caller-side holder below).
-static int32_t tree_build_device(dapol_ctx* ctx, int height, size_t n, uint64_t* d_idx, uint64_t* d_v, uint32_t* d_r,
+static int32_t tree_build_device(dapol_ctx* ctx, int index_bits, int shard_bits, size_t n, uint64_t* d_idx, uint64_t* d_v, uint32_t* d_r,
                                  const uint8_t pad_seed32[32], dapol_tree* t) {
     hipStream_t st = ctx->stream;
+    const int height = index_bits - shard_bits;       // levels built on this GPU
     t->ctx = ctx;
     t->height = height;
     t->leaf_idx = d_idx; t->leaf_v = d_v; t->leaf_r = d_r;
@@ -229,12 +230,12 @@ static int32_t tree_build_device(dapol_ctx* ctx, int height, size_t n, uint64_t*
     HIPCHK(bad.alloc(1)); HIPCHK(seed.alloc(8)); HIPCHK(total.alloc(1));
     HIPCHK(hipMemsetAsync(bad.p, 0, 4, st));
     HIPCHK(hipMemcpyAsync(seed.p, pad_seed32, 32, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_tree_check_leaves, dim3(nblk(n, 256)), dim3(256), 0, st, n, d_idx, height, bad.p);
+    hipLaunchKernelGGL(k_tree_check_leaves, dim3(nblk(n, 256)), dim3(256), 0, st, n, d_idx, index_bits, height, bad.p);
     LAUNCH_CHECK();
     uint32_t h_bad = 0;
     HIPCHK(hipMemcpyAsync(&h_bad, bad.p, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    if (h_bad) return fail(DAPOL_ERR_INVALID_ARGUMENT, "leaf indexes must be strictly increasing and below 2^height");
+    if (h_bad) return fail(DAPOL_ERR_INVALID_ARGUMENT, "leaf indexes must be strictly increasing, below 2^height, and (shard build) share their top shard_bits bits");
     HIPCHK(flag.alloc(n)); HIPCHK(pos.alloc(n)); HIPCHK(head.alloc(n)); HIPCHK(bsums.alloc(nblk(n, 1024) + 1));
     DevBuf<int32_t> ext_a, ext_b;
     HIPCHK(ext_a.alloc(n * 40)); HIPCHK(ext_b.alloc(n * 40));
@@ -296,10 +297,100 @@ int32_t dapol_tree_build(dapol_ctx* ctx, int32_t height, size_t n, const uint64_
     HIPCHK(hipMemcpyAsync(t->leaves.idx.p, leaf_idx, n * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(t->leaves.v.p, v, n * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(t->leaves.r.p, r32, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    int32_t rc = tree_build_device(ctx, height, n, t->leaves.idx.p, t->leaves.v.p, t->leaves.r.p, pad_seed32, t);
+    int32_t rc = tree_build_device(ctx, height, 0, n, t->leaves.idx.p, t->leaves.v.p, t->leaves.r.p, pad_seed32, t);
     if (rc != DAPOL_OK) return rc;
     guard.t = nullptr;
     *out = t;
+    return DAPOL_OK;
+}
+
+int32_t dapol_tree_build_shard(dapol_ctx* ctx, int32_t total_height, int32_t shard_bits, size_t n, const uint64_t* leaf_idx,
+                               const uint64_t* v, const uint8_t* r32, const uint8_t pad_seed32[32], dapol_tree** out) {
+    if (!ctx || !out || !pad_seed32 || !n || !leaf_idx || !v || !r32) return fail(DAPOL_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (total_height < 0 || total_height > 64) return fail(DAPOL_ERR_TREE_HEIGHT_TOO_BIG, "tree height must not exceed 64");
+    if (shard_bits < 0 || shard_bits > total_height || shard_bits > 16) return fail(DAPOL_ERR_INVALID_ARGUMENT, "shard_bits out of range");
+    if (n > (size_t)1 << 24) return fail(DAPOL_ERR_INVALID_ARGUMENT, "at most 2^24 leaves per GPU");
+    HIPCHK(hipSetDevice(ctx->device));
+    dapol_tree_owned* t = new dapol_tree_owned();
+    struct Guard { dapol_tree* t; ~Guard() { if (t) dapol_tree_destroy(t); } } guard{t};
+    HIPCHK(t->leaves.idx.alloc(n)); HIPCHK(t->leaves.v.alloc(n)); HIPCHK(t->leaves.r.alloc(n * 8));
+    HIPCHK(hipMemcpyAsync(t->leaves.idx.p, leaf_idx, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(t->leaves.v.p, v, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(t->leaves.r.p, r32, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    int32_t rc = tree_build_device(ctx, total_height, shard_bits, n, t->leaves.idx.p, t->leaves.v.p, t->leaves.r.p, pad_seed32, t);
+    if (rc != DAPOL_OK) return rc;
+    guard.t = nullptr;
+    *out = t;
+    return DAPOL_OK;
+}
+
+// Mergeable::merge on compressed records
+__global__ void k_merge_records(size_t n, const uint32_t* CL, const uint32_t* HL, const uint64_t* vL, const uint32_t* rL,
+                                const uint32_t* CR, const uint32_t* HR, const uint64_t* vR, const uint32_t* rR, uint32_t* C, uint32_t* H,
+                                uint64_t* v, uint32_t* r, uint32_t* bad) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t cl[8], cr[8], hl[8], hr[8], cp[8], hp[8];
+    ld8(cl, CL + i * 8); ld8(cr, CR + i * 8); ld8(hl, HL + i * 8); ld8(hr, HR + i * 8);
+    ge_p3 a, b, p;
+    bool ok = ge_decompress(a, cl) & ge_decompress(b, cr);
+    if (!ok) { atomicOr(bad, 1u); return; }
+    ge_add(p, a, b);
+    ge_compress(cp, p);
+    blake3_hash128(hp, cl, cr, hl, hr);
+    st8(C + i * 8, cp);
+    st8(H + i * 8, hp);
+    if (v) {
+        uint32_t ra[8], rb[8], rp[8];
+        ld8(ra, rL + i * 8); ld8(rb, rR + i * 8);
+        sc ma, mb, ms;
+        sc_to_mont(ma, ra); sc_to_mont(mb, rb); sc_add(ms, ma, mb); sc_from_mont(rp, ms);
+        st8(r + i * 8, rp);
+        v[i] = vL[i] + vR[i];
+    }
+}
+
+int32_t dapol_merge_batch(dapol_ctx* ctx, size_t n, const uint8_t* CL32, const uint8_t* HL32, const uint64_t* vL, const uint8_t* rL32,
+                          const uint8_t* CR32, const uint8_t* HR32, const uint64_t* vR, const uint8_t* rR32, uint8_t* C32, uint8_t* H32,
+                          uint64_t* v, uint8_t* r32) {
+    if (!ctx || (n && (!CL32 || !HL32 || !CR32 || !HR32 || !C32 || !H32))) return fail(DAPOL_ERR_INVALID_ARGUMENT, "null argument");
+    bool with_secrets = vL || rL32 || vR || rR32 || v || r32;
+    if (with_secrets && !(vL && rL32 && vR && rR32 && v && r32)) return fail(DAPOL_ERR_INVALID_ARGUMENT, "v/r pointers must be all set or all null");
+    if (n == 0) return DAPOL_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    DevBuf<uint32_t> d[8], bad;
+    DevBuf<uint64_t> dv[3];
+    for (auto& x : d) HIPCHK(x.alloc(n * 8));
+    HIPCHK(bad.alloc(1));
+    HIPCHK(hipMemsetAsync(bad.p, 0, 4, st));
+    HIPCHK(hipMemcpyAsync(d[0].p, CL32, n * 32, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d[1].p, HL32, n * 32, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d[2].p, CR32, n * 32, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d[3].p, HR32, n * 32, hipMemcpyHostToDevice, st));
+    if (with_secrets) {
+        for (auto& x : dv) HIPCHK(x.alloc(n));
+        HIPCHK(hipMemcpyAsync(d[4].p, rL32, n * 32, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(d[5].p, rR32, n * 32, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(dv[0].p, vL, n * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(dv[1].p, vR, n * 8, hipMemcpyHostToDevice, st));
+    }
+    DevBuf<uint32_t> oC, oH;
+    HIPCHK(oC.alloc(n * 8)); HIPCHK(oH.alloc(n * 8));
+    hipLaunchKernelGGL(k_merge_records, dim3(nblk(n, 64)), dim3(64), 0, st, n, d[0].p, d[1].p, with_secrets ? dv[0].p : nullptr, d[4].p,
+                       d[2].p, d[3].p, with_secrets ? dv[1].p : nullptr, d[5].p, oC.p, oH.p, with_secrets ? dv[2].p : nullptr, d[6].p, bad.p);
+    LAUNCH_CHECK();
+    uint32_t h_bad = 0;
+    HIPCHK(hipMemcpyAsync(&h_bad, bad.p, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(C32, oC.p, n * 32, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(H32, oH.p, n * 32, hipMemcpyDeviceToHost, st));
+    if (with_secrets) {
+        HIPCHK(hipMemcpyAsync(v, dv[2].p, n * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(r32, d[6].p, n * 32, hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    if (h_bad) return fail(DAPOL_ERR_VALUE_DECODING, "Not the canonical encoding of a point.");
     return DAPOL_OK;
 }
 
@@ -386,7 +477,7 @@ int32_t dapol_tree_level_nodes(dapol_tree* tree, int32_t level, uint64_t* idx, u
 }
 
 // Gathers the siblings of b leaves into device buffers (any of which may be null).
-static int32_t tree_paths_device(dapol_tree* tree, size_t b, const uint64_t* d_leaf_idx, PathOut out, uint32_t* d_pos) {
+static int32_t tree_paths_device(dapol_tree* tree, size_t b, const uint64_t* d_leaf_idx, PathOut out, uint32_t* d_pos, int n_upper = 0) {
     hipStream_t st = tree->ctx->stream;
     DevBuf<uint32_t> missing;
     HIPCHK(missing.alloc(1));
@@ -399,7 +490,7 @@ static int32_t tree_paths_device(dapol_tree* tree, size_t b, const uint64_t* d_l
     HIPCHK(hipStreamSynchronize(st));
     if (h_missing) return fail(DAPOL_ERR_UNKNOWN_LEAF, "no liability at one of the requested leaves");
     for (int k = 0; k < tree->height; k++) {
-        hipLaunchKernelGGL(k_tree_path_level, dim3(nblk(b, 256)), dim3(256), 0, st, b, d_pos, tree->view(k, nullptr), k, tree->height, out);
+        hipLaunchKernelGGL(k_tree_path_level, dim3(nblk(b, 256)), dim3(256), 0, st, b, d_pos, tree->view(k, nullptr), k, tree->height, n_upper, out);
         LAUNCH_CHECK();
     }
     return DAPOL_OK;

@@ -277,10 +277,11 @@ __global__ __launch_bounds__(256) void k_tree_merge(TableView tbl, LevelView cur
 }
 
 // Validation of the leaf index array: strictly increasing and below 2^height (smtree panics otherwise).
-__global__ void k_tree_check_leaves(size_t n, const uint64_t* idx, int height, uint32_t* bad) {
+__global__ void k_tree_check_leaves(size_t n, const uint64_t* idx, int index_bits, int levels, uint32_t* bad) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    bool b = (height < 64 && (idx[i] >> height) != 0) || (i > 0 && idx[i] <= idx[i - 1]);
+    bool b = (index_bits < 64 && (idx[i] >> index_bits) != 0) || (i > 0 && idx[i] <= idx[i - 1]);
+    if (levels < 64 && (idx[i] >> levels) != (idx[0] >> levels)) b = true;     // all leaves in one shard subtree
     if (b) atomicOr(bad, 1u);
 }
 
@@ -304,12 +305,12 @@ __global__ void k_tree_find_leaves(size_t b, const uint64_t* want, size_t n, con
     else { pos[t] = 0xffffffffu; atomicOr(missing, 1u); }
 }
 // Walk one level for all proofs: writes the sibling of each proof's current node and moves to the parent.
-__global__ void k_tree_path_level(size_t b, uint32_t* pos, LevelView lv, int level, int height, PathOut out) {
+__global__ void k_tree_path_level(size_t b, uint32_t* pos, LevelView lv, int level, int height, int n_upper, PathOut out) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= b) return;
     uint32_t p = pos[t];
     if (p == 0xffffffffu) return;
-    size_t slot = t * (size_t)height + (size_t)(height - 1 - level);
+    size_t slot = t * (size_t)(height + n_upper) + (size_t)(n_upper + height - 1 - level);
     uint32_t c[8], h[8], r[8];
     uint64_t v = 0;
     if (lv.has_pad[p]) {
@@ -328,6 +329,20 @@ __global__ void k_tree_path_level(size_t b, uint32_t* pos, LevelView lv, int lev
     if (out.v) out.v[slot] = v;
     if (out.r) st8(out.r + slot * 8, r);
     pos[t] = lv.parent[p];
+}
+// Siblings above a shard root are the same for every leaf of the shard: broadcast them into slots [0, n_upper).
+__global__ void k_tree_path_upper(size_t b, int height, int n_upper, const uint32_t* uC, const uint32_t* uH, const uint64_t* uv,
+                                  const uint32_t* ur, PathOut out) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= b * (size_t)n_upper) return;
+    size_t e = t / n_upper;
+    int u = (int)(t - e * n_upper);
+    size_t slot = e * (size_t)(height + n_upper) + u;
+    uint32_t w[8];
+    if (out.C) { ld8(w, uC + u * 8); st8(out.C + slot * 8, w); }
+    if (out.H) { ld8(w, uH + u * 8); st8(out.H + slot * 8, w); }
+    if (out.v) out.v[slot] = uv[u];
+    if (out.r) { ld8(w, ur + u * 8); st8(out.r + slot * 8, w); }
 }
 
 }  // namespace dapol

@@ -1,0 +1,99 @@
+"""Multi-GPU sharding of the proving path: one process per GPU, each owning one top-level
+subtree of the sparse Merkle tree.  The only exchange step is an all-gather of the G subtree-root records
+(C, H, v, r: 104 bytes each) over torch.distributed (RCCL on ROCm); every rank then merges the log2 G replicated
+top levels itself and proves its own entities.  A final all-reduce sums the per-rank proof checksums.
+
+Indices stay global everywhere, so padding-node seeds and nonce stream ids -- and therefore every byte -- equal
+the single-GPU result (tests/test_sharded.py emulates G shards on one device and checks exactly that)."""
+import numpy as np
+
+from . import capi
+
+RECORD_BYTES = 32 + 32 + 8 + 32
+
+
+def pack_record(root):
+    C, H, v, r = root
+    return np.frombuffer(C + H + int(v).to_bytes(8, "little") + r, np.uint8).copy()
+
+
+def unpack_records(buf, g):
+    buf = np.asarray(buf, np.uint8).reshape(g, RECORD_BYTES)
+    C, H = buf[:, :32].copy(), buf[:, 32:64].copy()
+    v = np.array([int.from_bytes(buf[i, 64:72].tobytes(), "little") for i in range(g)], np.uint64)
+    r = buf[:, 72:104].copy()
+    return C, H, v, r
+
+
+def exchange_records(dist, torch, record, world, device):
+    """All-gather of the per-rank subtree-root records, in rank order: the one layer-boundary exchange of the path."""
+    mine = torch.from_numpy(np.ascontiguousarray(record, np.uint8)).to(device)
+    allr = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    return torch.stack(allr).cpu().numpy()
+
+
+def top_levels(ctx, records, rank, merge=None):
+    """Merges the G subtree roots up to the global root (Mergeable::merge on the GPU, dapol_merge_batch) and returns
+    (root record, upper siblings of `rank`, root side first).  G must be a power of two and every shard non-empty.
+    `merge` overrides the merge primitive (CPU tests plug the oracle in; the product path always uses the GPU)."""
+    merge = merge or ctx.merge_batch
+    C, H, v, r = records
+    g = C.shape[0]
+    assert g & (g - 1) == 0
+    sib = []
+    pos = rank
+    while g > 1:
+        s = pos ^ 1
+        sib.append((C[s].copy(), H[s].copy(), int(v[s]), r[s].copy()))
+        C, H, v, r = merge(C[0::2], H[0::2], C[1::2], H[1::2], v[0::2], r[0::2], v[1::2], r[1::2])
+        g //= 2
+        pos //= 2
+    sib.reverse()
+    upper = (np.array([x[0] for x in sib], np.uint8).reshape(-1, 32), np.array([x[1] for x in sib], np.uint8).reshape(-1, 32),
+             np.array([x[2] for x in sib], np.uint64), np.array([x[3] for x in sib], np.uint8).reshape(-1, 32))
+    return (C[0].tobytes(), H[0].tobytes(), int(v[0]), r[0].tobytes()), upper
+
+
+class ShardedProver:
+    """bench.py's step: build this rank's subtree, exchange roots, prove this rank's entities."""
+
+    def __init__(self, ctx, height, leaf_idx, v, r32, rank=0, world=1, dist=None, torch=None):
+        assert world & (world - 1) == 0, "number of GPUs must be a power of two"
+        self.ctx, self.height, self.rank, self.world, self.dist, self.torch = ctx, height, rank, world, dist, torch
+        self.shard_bits = world.bit_length() - 1
+        self.idx = np.ascontiguousarray(leaf_idx, np.uint64)
+        self.w = capi.Workload(ctx, height, leaf_idx, v, r32, shard_bits=self.shard_bits)
+        self.upper = None
+        self.root = None
+
+    def _exchange(self, root):
+        if self.world == 1:
+            self.root, self.upper = root, None
+            return
+        buf = exchange_records(self.dist, self.torch, pack_record(root), self.world, "cuda")   # RCCL over xGMI
+        recs = unpack_records(buf, self.world)
+        self.root, self.upper = top_levels(self.ctx, recs, self.rank)
+
+    def step(self, pad_seed, nonce_seed, n_bits=64):
+        root, st = self.w.build(pad_seed)
+        self._exchange(root)
+        st = self.w.prove(nonce_seed, n_bits, upper=self.upper, stats=st)
+        if self.world > 1:
+            t = self.torch
+            # final reduce of the aggregated proof transcript checksum (wrapping 64-bit sum, carried as two 32-bit halves)
+            cs = t.tensor([st.checksum & 0xFFFFFFFF, st.checksum >> 32], dtype=t.int64, device="cuda")
+            self.dist.all_reduce(cs)
+            st.checksum = (int(cs[0].item()) + (int(cs[1].item()) << 32)) & 0xFFFFFFFFFFFFFFFF
+        return st
+
+    def sample_paths(self, leaf_ids, pad_seed):
+        return self.w.paths(leaf_ids, upper=self.upper)
+
+    def sample_proofs(self, leaf_ids, proof_size):
+        """Proofs of the given leaves from the last step (leaf_ids must be leaves of this rank, any order)."""
+        pos = np.searchsorted(self.idx, np.ascontiguousarray(leaf_ids, np.uint64))
+        out = np.zeros((len(pos), proof_size), np.uint8)
+        for k, p in enumerate(pos):
+            out[k] = self.w.proofs(int(p), 1, proof_size)[0]
+        return out

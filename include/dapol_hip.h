@@ -80,6 +80,19 @@ int32_t dapol_commit_hash_batch(dapol_ctx* ctx, size_t n, const uint64_t* v, con
  * their blinding from pad_seed32 (seed mode, positional). */
 int32_t dapol_tree_build(dapol_ctx* ctx, int32_t height, size_t n, const uint64_t* leaf_idx, const uint64_t* v,
                          const uint8_t* r32, const uint8_t pad_seed32[32], int32_t enforce_sparsity, dapol_tree** out);
+/* Multi-GPU sharding: builds only the subtree that holds all the given leaves, i.e. the
+ * lowest (total_height - shard_bits) levels; every leaf index (GLOBAL, < 2^total_height) must share its top
+ * shard_bits bits.  Padding seeds and nonce stream ids use the global indexes, so the nodes equal the ones a
+ * single-GPU build of the whole tree produces.  dapol_tree_root then returns the subtree root. */
+int32_t dapol_tree_build_shard(dapol_ctx* ctx, int32_t total_height, int32_t shard_bits, size_t n, const uint64_t* leaf_idx,
+                               const uint64_t* v, const uint8_t* r32, const uint8_t pad_seed32[32], dapol_tree** out);
+/* Mergeable::merge (src/dapol/node.rs:64-80; the (C,H) half is DapolProofNode::merge, src/proof/node.rs:56-69),
+ * batched on compressed inputs: parent[i] = merge(left[i], right[i]).  Used for the replicated top levels above
+ * the shard roots and by the Merkle-path re-merge of verification.  v/r pointers may all be NULL ((C,H) only).
+ * A commitment that does not decode -> DAPOL_ERR_VALUE_DECODING. */
+int32_t dapol_merge_batch(dapol_ctx* ctx, size_t n, const uint8_t* CL32, const uint8_t* HL32, const uint64_t* vL, const uint8_t* rL32,
+                          const uint8_t* CR32, const uint8_t* HR32, const uint64_t* vR, const uint8_t* rR32, uint8_t* C32,
+                          uint8_t* H32, uint64_t* v, uint8_t* r32);
 int32_t dapol_tree_destroy(dapol_tree* tree);
 /* Dapol::root_raw / Dapol::root (src/dapol/mod.rs:134-141). Any out pointer may be NULL. */
 int32_t dapol_tree_root(dapol_tree* tree, uint8_t C32[32], uint8_t H32[32], uint64_t* v, uint8_t r32[32]);
@@ -121,12 +134,22 @@ int32_t dapol_prove_entities(dapol_ctx* ctx, dapol_tree* tree, size_t b, const u
                              int32_t aggregation_factor, int32_t n_bits, const uint8_t nonce_seed32[32], uint8_t* path_C32,
                              uint8_t* path_H32, uint8_t* range_out);
 size_t dapol_entity_proof_size(int32_t height, int32_t policy, int32_t aggregation_factor, int32_t n_bits);
+/* Same, for a shard tree: the n_upper siblings above the shard root (root side first; identical for every leaf
+ * of the shard) are prepended to each leaf's own siblings before the policy is applied.  Path outputs are
+ * [b][n_upper + tree height][32]. */
+int32_t dapol_prove_entities_upper(dapol_ctx* ctx, dapol_tree* tree, size_t b, const uint64_t* leaf_idx, int32_t policy,
+                                   int32_t aggregation_factor, int32_t n_bits, const uint8_t nonce_seed32[32], int32_t n_upper,
+                                   const uint8_t* up_C32, const uint8_t* up_H32, const uint64_t* up_v, const uint8_t* up_r32,
+                                   uint8_t* path_C32, uint8_t* path_H32, uint8_t* range_out);
 
 /* Bench / roofline support: device-resident variant of build + prove-all used by bench.py so that the timed
  * region starts with inputs already in HBM and nothing is copied back.  Handles are opaque device buffers. */
 typedef struct dapol_workload dapol_workload;
 int32_t dapol_workload_create(dapol_ctx* ctx, int32_t height, size_t n, const uint64_t* leaf_idx, const uint64_t* v,
                               const uint8_t* r32, dapol_workload** out);
+/* Sharded variant: this GPU holds the leaves of one top-level subtree (see dapol_tree_build_shard). */
+int32_t dapol_workload_create_shard(dapol_ctx* ctx, int32_t total_height, int32_t shard_bits, size_t n, const uint64_t* leaf_idx,
+                                    const uint64_t* v, const uint8_t* r32, dapol_workload** out);
 int32_t dapol_workload_destroy(dapol_workload* w);
 /* One pass: tree build + one padding-policy inclusion range proof per entity (aggregation_factor = height).
  * Returns device time of the two phases in milliseconds (HIP events on the ctx stream), the time and launch
@@ -139,6 +162,16 @@ typedef struct {
 } dapol_workload_stats;
 int32_t dapol_workload_run(dapol_workload* w, const uint8_t pad_seed32[32], const uint8_t nonce_seed32[32], int32_t n_bits,
                            size_t first_entity, size_t n_entities, dapol_workload_stats* stats);
+/* The two halves of dapol_workload_run, so that the subtree-root exchange can sit between them: build returns the
+ * (sub)tree root record; prove takes the siblings above it (n_upper may be 0).  Both fill their part of *stats. */
+int32_t dapol_workload_build(dapol_workload* w, const uint8_t pad_seed32[32], uint8_t root_C[32], uint8_t root_H[32], uint64_t* root_v,
+                             uint8_t root_r[32], dapol_workload_stats* stats);
+int32_t dapol_workload_prove(dapol_workload* w, const uint8_t nonce_seed32[32], int32_t n_bits, size_t first_entity, size_t n_entities,
+                             int32_t n_upper, const uint8_t* up_C32, const uint8_t* up_H32, const uint64_t* up_v, const uint8_t* up_r32,
+                             dapol_workload_stats* stats);
+/* Siblings (v, r) of sampled leaves of the last build, with the upper siblings prepended: [b][n_upper+levels]. */
+int32_t dapol_workload_paths(dapol_workload* w, size_t b, const uint64_t* leaf_idx, int32_t n_upper, const uint64_t* up_v,
+                             const uint8_t* up_r32, uint64_t* sib_v, uint8_t* sib_r32);
 /* Copies back the proofs of entities [first, first+count) of the last run (count*proof_size bytes). */
 int32_t dapol_workload_proofs(dapol_workload* w, size_t first, size_t count, uint8_t* out);
 

@@ -816,8 +816,9 @@ def policy_serialize(policy, aggregated, individual):
     return out
 
 
-def policy_deserialize(policy, data, begin=0):
-    """Returns (aggregated, individual, new_begin) or raises ValueError (DecodingError)."""
+def policy_deserialize(policy, data, begin=0, single_size=SINGLE_PROOF_BYTE_NUM):
+    """Returns (aggregated, individual, new_begin) or raises ValueError (DecodingError).  single_size is 672 in the
+    reference (BIT_SIZE = 64 is hard-coded, src/range/mod.rs:16-18); other bit sizes are a build extension."""
     def take_int(nb):
         nonlocal begin
         if len(data) - begin < nb:
@@ -838,7 +839,7 @@ def policy_deserialize(policy, data, begin=0):
     n_agg = 1 if policy == "padding" else take_int(AGGREGATED_NUM_BYTE_NUM)
     for _ in range(n_agg):
         aggregated.append(take(take_int(PROOF_SIZE_BYTE_NUM)))
-    individual = [take(SINGLE_PROOF_BYTE_NUM) for _ in range(take_int(INDIVIDUAL_NUM_BYTE_NUM))]
+    individual = [take(single_size) for _ in range(take_int(INDIVIDUAL_NUM_BYTE_NUM))]
     return aggregated, individual, begin
 
 

@@ -1,0 +1,332 @@
+"""GPU parity tests proper: every call goes through the C ABI (libdapol_hip.so); the oracles only check.
+Bit-exact is the bar for everything here (integer / byte work)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+SEED = bytes(range(32))
+
+
+def _arr(hexes):
+    return np.array([list(bytes.fromhex(h)) for h in hexes], np.uint8)
+
+
+def _ref_tree(ref, height, idx, v, r, seed=SEED, faithful=0):
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    t = ref.ref_tree_build(height, ctypes.c_size_t(len(idx)), p(idx), p(v), p(r), seed, faithful)
+    assert t is not None
+    return ctypes.c_void_p(t)
+
+
+def _ref_root(ref, t):
+    C, H, r, v = (ctypes.create_string_buffer(32) for _ in range(3)) + (ctypes.c_uint64(),)
+    ref.ref_tree_root(t, C, H, ctypes.byref(v), r)
+    return C.raw, H.raw, v.value, r.raw
+
+
+def _rand_leaves(rng, height, n, vmax=2**32):
+    if height >= 63:
+        idx = np.sort(np.unique(rng.integers(0, 2**63, size=n, dtype=np.uint64)))
+    else:
+        idx = np.sort(rng.choice(1 << height, size=n, replace=False).astype(np.uint64)) if (1 << height) <= 1 << 22 else \
+            np.sort(np.unique(rng.integers(0, 1 << height, size=n, dtype=np.uint64)))
+    n = len(idx)
+    v = rng.integers(0, vmax, size=n, dtype=np.uint64)
+    r = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    r[:, 31] &= 0x0F
+    return idx, v, r
+
+
+# ------------------------------------------------------------------------------------------------ golden vectors
+def test_generators(gpu_ctx, pyref):
+    kat = load_golden("kat.json")
+    assert gpu_ctx.generator(0).hex() == kat["B"] and gpu_ctx.generator(1).hex() == kat["B_blinding"]
+    for j in range(2):
+        for i in range(8):
+            assert gpu_ctx.generator(2, j, i).hex() == kat["gens_n8_m2"]["G"][j * 8 + i]
+            assert gpu_ctx.generator(3, j, i).hex() == kat["gens_n8_m2"]["H"][j * 8 + i]
+    G, H = pyref.bp_gens(64, 2)
+    for i in (0, 9, 63):
+        assert gpu_ctx.generator(2, 1, i) == G[64 + i].compress() and gpu_ctx.generator(3, 1, i) == H[64 + i].compress()
+
+
+def test_commit_hash_golden(gpu_ctx):
+    cm = load_golden("commit.json")       # includes v = 0 / 2^64-1 and r = 0, 1, l-1, l, l+1, 2^255-1 (unreduced)
+    C, H = gpu_ctx.commit_hash_batch([c["v"] for c in cm], _arr([c["r"] for c in cm]))
+    for i, c in enumerate(cm):
+        assert C[i].tobytes().hex() == c["C"] and H[i].tobytes().hex() == c["H"], i
+
+
+def test_trees_golden_every_node(gpu_ctx, hip_lib):
+    for t in load_golden("trees.json"):
+        idx = np.array([l["idx"] for l in t["leaves"]], np.uint64)
+        v = np.array([l["v"] for l in t["leaves"]], np.uint64)
+        tr = hip_lib.Tree(gpu_ctx, t["height"], idx, v, _arr([l["r"] for l in t["leaves"]]), bytes.fromhex(t["pad_seed"]))
+        C, H, rv, rr = tr.root()
+        assert (C.hex(), H.hex(), rv, rr.hex()) == (t["root"]["C"], t["root"]["H"], t["root"]["v"], t["root"]["r"])
+        assert sum(tr.node_count()) == t["node_count"]
+        for k, lev in enumerate(t.get("levels", [])):
+            i_, v_, r_, C_, H_, p_ = tr.level_nodes(k)
+            got = {int(i_[j]): (int(v_[j]), r_[j].tobytes().hex(), C_[j].tobytes().hex(), H_[j].tobytes().hex(), bool(p_[j])) for j in range(len(i_))}
+            assert got == {n["idx"]: (n["v"], n["r"], n["C"], n["H"], n["pad"]) for n in lev}, (t["height"], k)
+        pk = sorted(int(k) for k in t["paths"])
+        pC, pH, pv, pr = tr.paths(pk)
+        for a, li in enumerate(pk):
+            for s, e in enumerate(t["paths"][str(li)]):
+                assert (pC[a, s].tobytes().hex(), pH[a, s].tobytes().hex(), int(pv[a, s]), pr[a, s].tobytes().hex()) == (e["C"], e["H"], e["v"], e["r"])
+
+
+def test_range_proofs_golden(gpu_ctx):
+    for c in load_golden("range.json"):
+        n, m = c["n"], c["m"]
+        pr = gpu_ctx.range_prove_batch(n, m, np.array(c["values"], np.uint64).reshape(1, m), _arr(c["blindings"]).reshape(1, m, 32),
+                                       nonce_seed=bytes.fromhex(c["nonce_seed"]), stream_id=[c["stream_id"]])
+        assert pr[0].tobytes().hex() == c["proof"], (n, m)
+
+
+def test_entity_proofs_golden_both_policies(gpu_ctx, hip_lib):
+    for c in load_golden("dapol.json"):
+        idx = np.array([l["idx"] for l in c["leaves"]], np.uint64)
+        v = np.array([l["v"] for l in c["leaves"]], np.uint64)
+        tr = hip_lib.Tree(gpu_ctx, c["height"], idx, v, _arr([l["r"] for l in c["leaves"]]), bytes.fromhex(c["pad_seed"]))
+        pol = hip_lib.POLICY_PADDING if c["policy"] == "padding" else hip_lib.POLICY_SPLITTING
+        pC, pH, out = tr.prove_entities([c["leaf"]], pol, c["agg"], c["n_bits"], bytes.fromhex(c["nonce_seed"]))
+        assert out[0].tobytes().hex() == "".join(c["aggregated"]) + "".join(c["individual"])
+        for s, e in enumerate(c["siblings"]):
+            assert pC[0, s].tobytes().hex() == e["C"] and pH[0, s].tobytes().hex() == e["H"]
+
+
+# ------------------------------------------------------------------------------------------------ vs the C oracle, seeded
+@pytest.mark.parametrize("height,n", [(12, 700), (24, 4096), (32, 2048), (64, 300)])
+def test_tree_vs_oracle_random(gpu_ctx, hip_lib, ref, height, n):
+    rng = np.random.default_rng(height * 1000 + n)
+    idx, v, r = _rand_leaves(rng, height, n)
+    r[::7, 31] |= 0x70                        # unreduced Scalar::from_bits blindings (>= l) on some leaves
+    tr = hip_lib.Tree(gpu_ctx, height, idx, v, r, SEED)
+    t = _ref_tree(ref, height, idx, v, r)
+    assert tr.root() == _ref_root(ref, t)
+    assert sum(tr.node_count()) == ref.ref_tree_node_count(t)
+    assert tr.root()[2] == int(v.sum())                          # root value = sum of liabilities (src/dapol/tests.rs:24)
+    sample = idx[:: max(1, len(idx) // 16)]
+    pC, pH, pv, pr = tr.paths(sample)
+    for a, li in enumerate(sample):
+        sC, sH, sr, sv = (ctypes.create_string_buffer(32 * height) for _ in range(3)) + ((ctypes.c_uint64 * height)(),)
+        assert ref.ref_tree_path(t, ctypes.c_uint64(int(li)), sC, sH, sv, sr) == 1
+        assert pC[a].tobytes() == sC.raw and pH[a].tobytes() == sH.raw and pr[a].tobytes() == sr.raw and list(map(int, pv[a])) == list(sv)
+    ref.ref_tree_free(t)
+
+
+@pytest.mark.parametrize("n_bits,m,b", [(64, 32, 48), (64, 1, 64), (32, 16, 32), (8, 1, 130), (16, 8, 33)])
+def test_range_prove_vs_oracle_random(gpu_ctx, ref, n_bits, m, b):
+    rng = np.random.default_rng(n_bits * 100 + m)
+    v = rng.integers(0, 2**n_bits if n_bits < 64 else 2**63, size=(b, m), dtype=np.uint64)
+    if n_bits == 64:
+        v[0, 0] = 2**64 - 1
+    v[1 % b, 0] = 0
+    r = rng.integers(0, 256, size=(b, m, 32), dtype=np.uint8)
+    r[:, :, 31] &= 0x0F
+    sid = rng.integers(0, 2**63, size=b, dtype=np.uint64)
+    got = gpu_ctx.range_prove_batch(n_bits, m, v, r, nonce_seed=SEED, stream_id=sid, slot_base=5)
+    ps = ref.ref_range_proof_size(n_bits, m)
+    out = ctypes.create_string_buffer(ps * b)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    assert ref.ref_range_prove_batch(n_bits, m, ctypes.c_size_t(b), p(v), p(r), SEED, p(sid), ctypes.c_uint64(5), None, 0, out) == 0
+    assert got.tobytes() == out.raw
+    # every proof verifies against its commitments (round trip), a tampered one does not
+    C, _ = gpu_ctx.commit_hash_batch(v.reshape(-1), r.reshape(-1, 32))
+    c7 = bytes([7]) + bytes(31)
+    for k in (0, b - 1):
+        Vs = C[k * m:(k + 1) * m].tobytes()
+        assert ref.ref_range_verify(n_bits, m, got[k].tobytes(), ctypes.c_size_t(ps), Vs, c7, 0) == 1
+        bad = bytearray(got[k].tobytes())
+        bad[ps - 1] ^= 1
+        assert ref.ref_range_verify(n_bits, m, bytes(bad), ctypes.c_size_t(ps), Vs, c7, 0) == 0
+
+
+def test_tape_mode_equals_seed_mode(gpu_ctx, pyref):
+    n, m, b = 16, 4, 3
+    slots = m * (2 * n + 4)
+    sid = [11, 2**40 + 3, 0]
+    tape = np.frombuffer(b"".join(pyref.seed_wide(SEED, 2, s, k) for s in sid for k in range(slots)), np.uint8)
+    rng = np.random.default_rng(5)
+    v = rng.integers(0, 2**16, size=(b, m), dtype=np.uint64)
+    r = rng.integers(0, 256, size=(b, m, 32), dtype=np.uint8)
+    r[:, :, 31] &= 0x0F
+    a = gpu_ctx.range_prove_batch(n, m, v, r, nonce_seed=SEED, stream_id=sid)
+    t = gpu_ctx.range_prove_batch(n, m, v, r, tape=tape)
+    assert a.tobytes() == t.tobytes()
+
+
+@pytest.mark.parametrize("height,policy,agg", [(8, 0, 8), (8, 1, 5), (6, 0, 3), (5, 1, 0), (7, 0, 0), (9, 1, 9)])
+def test_entity_proofs_vs_python_oracle(gpu_ctx, hip_lib, pyref, height, policy, agg):
+    """Padding and splitting policies with aggregation_factor below the height (individual proofs) vs pyref, n = 8 bits."""
+    rng = np.random.default_rng(height * 10 + agg)
+    idx, v, r = _rand_leaves(rng, height, 5, vmax=8)
+    tr = hip_lib.Tree(gpu_ctx, height, idx, v, r, SEED)
+    leaves = [(int(i), pyref.node_new(int(vv), int.from_bytes(rr.tobytes(), "little"))) for i, vv, rr in zip(idx, v, r)]
+    pt = pyref.Tree(height, leaves, SEED)
+    name = "padding" if policy == 0 else "splitting"
+    pC, pH, out = tr.prove_entities(idx[:2], policy, agg, 8, SEED)
+    for k in range(2):
+        sibs, aggregated, individual = pyref.dapol_prove(pt, int(idx[k]), name, agg, SEED, n=8)
+        assert out[k].tobytes() == b"".join(aggregated) + b"".join(individual)
+        assert pyref.policy_verify(name, aggregated, individual, [pC[k, s].tobytes() for s in range(height)], n=8)
+        lf = pt.levels[0][int(idx[k])]
+        assert pyref.verify_path(pt.root.C, pt.root.H, lf.C, lf.H, int(idx[k]), [(pC[k, s].tobytes(), pH[k, s].tobytes()) for s in range(height)])
+
+
+# ------------------------------------------------------------------------------------------------ edge cases / errors
+def test_error_behaviour(gpu_ctx, hip_lib):
+    E = hip_lib.DapolError
+    r2 = np.zeros((2, 32), np.uint8)
+    with pytest.raises(E) as e:
+        hip_lib.Tree(gpu_ctx, 4, [5, 5], [1, 2], r2, SEED)            # duplicate leaf: smtree panics
+    assert e.value.code == 8
+    with pytest.raises(E) as e:
+        hip_lib.Tree(gpu_ctx, 4, [7, 3], [1, 2], r2, SEED)            # unsorted
+    assert e.value.code == 8
+    with pytest.raises(E) as e:
+        hip_lib.Tree(gpu_ctx, 4, [3, 16], [1, 2], r2, SEED)           # index >= 2^height
+    assert e.value.code == 8
+    with pytest.raises(E) as e:
+        hip_lib.Tree(gpu_ctx, 65, [3], [1], r2[:1], SEED)             # DapolError::TreeHeightTooBig
+    assert e.value.code == 1
+    with pytest.raises(E) as e:
+        hip_lib.Tree(gpu_ctx, 2, [0, 1, 2], [1, 2, 3], np.zeros((3, 32), np.uint8), SEED, enforce_sparsity=True)   # SparsityTooSmall
+    assert e.value.code == 2
+    tr = hip_lib.Tree(gpu_ctx, 4, [3, 9], [1, 2], r2, SEED)
+    with pytest.raises(E) as e:
+        tr.paths([4])                                                 # Dapol::generate_proof -> None
+    assert e.value.code == 9
+    with pytest.raises(E) as e:
+        tr.prove_entities([3], 0, 5, 8, SEED)                         # aggregation_factor > #siblings: reference panics
+    assert e.value.code == 8
+    with pytest.raises(E) as e:
+        gpu_ctx.range_prove_batch(64, 64, np.zeros((1, 64), np.uint64), np.zeros((1, 64, 32), np.uint8), nonce_seed=SEED, stream_id=[0])
+    assert e.value.code == 8                                          # m > max_parties (InvalidGeneratorsLength)
+    with pytest.raises(E):
+        gpu_ctx.range_prove_batch(12, 1, np.zeros((1, 1), np.uint64), np.zeros((1, 1, 32), np.uint8), nonce_seed=SEED, stream_id=[0])
+    C, H = gpu_ctx.commit_hash_batch(np.zeros(0, np.uint64), np.zeros((0, 32), np.uint8))      # empty batch is a no-op
+    assert C.shape == (0, 32)
+
+
+def test_single_leaf_and_full_level(gpu_ctx, hip_lib, ref):
+    for height, idx in ((1, [1]), (3, list(range(8))), (10, [1023])):
+        idx = np.array(idx, np.uint64)
+        v = np.arange(1, len(idx) + 1, dtype=np.uint64)
+        r = np.tile(np.arange(32, dtype=np.uint8), (len(idx), 1))
+        r[:, 31] &= 0x0F
+        tr = hip_lib.Tree(gpu_ctx, height, idx, v, r, SEED)
+        t = _ref_tree(ref, height, idx, v, r)
+        assert tr.root() == _ref_root(ref, t)
+        ref.ref_tree_free(t)
+
+
+def test_value_sum_wraps_like_release_rust(gpu_ctx, hip_lib, ref):
+    idx = np.array([0, 1], np.uint64)
+    v = np.array([2**64 - 1, 5], np.uint64)
+    r = np.ones((2, 32), np.uint8)
+    r[:, 31] = 0
+    tr = hip_lib.Tree(gpu_ctx, 1, idx, v, r, SEED)
+    assert tr.root()[2] == 4                                          # u64 wrap (node.rs:72 in release builds)
+    t = _ref_tree(ref, 1, idx, v, r)
+    assert tr.root() == _ref_root(ref, t)
+    ref.ref_tree_free(t)
+
+
+def test_merge_batch(gpu_ctx, hip_lib, pyref):
+    nodes = [pyref.node_new(3 + i, 77 + 1000 * i) for i in range(6)]
+    f = lambda attr, ns: np.array([list(getattr(n, attr)) for n in ns], np.uint8)
+    L, R = nodes[0::2], nodes[1::2]
+    C, H, v, r = gpu_ctx.merge_batch(f("C", L), f("H", L), f("C", R), f("H", R), [n.v for n in L], np.array([list(pyref.scalar_bytes(n.r)) for n in L], np.uint8),
+                                     [n.v for n in R], np.array([list(pyref.scalar_bytes(n.r)) for n in R], np.uint8))
+    for i in range(3):
+        p = pyref.node_merge(L[i], R[i])
+        assert (C[i].tobytes(), H[i].tobytes(), int(v[i]), r[i].tobytes()) == (p.C, p.H, p.v, pyref.scalar_bytes(p.r))
+    C2, H2 = gpu_ctx.merge_batch(f("C", L), f("H", L), f("C", R), f("H", R))
+    assert C2.tobytes() == C.tobytes() and H2.tobytes() == H.tobytes()
+    bad = f("C", L)
+    bad[0, 0] ^= 1                                                    # odd s -> not a canonical ristretto encoding
+    with pytest.raises(hip_lib.DapolError) as e:
+        gpu_ctx.merge_batch(bad, f("H", L), f("C", R), f("H", R))
+    assert e.value.code == 7
+
+
+# ------------------------------------------------------------------------------------------------ sharding (section 8e)
+@pytest.mark.parametrize("shard_bits", [1, 2, 3])
+def test_sharded_equals_single_gpu(gpu_ctx, hip_lib, shard_bits):
+    """G logical shards on one device: subtree builds + merged top levels + upper siblings give the same root, paths and
+    proof bytes as the single-GPU build of the whole tree."""
+    from dapol_amd import sharded
+    height, n_bits, g = 7, 8, 1 << shard_bits
+    rng = np.random.default_rng(shard_bits)
+    idx = np.sort(np.concatenate([rng.choice(1 << (height - shard_bits), size=3, replace=False).astype(np.uint64) + np.uint64(s << (height - shard_bits))
+                                  for s in range(g)]))
+    v = rng.integers(0, 4, size=len(idx), dtype=np.uint64)
+    r = rng.integers(0, 256, size=(len(idx), 32), dtype=np.uint8)
+    r[:, 31] &= 0x0F
+    full = hip_lib.Tree(gpu_ctx, height, idx, v, r, SEED)
+    fC, fH, fout = full.prove_entities(idx, hip_lib.POLICY_PADDING, height, n_bits, SEED)
+    shards, recs = [], []
+    for s in range(g):
+        sel = (idx >> np.uint64(height - shard_bits)) == s
+        t = hip_lib.Tree(gpu_ctx, height, idx[sel], v[sel], r[sel], SEED, shard_bits=shard_bits)
+        shards.append((sel, t))
+        recs.append(sharded.pack_record(t.root()))
+    records = sharded.unpack_records(np.stack(recs), g)
+    for s, (sel, t) in enumerate(shards):
+        root, upper = sharded.top_levels(gpu_ctx, records, s)
+        assert root == full.root()
+        pC, pH, out = t.prove_entities(idx[sel], hip_lib.POLICY_PADDING, height, n_bits, SEED, upper=upper)
+        assert out.tobytes() == fout[sel].tobytes()
+        assert pC.tobytes() == fC[sel].tobytes() and pH.tobytes() == fH[sel].tobytes()
+
+
+# ------------------------------------------------------------------------------------------------ workload (bench path)
+def test_workload_matches_api_and_is_deterministic(gpu_ctx, hip_lib):
+    height, n = 10, 64
+    stride = (1 << height) // n
+    idx = (np.arange(n, dtype=np.uint64) * np.uint64(stride))
+    rng = np.random.default_rng(3)
+    v = rng.integers(0, 4, size=n, dtype=np.uint64)
+    r = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    r[:, 31] &= 0x0F
+    w = hip_lib.Workload(gpu_ctx, height, idx, v, r)
+    st1 = w.run(SEED, SEED, n_bits=8)
+    proofs = w.proofs(0, n, st1.proof_bytes // n)
+    st2 = w.run(SEED, SEED, n_bits=8)
+    assert st1.checksum == st2.checksum and st1.proofs == n and st1.msm_launches > 0 and st1.msm_ms > 0
+    tr = hip_lib.Tree(gpu_ctx, height, idx, v, r, SEED)
+    assert bytes(st1.root_C) == tr.root()[0] and bytes(st1.root_H) == tr.root()[1]
+    _, _, out = tr.prove_entities(idx, hip_lib.POLICY_PADDING, height, 8, SEED)
+    assert out.tobytes() == proofs.tobytes()
+    st3 = w.run(SEED, bytes(32), n_bits=8)                            # another nonce seed -> other proof bytes
+    assert st3.checksum != st1.checksum
+
+
+def test_bench_layout_at_baseline_config_properties(gpu_ctx, hip_lib, ref):
+    """BASELINE.json configs[1] shape (height 24, 64-bit proofs, strided leaves) at a size the oracle still finishes:
+    root equals the oracle's, root value = sum, sampled proofs bit-exact and verifying."""
+    height, n = 24, 1 << 12
+    idx = (np.arange(n, dtype=np.uint64) * np.uint64((1 << height) // n))
+    rng = np.random.default_rng(24)
+    v = rng.integers(0, 2**32, size=n, dtype=np.uint64)
+    r = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    r[:, 31] &= 0x0F
+    w = hip_lib.Workload(gpu_ctx, height, idx, v, r)
+    st = w.run(SEED, SEED, n_bits=64)
+    ps = st.proof_bytes // n
+    assert ps == 992
+    t = _ref_tree(ref, height, idx, v, r)
+    rC, rH, rv, _ = _ref_root(ref, t)
+    assert bytes(st.root_C) == rC and bytes(st.root_H) == rH and rv == int(v.sum())
+    sample = np.ascontiguousarray(idx[::512])
+    out = ctypes.create_string_buffer(ps * len(sample))
+    assert ref.ref_prove_entities_padding(t, ctypes.c_size_t(len(sample)), sample.ctypes.data_as(ctypes.c_void_p), 64, SEED, 0, out) == 0
+    for k in range(len(sample)):
+        assert w.proofs(k * 512, 1, ps).tobytes() == out.raw[k * ps:(k + 1) * ps]
+    ref.ref_tree_free(t)

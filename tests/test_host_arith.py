@@ -1,0 +1,119 @@
+"""The PRODUCT limb arithmetic (dapol_amd/csrc/{fe,ge,sc,hash}.h compiled for the host) against the big-integer
+oracle.  CPU only -- the same headers are what the gfx950 kernels inline."""
+import ctypes
+import hashlib
+import random
+
+
+def buf(n):
+    return ctypes.create_string_buffer(n)
+
+
+def test_field_ops(host_shim, pyref):
+    P = pyref.P
+    rnd = random.Random(1)
+    edge = [0, 1, 2, P - 1, P - 2, 2**255 - 20, 2**254, 19, 2**26 - 1, 2**255 - 19 - 2**26]
+
+    def op(k, a, b):
+        o = buf(32)
+        host_shim.t_fe_op(k, a.to_bytes(32, "little"), b.to_bytes(32, "little"), o)
+        return int.from_bytes(o.raw, "little")
+    for it in range(1500):
+        a = rnd.choice(edge) if it < 100 else rnd.randrange(P)
+        b = rnd.choice(edge) if it < 100 and it % 2 else rnd.randrange(P)
+        assert op(0, a, b) == a * b % P
+        assert op(1, a, b) == a * a % P
+        assert op(3, a, b) == (2 * a + b) * b % P          # loose f operand
+        assert op(4, a, b) == (a - b) ** 2 % P             # tight difference squared
+        assert op(5, a, b) == (-(a - 2 * b)) % P           # carry of a negative loose value
+        if it < 100 and a % P:
+            assert op(2, a, b) == pow(a, P - 2, P)
+
+
+def test_group_law_and_codec(host_shim, pyref):
+    R = pyref
+    rnd = random.Random(2)
+    for it in range(24):
+        k = [0, 1, 2, R.L - 1, R.L, 2**255 - 1, 8 * R.L][it] if it < 7 else rnd.randrange(2**255)
+        o = buf(32)
+        host_shim.t_basemul((k % 2**256).to_bytes(32, "little"), o)
+        assert o.raw == (k * R.BASEPOINT).compress()
+    Bb = R.B_BLINDING.compress()
+    for it in range(10):
+        k = rnd.randrange(2**255)
+        o = buf(32)
+        host_shim.t_maddmul(Bb, k.to_bytes(32, "little"), it & 1, o)
+        e = k * R.B_BLINDING
+        assert o.raw == (-e if it & 1 else e).compress()
+    for it in range(40):
+        c = (rnd.randrange(R.L) * R.BASEPOINT).compress() if it < 20 else bytes(rnd.randrange(256) for _ in range(31)) + bytes([rnd.randrange(128)])
+        o = buf(32)
+        ok = host_shim.t_decompress(c, o)
+        ref = R.decompress(c)
+        assert bool(ok) == (ref is not None)
+        if ok:
+            assert o.raw == c
+    for c in (bytes(32), R.P.to_bytes(32, "little"), (1).to_bytes(32, "little"), b"\xff" * 32):
+        assert bool(host_shim.t_decompress(c, buf(32))) == (R.decompress(c) is not None)
+    for it in range(20):
+        u = bytes(rnd.randrange(256) for _ in range(64))
+        o = buf(32)
+        host_shim.t_from_uniform(u, o)
+        assert o.raw == R.from_uniform_bytes(u).compress()
+
+
+def test_scalar_field(host_shim, pyref):
+    L = pyref.L
+    rnd = random.Random(3)
+    for it in range(600):
+        a = rnd.randrange(2**256) if it % 3 else rnd.randrange(L)
+        b = rnd.randrange(L)
+        for k, f in ((0, a * b % L), (1, (a + b) % L), (2, (a - b) % L)):
+            o = buf(32)
+            host_shim.t_sc_op(k, (a % L if k else a).to_bytes(32, "little"), b.to_bytes(32, "little"), o)
+            exp = f if k == 0 else ((a % L + b) % L if k == 1 else (a % L - b) % L)
+            assert int.from_bytes(o.raw, "little") == exp
+        if it < 30 and a % L:
+            o = buf(32)
+            host_shim.t_sc_op(3, a.to_bytes(32, "little"), b.to_bytes(32, "little"), o)
+            assert int.from_bytes(o.raw, "little") == pow(a, L - 2, L)
+        w = [bytes(64), b"\xff" * 64, L.to_bytes(64, "little"), (L * L).to_bytes(64, "little")][it] if it < 4 else bytes(rnd.randrange(256) for _ in range(64))
+        o = buf(32)
+        host_shim.t_sc_from_wide(w, o)
+        assert int.from_bytes(o.raw, "little") == int.from_bytes(w, "little") % L
+        x = [2**255 - 1, 0, 2**255 - 2**247][it] if it < 3 else rnd.randrange(2**255)
+        d = (ctypes.c_int16 * 32)()
+        host_shim.t_sc_recode(x.to_bytes(32, "little"), d)
+        assert sum(int(d[i]) * 256**i for i in range(32)) == x and all(abs(int(v)) <= 128 for v in d)
+
+
+def test_hashes_and_transcript(host_shim, pyref):
+    R = pyref
+    rnd = random.Random(4)
+    for it in range(30):
+        m = bytes(rnd.randrange(256) for _ in range(128))
+        o = buf(32)
+        host_shim.t_blake3_32(m[:32], o)
+        assert o.raw == R.blake3(m[:32])
+        host_shim.t_blake3_128(m, o)
+        assert o.raw == R.blake3(m)
+        o = buf(64)
+        a, b = rnd.randrange(2**64), rnd.randrange(2**64)
+        host_shim.t_seed_wide(m[:32], it, ctypes.c_uint64(a), ctypes.c_uint64(b), o)
+        assert o.raw == R.seed_wide(m[:32], it, a, b)
+        n = rnd.randrange(0, 300)
+        o = buf(200)
+        host_shim.t_sponge(136, 0x1F, m * 3, n, o, 200)
+        assert o.raw == hashlib.shake_256((m * 3)[:n]).digest(200)
+        o = buf(64)
+        host_shim.t_sponge(72, 0x06, m * 3, n, o, 64)
+        assert o.raw == hashlib.sha3_512((m * 3)[:n]).digest()
+    o = buf(64)
+    host_shim.t_merlin(b"test protocol", 13, b"some label", 10, b"some data", 9, b"challenge", 9, o)
+    t = R.Transcript(b"test protocol")
+    t.append_message(b"some label", b"some data")
+    assert o.raw == t.challenge_bytes(b"challenge", 64)
+    host_shim.t_merlin(b"", 0, b"dom-sep", 7, b"rangeproof v1", 13, b"y", 1, o)
+    t = R.Transcript(b"")
+    t.append_message(b"dom-sep", b"rangeproof v1")
+    assert o.raw == t.challenge_bytes(b"y", 64)
