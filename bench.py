@@ -86,8 +86,18 @@ def cpu_baseline(ref, height, n_bits, idx, v, r, sample_paths, budget_s=20.0):
     t0 = time.perf_counter()
     ref.ref_range_prove(n_bits, m, p(pv), p(pr), NONCE_SEED, ctypes.c_uint64(int(leaf_ids[0])), ctypes.c_uint64(0), None, 0, out1)
     one = time.perf_counter() - t0
-    ns = int(max(1, min(len(leaf_ids), budget_s / max(one, 1e-3) * cores)))
-    ns = min(ns, len(leaf_ids))
+    # pilot batch (one proof per core) to learn the parallel rate on this host, then size the sample to ~budget_s
+    npilot = min(len(leaf_ids), cores)
+    PV = np.zeros((npilot, m), np.uint64)
+    PR = np.zeros((npilot, m, 32), np.uint8)
+    for k in range(npilot):
+        PV[k], PR[k] = parties(k)
+    sid = np.ascontiguousarray(leaf_ids[:npilot], dtype=np.uint64)
+    outp = ctypes.create_string_buffer(ps * npilot)
+    t0 = time.perf_counter()
+    ref.ref_range_prove_batch(n_bits, m, ctypes.c_size_t(npilot), p(PV), p(PR), NONCE_SEED, p(sid), ctypes.c_uint64(0), None, 0, outp)
+    pilot = time.perf_counter() - t0
+    ns = int(max(npilot, min(len(leaf_ids), npilot * budget_s / max(pilot, 1e-3))))
     PV = np.zeros((ns, m), np.uint64)
     PR = np.zeros((ns, m, 32), np.uint8)
     for k in range(ns):

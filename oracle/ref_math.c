@@ -142,6 +142,25 @@ void pt_msm_vartime(pt* r, const scl* scalars, const pt* points, size_t n) {
     pt acc;
     pt_identity(&acc);
     if (n == 0) { *r = acc; return; }
+    if (n <= 4) {                      /* the 2-term generator folds of the inner-product argument: no heap traffic */
+        uint8_t k4[4 * 32];
+        pt t4[4 * 16];
+        for (size_t i = 0; i < n; i++) {
+            sc_to_bytes(k4 + 32 * i, &scalars[i]);
+            pt_identity(&t4[16 * i]);
+            t4[16 * i + 1] = points[i];
+            for (int k = 2; k < 16; k++) pt_add(&t4[16 * i + k], &t4[16 * i + k - 1], &points[i]);
+        }
+        for (int w = 63; w >= 0; w--) {
+            for (int d = 0; d < 4; d++) pt_dbl(&acc, &acc);
+            for (size_t i = 0; i < n; i++) {
+                int nib = (k4[32 * i + (w >> 1)] >> (4 * (w & 1))) & 15;
+                if (nib) pt_add(&acc, &acc, &t4[16 * i + nib]);
+            }
+        }
+        *r = acc;
+        return;
+    }
     uint8_t* kb = (uint8_t*)malloc(32 * n);
     for (size_t i = 0; i < n; i++) sc_to_bytes(kb + 32 * i, &scalars[i]);
     if (n < 96) {

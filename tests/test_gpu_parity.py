@@ -23,7 +23,7 @@ def _ref_tree(ref, height, idx, v, r, seed=SEED, faithful=0):
 
 
 def _ref_root(ref, t):
-    C, H, r, v = (ctypes.create_string_buffer(32) for _ in range(3)) + (ctypes.c_uint64(),)
+    C, H, r, v = [ctypes.create_string_buffer(32) for _ in range(3)] + [ctypes.c_uint64()]
     ref.ref_tree_root(t, C, H, ctypes.byref(v), r)
     return C.raw, H.raw, v.value, r.raw
 
@@ -114,7 +114,7 @@ def test_tree_vs_oracle_random(gpu_ctx, hip_lib, ref, height, n):
     sample = idx[:: max(1, len(idx) // 16)]
     pC, pH, pv, pr = tr.paths(sample)
     for a, li in enumerate(sample):
-        sC, sH, sr, sv = (ctypes.create_string_buffer(32 * height) for _ in range(3)) + ((ctypes.c_uint64 * height)(),)
+        sC, sH, sr, sv = [ctypes.create_string_buffer(32 * height) for _ in range(3)] + [(ctypes.c_uint64 * height)()]
         assert ref.ref_tree_path(t, ctypes.c_uint64(int(li)), sC, sH, sv, sr) == 1
         assert pC[a].tobytes() == sC.raw and pH[a].tobytes() == sH.raw and pr[a].tobytes() == sr.raw and list(map(int, pv[a])) == list(sv)
     ref.ref_tree_free(t)
