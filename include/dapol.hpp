@@ -1,0 +1,183 @@
+// dapol.hpp -- C++ host-side mirror of the reference crate's public surface for the GPU proving path
+// (src/lib.rs:1-11), over the C ABI of dapol_hip.h.  Same names, argument meaning and error behaviour:
+//   Result<_, DapolError>  -> throws dapol::DapolError          (src/errors.rs:6-17)
+//   Option<_>              -> std::optional                      (src/dapol/mod.rs:148-190)
+//   panics                 -> throws dapol::DapolError{code 8}   (src/range/padding.rs:95-98, smtree build)
+// Header-only; link with -ldapol_hip.  No computation happens here.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "dapol_hip.h"
+
+namespace dapol {
+
+using Bytes32 = std::array<uint8_t, 32>;
+
+struct DapolError : std::runtime_error {      // src/errors.rs:6-17 (+ the ABI's extra codes)
+    int32_t code;
+    DapolError(int32_t c) : std::runtime_error(std::string(dapol_strerror(c)) + " [" + dapol_last_error() + "]"), code(c) {}
+};
+inline void check(int32_t rc) { if (rc != DAPOL_OK) throw DapolError(rc); }
+
+// DapolProofNode<D> (src/proof/node.rs:17-22): commitment + hash, both 32 bytes (D = blake3::Hasher).
+struct DapolProofNode {
+    Bytes32 com{}, hash{};
+    bool operator==(const DapolProofNode& o) const { return com == o.com && hash == o.hash; }   // src/proof/node.rs:24-29
+};
+// DapolNode<D> (src/dapol/node.rs:19-25) as it crosses the boundary: value, blinding, commitment, hash.
+struct DapolNode {
+    uint64_t v = 0;
+    Bytes32 v_blinding{}, com{}, hash{};
+    uint64_t get_value() const { return v; }
+    const Bytes32& get_blinding() const { return v_blinding; }
+    DapolProofNode get_proof_node() const { return {com, hash}; }      // ProofExtractable (node.rs:91-96)
+    bool operator==(const DapolNode& o) const { return v == o.v; }     // node.rs:115-120: equal iff values are equal
+};
+
+class Context {                                // PedersenGens::default() + BulletproofGens::new(64, m), once
+  public:
+    explicit Context(int device = 0, int max_parties = 32) { check(dapol_ctx_create(device, max_parties, DAPOL_DIGEST_BLAKE3, &h_)); }
+    ~Context() { dapol_ctx_destroy(h_); }
+    Context(const Context&) = delete;
+    Context& operator=(const Context&) = delete;
+    dapol_ctx* get() const { return h_; }
+    // DapolNode::new (src/dapol/node.rs:29-45)
+    DapolNode node_new(uint64_t value, const Bytes32& blinding) const {
+        DapolNode n;
+        n.v = value;
+        n.v_blinding = blinding;
+        check(dapol_commit_hash_batch(h_, 1, &value, blinding.data(), n.com.data(), n.hash.data()));
+        return n;
+    }
+    // Mergeable::merge (src/dapol/node.rs:64-80)
+    DapolNode merge(const DapolNode& l, const DapolNode& r) const {
+        DapolNode p;
+        check(dapol_merge_batch(h_, 1, l.com.data(), l.hash.data(), &l.v, l.v_blinding.data(), r.com.data(), r.hash.data(), &r.v,
+                                r.v_blinding.data(), p.com.data(), p.hash.data(), &p.v, p.v_blinding.data()));
+        return p;
+    }
+  private:
+    dapol_ctx* h_ = nullptr;
+};
+
+enum class Policy { Padding = DAPOL_POLICY_PADDING, Splitting = DAPOL_POLICY_SPLITTING };
+
+// RangeProofPadding / RangeProofSplitting (src/range/padding.rs:20-23, splitting.rs:22-25): aggregated + individual proofs.
+struct RangeProofs {
+    Policy policy = Policy::Padding;
+    std::vector<std::vector<uint8_t>> aggregated, individual;
+};
+
+// RangeProvable::generate_proof (src/range/mod.rs:29) for one sibling list, through the batched prover.
+inline RangeProofs generate_proof(const Context& ctx, Policy policy, const std::vector<uint64_t>& secrets, const std::vector<Bytes32>& blindings,
+                                  size_t aggregation_factor, const Bytes32& nonce_seed, uint64_t stream_id, int n_bits = 64) {
+    if (aggregation_factor > secrets.size() || secrets.size() != blindings.size()) throw DapolError(DAPOL_ERR_INVALID_ARGUMENT);
+    RangeProofs out;
+    out.policy = policy;
+    uint64_t slot = 0;
+    auto prove = [&](size_t start, size_t count, size_t m) {
+        std::vector<uint64_t> v(m, 0);
+        std::vector<uint8_t> r(m * 32, 0);
+        for (size_t j = 0; j < m; j++) {
+            if (j < count) { v[j] = secrets[start + j]; std::memcpy(&r[32 * j], blindings[start + j].data(), 32); }
+            else r[32 * j] = 1;                                            // (0, Scalar::one())  padding.rs:100-103
+        }
+        std::vector<uint8_t> p(dapol_range_proof_size(n_bits, (int)m));
+        check(dapol_range_prove_batch(ctx.get(), n_bits, (int)m, 1, v.data(), r.data(), nonce_seed.data(), &stream_id, slot, nullptr, p.data()));
+        slot += m * (2 * (uint64_t)n_bits + 4);
+        return p;
+    };
+    auto np2 = [](size_t x) { size_t p = 1; while (p < x) p <<= 1; return p; };
+    if (policy == Policy::Padding) {
+        out.aggregated.push_back(prove(0, aggregation_factor, np2(aggregation_factor)));
+    } else {
+        size_t base = np2(aggregation_factor), pos = 0;
+        while (pos < aggregation_factor) {
+            if (aggregation_factor & base) { out.aggregated.push_back(prove(pos, base, base)); pos += base; }
+            base >>= 1;
+        }
+    }
+    for (size_t i = aggregation_factor; i < secrets.size(); i++) out.individual.push_back(prove(i, 1, 1));
+    return out;
+}
+
+// DapolProof<D, R> (src/proof/mod.rs:15-22) for single leaves: Merkle siblings (root side first) + range proofs.
+struct DapolProof {
+    uint64_t leaf_index = 0;
+    std::vector<DapolProofNode> merkle_siblings;
+    std::vector<uint8_t> range_proofs;           // aggregated proofs then individual proofs, concatenated
+};
+
+// Dapol<D, R> (src/dapol/mod.rs:78-83)
+class Dapol {
+  public:
+    // Dapol::new_blank (mod.rs:196-204)
+    static Dapol new_blank(std::shared_ptr<Context> ctx, int height, size_t aggregation_factor, Policy policy = Policy::Padding) {
+        Dapol d;
+        d.ctx_ = std::move(ctx);
+        d.height_ = height;
+        d.aggregation_factor_ = aggregation_factor;
+        d.policy_ = policy;
+        return d;
+    }
+    // Dapol::build (mod.rs:206-208): input = sorted (tree index, value, blinding); pad_seed stands in for thread_rng().
+    void build(const std::vector<uint64_t>& idx, const std::vector<uint64_t>& values, const std::vector<Bytes32>& blindings,
+               const Bytes32& pad_seed, bool enforce_sparsity = false) {
+        if (idx.size() != values.size() || idx.size() != blindings.size()) throw DapolError(DAPOL_ERR_INVALID_ARGUMENT);
+        dapol_tree* t = nullptr;
+        check(dapol_tree_build(ctx_->get(), height_, idx.size(), idx.data(), values.data(), blindings.empty() ? nullptr : blindings[0].data(),
+                               pad_seed.data(), enforce_sparsity ? 1 : 0, &t));
+        tree_.reset(t, [](dapol_tree* p) { dapol_tree_destroy(p); });
+    }
+    // Dapol::root_raw / Dapol::root (mod.rs:134-141)
+    DapolNode root_raw() const {
+        DapolNode n;
+        check(dapol_tree_root(tree_.get(), n.com.data(), n.hash.data(), &n.v, n.v_blinding.data()));
+        return n;
+    }
+    DapolProofNode root() const { return root_raw().get_proof_node(); }
+    // Dapol::generate_proof (mod.rs:167-169): None when there is no liability at the leaf.
+    std::optional<DapolProof> generate_proof(uint64_t leaf_idx, const Bytes32& nonce_seed, int n_bits = 64) const {
+        auto v = generate_proofs({leaf_idx}, nonce_seed, n_bits);
+        if (!v) return std::nullopt;
+        return std::move((*v)[0]);
+    }
+    // Many single-leaf proofs in one GPU batch (the throughput path).
+    std::optional<std::vector<DapolProof>> generate_proofs(const std::vector<uint64_t>& leaves, const Bytes32& nonce_seed, int n_bits = 64) const {
+        size_t es = dapol_entity_proof_size(height_, (int)policy_, (int)aggregation_factor_, n_bits);
+        if (es == 0) throw DapolError(DAPOL_ERR_INVALID_ARGUMENT);
+        size_t b = leaves.size(), h = (size_t)height_;
+        std::vector<uint8_t> C(b * h * 32), H(b * h * 32), R(b * es);
+        int32_t rc = dapol_prove_entities(ctx_->get(), tree_.get(), b, leaves.data(), (int)policy_, (int)aggregation_factor_, n_bits,
+                                          nonce_seed.data(), C.data(), H.data(), R.data());
+        if (rc == DAPOL_ERR_UNKNOWN_LEAF) return std::nullopt;
+        check(rc);
+        std::vector<DapolProof> out(b);
+        for (size_t e = 0; e < b; e++) {
+            out[e].leaf_index = leaves[e];
+            out[e].merkle_siblings.resize(h);
+            for (size_t s = 0; s < h; s++) {
+                std::memcpy(out[e].merkle_siblings[s].com.data(), &C[(e * h + s) * 32], 32);
+                std::memcpy(out[e].merkle_siblings[s].hash.data(), &H[(e * h + s) * 32], 32);
+            }
+            out[e].range_proofs.assign(R.begin() + e * es, R.begin() + (e + 1) * es);
+        }
+        return out;
+    }
+  private:
+    std::shared_ptr<Context> ctx_;
+    std::shared_ptr<dapol_tree> tree_;
+    int height_ = 0;
+    size_t aggregation_factor_ = 0;
+    Policy policy_ = Policy::Padding;
+};
+
+}  // namespace dapol
