@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdapol_hip.so")
+LIB_PATH = os.environ.get("DAPOL_HIP_LIB", os.path.join(_HERE, "libdapol_hip.so"))   # override only for A/B builds
 
 POLICY_PADDING, POLICY_SPLITTING = 0, 1
 DIGEST_BLAKE3 = 0

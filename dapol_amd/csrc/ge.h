@@ -101,6 +101,43 @@ DAPOL_HD void ge_dbl(ge_p3& r, const ge_p3& p, bool want_t) {
     if (want_t) fe_mul(r.T, H, E);
 }
 
+// Projective precomputed point for repeated additions of the same variable point: (Y+X, Y-X, Z, 2dT), all reduced.
+struct ge_cached {
+    fe YpX, YmX, Z, T2d;
+};
+DAPOL_HD void ge_to_cached(ge_cached& r, const ge_p3& p) {
+    fe t;
+    fe_addc(r.YpX, p.Y, p.X);
+    fe_sub(t, p.Y, p.X);
+    fe_carry(r.YmX, t);
+    r.Z = p.Z;
+    fe_mul(r.T2d, p.T, FE_D2);
+}
+// r = p + (neg ? -q : q).  8 mul + 1 carry.
+DAPOL_HD void ge_add_cached(ge_p3& r, const ge_p3& p, const ge_cached& q, bool neg) {
+    fe ypx, ymx, A, B, C, D, E, F, G, H, qa = q.YmX, qb = q.YpX;
+    fe_cswap(qa, qb, neg);
+    fe_add(ypx, p.Y, p.X);          // loose(2)
+    fe_sub(ymx, p.Y, p.X);          // tight
+    fe_mul(A, ymx, qa);
+    fe_mul(B, ypx, qb);
+    fe_mul(C, p.T, q.T2d);
+    fe nC;
+    fe_neg(nC, C);
+    fe_cmov(C, nC, neg);
+    fe_mul(D, p.Z, q.Z);
+    fe_add(D, D, D);                // loose(2)
+    fe_sub(E, B, A);
+    fe_add(H, B, A);
+    fe_sub(F, D, C);
+    fe_add(G, D, C);
+    fe_carry(G, G);
+    fe_mul(r.X, F, E);
+    fe_mul(r.Y, H, G);
+    fe_mul(r.Z, F, G);
+    fe_mul(r.T, H, E);
+}
+
 DAPOL_HD void ge_to_niels(ge_niels& r, const fe& x, const fe& y) {  // affine x, y (reduced)
     fe t;
     fe_addc(r.ypx, y, x);

@@ -63,7 +63,7 @@ __global__ void k_ctx_points(int32_t* base_pts /*[rows][40]*/, const uint32_t* u
     st_p3(base_pts + (size_t)r * 40, p);
 }
 // PedersenGens::default(): B = ristretto basepoint, B_blinding = hash_from_bytes::<Sha3_512>(B.compress()).
-// Lane 0 -> 256^w B_blinding rows, lane 1 -> 256^w B rows.
+// Lane 0 -> 2^(W w) B_blinding rows, lane 1 -> 2^(W w) B rows.
 __global__ void k_ctx_pedersen(int32_t* base_pts, int P) {
     int t = threadIdx.x;
     if (t >= 2) return;
@@ -84,10 +84,10 @@ __global__ void k_ctx_pedersen(int32_t* base_pts, int P) {
         }
         ge_from_uniform(p, w);
     }
-    int row0 = 128 * P + (t == 0 ? 0 : 32);
-    for (int w = 0; w < 32; w++) {
+    int row0 = 128 * P + (t == 0 ? 0 : NWIN);
+    for (int w = 0; w < NWIN; w++) {
         st_p3(base_pts + (size_t)(row0 + w) * 40, p);
-        for (int d = 0; d < 8; d++) { ge_p3 q; ge_dbl(q, p, true); p = q; }
+        for (int d = 0; d < WBITS; d++) { ge_p3 q; ge_dbl(q, p, true); p = q; }
     }
 }
 // One lane per table entry: k * base, normalised to affine niels form.
@@ -102,7 +102,7 @@ __global__ void k_ctx_table(int32_t* table, const int32_t* base_pts, int n_rows)
         ge_p3 base, acc, t;
         ld_p3(base, base_pts + (size_t)row * 40);
         ge_identity(acc);
-        for (int b = 7; b >= 0; b--) {
+        for (int b = WBITS - 1; b >= 0; b--) {
             ge_dbl(t, acc, true);
             acc = t;
             if ((k >> b) & 1) { ge_add(t, acc, base); acc = t; }

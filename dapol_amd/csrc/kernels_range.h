@@ -36,9 +36,11 @@ struct RangeArgs {
     const uint32_t* tape;       // [B][m(2n+4)][16] or null
     // scratch
     sc* a; sc* b; sc* s1; sc* s2;       // [B][N] each
-    int8_t* dig;                        // [B][32][TP]
+    dig_t* dig;                         // [B][NWIN][TP] signed radix-2^WBITS digits
     ProofState* st;                     // [B]
     int32_t* PA; int32_t* P0; int32_t* P1;   // [B][40] partial points
+    int32_t* tailT;                     // [B][64][8][40]  per-lane window tables of the materialised folded generators
+    sc* tailS;                          // [B][64]         running u^{+-1} coefficients of those generators
     uint32_t* out;                      // [B][out_words]
     int out_words;
 };
@@ -72,17 +74,13 @@ __device__ __forceinline__ void st_sc(sc* p, const sc& r) {
 __device__ __forceinline__ void write_digits(const RangeArgs& A, size_t b, int pos, const sc& s_mont) {
     uint32_t c[8];
     sc_from_mont(c, s_mont);
-    int8_t* d = A.dig + (size_t)b * 32 * A.TP + pos;
-    int carry = 0;
-    for (int i = 0; i < 32; i++) {
-        int x = (int)((c[i >> 2] >> (8 * (i & 3))) & 0xff) + carry;
-        carry = (x > 127 && i < 31) ? 1 : 0;
-        d[(size_t)i * A.TP] = (int8_t)(x - (carry << 8));
-    }
+    dig_t* d = A.dig + (size_t)b * NWIN * A.TP + pos;
+    const int TP = A.TP;
+    sc_recode_w<WBITS>(c, [&](int i, int digit) { d[(size_t)i * TP] = (dig_t)digit; });
 }
 __device__ __forceinline__ void zero_digits(const RangeArgs& A, size_t b, int pos) {
-    int8_t* d = A.dig + (size_t)b * 32 * A.TP + pos;
-    for (int i = 0; i < 32; i++) d[(size_t)i * A.TP] = 0;
+    dig_t* d = A.dig + (size_t)b * NWIN * A.TP + pos;
+    for (int i = 0; i < NWIN; i++) d[(size_t)i * A.TP] = 0;
 }
 
 // List position -> generator.  A digit row holds two lists of N terms each: lanes 0-31 of the MSM wave walk
@@ -180,26 +178,27 @@ __global__ __launch_bounds__(64) void k_rp_A(RangeArgs A, TableView tbl) {
 
 // ------------------------------------------------------------------- K2: the fixed-base MSM (dominant kernel)
 // One wavefront per proof.  Lane l owns the terms at positions 64*i + l of the digit rows (N/32 terms), walks
-// the 32 signed 8-bit windows from the top with 8 shared doublings per window (Straus), and looks every digit up
-// in the generator's 129-entry row (one 128-byte cache line per lookup, L2 / Infinity-Cache resident).
+// the NWIN signed WBITS-bit windows from the top with WBITS shared doublings per window (Straus), and looks every
+// digit up in the generator's row (one 128-byte cache line per lookup, L2 / Infinity-Cache resident).
 // Lanes 0-31 accumulate list 0, lanes 32-63 list 1; two 32-lane LDS tree reductions give P0 and P1.
+template <bool MATERIALIZE>
 __global__ __launch_bounds__(64) void k_rp_msm(RangeArgs A, TableView tbl, int round) {
     __shared__ int32_t lds[40 * 64];
     size_t b = blockIdx.x;
     int l = threadIdx.x, side = l >> 5, ql = l & 31;
     int niter = (A.N + 31) >> 5;
-    const int8_t* dig = A.dig + b * 32 * (size_t)A.TP;
+    const dig_t* dig = A.dig + b * NWIN * (size_t)A.TP;
     ge_p3 acc;
     ge_identity(acc);
-    for (int w = 31; w >= 0; w--) {
-        if (w != 31) {
-            for (int d = 0; d < 8; d++) {
+    for (int w = NWIN - 1; w >= 0; w--) {
+        if (w != NWIN - 1) {
+            for (int d = 0; d < WBITS; d++) {
                 ge_p3 t;
-                ge_dbl(t, acc, d == 7);
+                ge_dbl(t, acc, d == WBITS - 1);
                 acc = t;
             }
         }
-        const int8_t* dw = dig + (size_t)w * A.TP + l;
+        const dig_t* dw = dig + (size_t)w * A.TP + l;
         for (int i = 0; i < niter; i++) {
             int q = 32 * i + ql;
             if (q < A.N) {
@@ -210,8 +209,142 @@ __global__ __launch_bounds__(64) void k_rp_msm(RangeArgs A, TableView tbl, int r
             }
         }
     }
-    wave_reduce_point(acc, lds, l, 32);
-    if (ql == 0) st_p3((side ? A.P1 : A.P0) + b * 40, acc);
+    if constexpr (MATERIALIZE) {
+        // Hybrid IPA: with the S-layout lane l owns exactly the generators j = l mod 32 (mod 32), so fed with the
+        // s-vector digits its accumulator IS the folded generator G'_(l&31) (lanes 0-31) / H'_(l&31) (lanes 32-63) of
+        // the round whose vectors have length 32.  Keep it (k_rp_tail_table turns it into a window table).
+        st_p3(A.tailT + (b * 64 + l) * (size_t)(8 * 40), acc);
+    } else {
+        wave_reduce_point(acc, lds, l, 32);
+        if (ql == 0) st_p3((side ? A.P1 : A.P0) + b * 40, acc);
+    }
+}
+
+// Per-lane table of the multiples 1..8 of each materialised folded generator, in cached form; coefficient := 1.
+__global__ __launch_bounds__(64) void k_rp_tail_table(RangeArgs A) {
+    size_t g = (size_t)blockIdx.x * 64 + threadIdx.x;          // (proof, lane) flattened
+    if (g >= A.B * 64) return;
+    int32_t* T = A.tailT + g * (size_t)(8 * 40);
+    ge_p3 base, mul;
+    ld_p3(base, T);
+    mul = base;
+    ge_cached c1;
+    ge_to_cached(c1, base);
+    for (int e = 0; e < 8; e++) {
+        ge_cached c;
+        ge_to_cached(c, mul);
+        int32_t w[40];
+        for (int i = 0; i < 10; i++) { w[i] = c.YpX.v[i]; w[10 + i] = c.YmX.v[i]; w[20 + i] = c.Z.v[i]; w[30 + i] = c.T2d.v[i]; }
+        int4* q4 = reinterpret_cast<int4*>(T + e * 40);
+        for (int i = 0; i < 10; i++) q4[i] = make_int4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+        if (e < 7) { ge_p3 t; ge_add_cached(t, mul, c1, false); mul = t; }
+    }
+    sc one;
+    sc_one_mont(one);
+    st_sc(A.tailS + g, one);
+}
+
+// Digits of the s-vectors themselves, in the S layout (list 0 = s_G over G, list 1 = s_H over H): input of the
+// materialising MSM above.  grid = B * (TP/64) blocks of 64.
+__global__ __launch_bounds__(64) void k_rp_mat_prep(RangeArgs A) {
+    int nch = A.TP >> 6;
+    size_t b = blockIdx.x / nch;
+    int ch = blockIdx.x % nch, l = threadIdx.x, side = l >> 5, q = 32 * ch + (l & 31), pos = 64 * ch + l;
+    if (q >= A.N) { zero_digits(A, b, pos); return; }
+    sc s;
+    ld_sc(s, (side ? A.s2 : A.s1) + b * A.N + q);
+    write_digits(A, b, pos, s);
+}
+
+// Tail round k (vector length n = N >> k <= 32): every lane multiplies ITS folded generator by its round scalar
+// (a or b entry times the running coefficient) -- one variable-base scalar multiplication per lane with signed 4-bit
+// windows over the lane's own table -- and two masked wave reductions give L_k and R_k (without the c*Q terms).
+__global__ __launch_bounds__(64) void k_rp_tail_mul(RangeArgs A, int round) {
+    __shared__ int32_t lds[40 * 64];
+    size_t b = blockIdx.x;
+    int l = threadIdx.x, isH = l >> 5, i = l & 31;
+    int lgh = A.lgN - 1 - round, half = 1 << lgh;
+    int off = i & (half - 1);
+    bool upper = (i >> lgh) & 1;
+    int vi = upper ? off : off + half;
+    sc v, cf, p;
+    ld_sc(v, (isH ? A.b : A.a) + b * A.N + vi);
+    ld_sc(cf, A.tailS + b * 64 + l);
+    sc_montmul(p, v, cf);
+    uint32_t k[8];
+    sc_from_mont(k, p);
+    const int32_t* T = A.tailT + (b * 64 + l) * (size_t)(8 * 40);
+    ge_p3 acc;
+    ge_identity(acc);
+    // signed radix-16 digits, most significant first (64 digits cover 256 bits; canonical scalars < 2^253)
+    int dig[64];
+    {
+        int carry = 0;
+        for (int j = 0; j < 64; j++) {
+            int x = (int)((k[j >> 3] >> (4 * (j & 7))) & 15) + carry;
+            carry = (x > 8 && j < 63) ? 1 : 0;
+            dig[j] = x - (carry << 4);
+        }
+    }
+    for (int j = 63; j >= 0; j--) {
+        if (j != 63) {
+            for (int d = 0; d < 4; d++) {
+                ge_p3 t;
+                ge_dbl(t, acc, d == 3);
+                acc = t;
+            }
+        }
+        int d = dig[j];
+        int ad = d < 0 ? -d : d;
+        int e = ad ? ad - 1 : 0;
+        const int4* q4 = reinterpret_cast<const int4*>(T + e * 40);
+        int32_t w[40];
+        for (int t = 0; t < 10; t++) { int4 x = q4[t]; w[4 * t] = x.x; w[4 * t + 1] = x.y; w[4 * t + 2] = x.z; w[4 * t + 3] = x.w; }
+        ge_cached c;
+        for (int t = 0; t < 10; t++) { c.YpX.v[t] = w[t]; c.YmX.v[t] = w[10 + t]; c.Z.v[t] = w[20 + t]; c.T2d.v[t] = w[30 + t]; }
+        ge_p3 r;
+        ge_add_cached(r, acc, c, d < 0);
+        if (ad) acc = r;
+    }
+    // L takes G upper / H lower, R takes G lower / H upper
+    bool toL = isH ? !upper : upper;
+    ge_p3 id, part;
+    ge_identity(id);
+    part = toL ? acc : id;
+    wave_reduce_point(part, lds, l, 64);
+    if (l == 0) st_p3(A.P0 + b * 40, part);
+    part = toL ? id : acc;
+    wave_reduce_point(part, lds, l, 64);
+    if (l == 0) st_p3(A.P1 + b * 40, part);
+}
+
+// After challenge u_k of a tail round: fold a, b and update the 64 running coefficients (one block of 64 per proof).
+__global__ __launch_bounds__(64) void k_rp_tail_fold(RangeArgs A, int round) {
+    size_t b = blockIdx.x;
+    int l = threadIdx.x, isH = l >> 5, i = l & 31;
+    const ProofState& ps = A.st[b];
+    sc u = ps.u, ui = ps.u_inv;
+    int lgh = A.lgN - 1 - round, half = 1 << lgh;
+    bool upper = (i >> lgh) & 1;
+    sc s, t;
+    ld_sc(s, A.tailS + b * 64 + l);
+    sc_montmul(t, s, isH ? (upper ? ui : u) : (upper ? u : ui));
+    st_sc(A.tailS + b * 64 + l, t);
+    if (l < half) {
+        sc lo, hi, r;
+        ld_sc(lo, A.a + b * A.N + l);
+        ld_sc(hi, A.a + b * A.N + half + l);
+        sc_montmul(lo, lo, u);
+        sc_montmul(hi, hi, ui);
+        sc_add(r, lo, hi);
+        st_sc(A.a + b * A.N + l, r);
+        ld_sc(lo, A.b + b * A.N + l);
+        ld_sc(hi, A.b + b * A.N + half + l);
+        sc_montmul(lo, lo, ui);
+        sc_montmul(hi, hi, u);
+        sc_add(r, lo, hi);
+        st_sc(A.b + b * A.N + l, r);
+    }
 }
 
 // --------------------------------------------------------------------------------------- transcript helpers

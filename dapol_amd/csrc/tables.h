@@ -1,12 +1,13 @@
 // Fixed-base window tables in HBM (L2 / Infinity-Cache resident) and the lookups the kernels use.
 //
-// Layout: a ROW holds the 129 multiples k*P, k = 0..128, of one base point P as 128-byte entries
+// Layout (W = DAPOL_WBITS-bit signed windows): a ROW holds the 2^(W-1)+1 multiples k*P, k = 0..2^(W-1), of one
+// base point P as 128-byte entries
 // (affine niels form: y+x, y-x, 2dxy as 3 x 10 int32 limbs, 2 words of padding -> eight 16-byte loads per lookup,
 // one cache line).  Entry 0 is the identity so a zero digit needs no branch; digits are signed (-128..128).
 //   rows [0, 64*P)            G[party][bit]      (P = max_parties)       bulletproofs BulletproofGens G chain
 //   rows [64*P, 128*P)        H[party][bit]                              ... H chain
-//   rows [128*P, 128*P+32)    256^w * B_blinding, w = 0..31             PedersenGens::default().B_blinding
-//   rows [128*P+32, 128*P+64) 256^w * B,          w = 0..31             PedersenGens::default().B
+//   rows [128*P, 128*P+NWIN)        2^(W w) * B_blinding, w = 0..NWIN-1   PedersenGens::default().B_blinding
+//   rows [128*P+NWIN, 128*P+2NWIN)  2^(W w) * B,          w = 0..NWIN-1   PedersenGens::default().B
 // The per-window rows of B / B_blinding make single-base commitments doubling-free (32 mixed adds); the G/H
 // rows are used Straus-style (shared doublings across the terms a lane owns).
 #pragma once
@@ -14,7 +15,24 @@
 
 namespace dapol {
 
-enum { TBL_ENTRIES = 129, TBL_ENTRY_WORDS = 32, TBL_ROW_WORDS = TBL_ENTRIES * TBL_ENTRY_WORDS };
+#ifndef DAPOL_WBITS
+#define DAPOL_WBITS 10         // window width of the fixed-base tables (table size doubles per bit).  Measured on
+                               // MI355X, 2^16 proofs n=64 m=32 (profiles/r01_wbits_ab.txt): k_rp_msm 178.8 / 164.5 / 151.2 ms
+                               // per launch at 8 / 9 / 10 bits; proofs byte-identical.  10 bits = 273 MB of tables.
+#endif
+enum {
+    WBITS = DAPOL_WBITS,
+    NWIN = (255 + WBITS - 1) / WBITS,             // windows per 255-bit scalar: 32 / 29 / 26
+    NWIN64 = (64 + WBITS - 1) / WBITS + 1,        // windows of a 64-bit value (+1 for the recoding carry)
+    TBL_ENTRIES = (1 << (WBITS - 1)) + 1,
+    TBL_ENTRY_WORDS = 32,
+    TBL_ROW_WORDS = TBL_ENTRIES * TBL_ENTRY_WORDS
+};
+#if DAPOL_WBITS > 8
+typedef int16_t dig_t;
+#else
+typedef int8_t dig_t;
+#endif
 
 struct TableView {
     const int32_t* base;   // device pointer
@@ -22,8 +40,8 @@ struct TableView {
     __host__ __device__ int row_G(int party, int bit) const { return party * 64 + bit; }
     __host__ __device__ int row_H(int party, int bit) const { return 64 * max_parties + party * 64 + bit; }
     __host__ __device__ int row_Bb(int w) const { return 128 * max_parties + w; }
-    __host__ __device__ int row_B(int w) const { return 128 * max_parties + 32 + w; }
-    __host__ __device__ int n_rows() const { return 128 * max_parties + 64; }
+    __host__ __device__ int row_B(int w) const { return 128 * max_parties + NWIN + w; }
+    __host__ __device__ int n_rows() const { return 128 * max_parties + 2 * NWIN; }
 };
 
 #if defined(__HIPCC__)
@@ -52,22 +70,26 @@ __device__ __forceinline__ void tbl_madd(ge_p3& acc, const TableView& t, int row
     acc = r;
 }
 
-// acc += s * Base for a 255-bit integer s (eight words), using the 32 per-window rows starting at row0.
+// acc += s * Base for a 255-bit integer s (eight words), using the NWIN per-window rows starting at row0.
 __device__ __forceinline__ void tbl_fixed_mul_add(ge_p3& acc, const TableView& t, int row0, const uint32_t* s8) {
     int carry = 0;
-    for (int i = 0; i < 32; i++) {
-        int b = (int)((s8[i >> 2] >> (8 * (i & 3))) & 0xff) + carry;
-        carry = (b > 127 && i < 31) ? 1 : 0;
-        tbl_madd(acc, t, row0 + i, b - (carry << 8));
+    for (int i = 0; i < NWIN; i++) {
+        int o = i * WBITS, wd = o >> 5, sh = o & 31;
+        uint32_t lo = s8[wd] >> sh;
+        uint32_t hi = (sh && wd + 1 < 8) ? (s8[wd + 1] << (32 - sh)) : 0u;
+        int b = (int)((lo | hi) & ((1u << WBITS) - 1)) + carry;
+        carry = (b >= (1 << (WBITS - 1)) && i < NWIN - 1) ? 1 : 0;
+        tbl_madd(acc, t, row0 + i, b - (carry << WBITS));
     }
 }
-// acc += v * B for a 64-bit v (nine signed windows)
+// acc += v * B for a 64-bit v (NWIN64 signed windows)
 __device__ __forceinline__ void tbl_fixed_mul_add_u64(ge_p3& acc, const TableView& t, int row0, uint64_t v) {
     int carry = 0;
-    for (int i = 0; i < 9; i++) {
-        int b = (i < 8 ? (int)((v >> (8 * i)) & 0xff) : 0) + carry;
-        carry = b > 127 ? 1 : 0;
-        tbl_madd(acc, t, row0 + i, b - (carry << 8));
+    for (int i = 0; i < NWIN64; i++) {
+        int o = i * WBITS;
+        int b = (o < 64 ? (int)((v >> o) & ((1u << WBITS) - 1)) : 0) + carry;
+        carry = b >= (1 << (WBITS - 1)) ? 1 : 0;
+        tbl_madd(acc, t, row0 + i, b - (carry << WBITS));
     }
 }
 #endif
