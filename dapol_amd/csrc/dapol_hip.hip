@@ -10,6 +10,7 @@
 #include "../../include/dapol_hip.h"
 #include "kernels_ctx_tree.h"
 #include "kernels_range.h"
+#include "kernels_verify.h"
 
 using namespace dapol;
 

@@ -330,3 +330,61 @@ def test_bench_layout_at_baseline_config_properties(gpu_ctx, hip_lib, ref):
     for k in range(len(sample)):
         assert w.proofs(k * 512, 1, ps).tobytes() == out.raw[k * ps:(k + 1) * ps]
     ref.ref_tree_free(t)
+
+
+# ------------------------------------------------------------------------------------------------ verifier (row a9)
+def test_verify_golden_and_tampered(gpu_ctx):
+    for c in load_golden("range.json"):
+        n, m = c["n"], c["m"]
+        proof = np.frombuffer(bytes.fromhex(c["proof"]), np.uint8)
+        Vs = _arr(c["commitments"]).reshape(1, m, 32)
+        cases, expect = [proof], [1]
+        for off in (3, 40, 100, 130, 170, 200, 230, len(proof) - 40, len(proof) - 5):      # A, S, T2, t_x, tau, mu, L0, a, b
+            bad = proof.copy()
+            bad[off] ^= 4
+            cases.append(bad)
+            expect.append(0)
+        nc = proof.copy()                      # non-canonical scalar: t_x + l
+        tx = int.from_bytes(proof[128:160].tobytes(), "little") + (2**252 + 27742317777372353535851937790883648493)
+        if tx < 2**256:
+            nc[128:160] = np.frombuffer(tx.to_bytes(32, "little"), np.uint8)
+            cases.append(nc)
+            expect.append(0)
+        zero_pt = proof.copy()
+        zero_pt[0:32] = 0                      # identity A: validate_and_append_point fails
+        cases.append(zero_pt)
+        expect.append(0)
+        ok = gpu_ctx.range_verify_batch(n, m, np.stack(cases), np.repeat(Vs, len(cases), axis=0), verify_seed=SEED)
+        assert list(ok) == expect, (n, m, list(ok))
+        badV = Vs.copy()
+        badV[0, m - 1, 1] ^= 2
+        assert list(gpu_ctx.range_verify_batch(n, m, proof.reshape(1, -1), badV, verify_seed=SEED)) == [0]
+
+
+@pytest.mark.parametrize("n_bits,m,b", [(64, 32, 40), (64, 1, 70), (16, 4, 65)])
+def test_prove_then_verify_roundtrip(gpu_ctx, ref, n_bits, m, b):
+    rng = np.random.default_rng(n_bits + m)
+    v = rng.integers(0, 2**n_bits if n_bits < 64 else 2**63, size=(b, m), dtype=np.uint64)
+    r = rng.integers(0, 256, size=(b, m, 32), dtype=np.uint8)
+    r[:, :, 31] &= 0x0F
+    proofs = gpu_ctx.range_prove_batch(n_bits, m, v, r, nonce_seed=SEED, stream_id=np.arange(b, dtype=np.uint64))
+    C, _ = gpu_ctx.commit_hash_batch(v.reshape(-1), r.reshape(-1, 32))
+    Vs = C.reshape(b, m, 32)
+    assert gpu_ctx.range_verify_batch(n_bits, m, proofs, Vs, verify_seed=SEED).all()
+    swapped = Vs.copy()
+    swapped[[0, 1]] = swapped[[1, 0]]          # proofs 0 and 1 against each other's commitments
+    ok = gpu_ctx.range_verify_batch(n_bits, m, proofs, swapped, verify_seed=bytes(32))
+    assert list(ok[:2]) == [0, 0] and ok[2:].all()
+    # GPU verdicts agree with the CPU oracle's verifier on the same bytes
+    ps = proofs.shape[1]
+    c7 = bytes([7]) + bytes(31)
+    for k in (0, b - 1):
+        assert ref.ref_range_verify(n_bits, m, proofs[k].tobytes(), ctypes.c_size_t(ps), Vs[k].tobytes(), c7, 0) == 1
+
+
+def test_out_of_range_value_is_rejected(gpu_ctx, pyref):
+    """A proof made for v >= 2^n (built by the oracle's prover, which does not check) must not verify."""
+    bl = [pyref.scalar_from_wide(pyref.seed_wide(SEED, 9, 0, i)) for i in range(2)]
+    pr = pyref.range_prove([256, 1], bl, 8, pyref.Tape(seed=SEED, stream_id=7))
+    Vs = np.array([list(pyref.pedersen_commit(v, b).compress()) for v, b in zip([256, 1], bl)], np.uint8).reshape(1, 2, 32)
+    assert list(gpu_ctx.range_verify_batch(8, 2, np.frombuffer(pr, np.uint8).reshape(1, -1), Vs, verify_seed=SEED)) == [0]
