@@ -2,6 +2,7 @@
 // byte of arithmetic (generator derivation included) runs on the GPU; there is no CPU fallback.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -100,26 +101,42 @@ int32_t dapol_ctx_create(int32_t device, int32_t max_parties, int32_t digest_id,
     struct Guard { dapol_ctx* c; ~Guard() { if (c) dapol_ctx_destroy(c); } } guard{c};
     HIPCHK(hipStreamCreate(&c->stream));
     const int P = max_parties;
-    TableView tv{nullptr, P};
+    // window width: the widest (<= 15 bits) whose tables fit the budget (DAPOL_TABLE_GB, default 12 GB), or DAPOL_WBITS
+    int wbits = WBITS_MIN;
+    {
+        const char* eb = getenv("DAPOL_TABLE_GB");
+        double budget = (eb ? atof(eb) : 12.0) * 1e9;
+        for (int w = WBITS_MIN; w <= WBITS_MAX; w++) {
+            TableView t{nullptr, P, w};
+            if ((double)t.n_rows() * (double)t.row_words() * 4.0 <= budget) wbits = w;
+        }
+        const char* ew = getenv("DAPOL_WBITS");
+        if (ew) {
+            int w = atoi(ew);
+            if (w < WBITS_MIN || w > WBITS_MAX) return fail(DAPOL_ERR_INVALID_ARGUMENT, "DAPOL_WBITS must be in [8, 15]");
+            wbits = w;
+        }
+    }
+    TableView tv{nullptr, P, wbits};
     const int rows = tv.n_rows();
     DevBuf<uint32_t> uniform;
     DevBuf<int32_t> base_pts;
     HIPCHK(uniform.alloc((size_t)2 * P * 64 * 16));
     HIPCHK(base_pts.alloc((size_t)rows * 40));
-    HIPCHK(c->table.alloc((size_t)rows * TBL_ROW_WORDS));
+    HIPCHK(c->table.alloc((size_t)rows * tv.row_words()));
     HIPCHK(c->gens_comp.alloc((size_t)rows * 8));
     hipLaunchKernelGGL(k_ctx_chains, dim3(nblk(2 * P, 64)), dim3(64), 0, c->stream, uniform.p, P);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_ctx_points, dim3(nblk(128 * P, 64)), dim3(64), 0, c->stream, base_pts.p, uniform.p, P);
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_ctx_pedersen, dim3(1), dim3(64), 0, c->stream, base_pts.p, P);
+    hipLaunchKernelGGL(k_ctx_pedersen, dim3(1), dim3(64), 0, c->stream, base_pts.p, P, wbits, tv.nwin());
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_ctx_table, dim3(nblk((size_t)rows * TBL_ENTRIES, 64)), dim3(64), 0, c->stream, c->table.p, base_pts.p, rows);
+    hipLaunchKernelGGL(k_ctx_table, dim3(nblk((size_t)rows * tv.entries(), 64)), dim3(64), 0, c->stream, c->table.p, base_pts.p, rows, wbits, tv.entries());
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_ctx_compress, dim3(nblk(rows, 64)), dim3(64), 0, c->stream, c->gens_comp.p, base_pts.p, rows);
     LAUNCH_CHECK();
     HIPCHK(hipStreamSynchronize(c->stream));
-    c->tv = TableView{c->table.p, P};
+    c->tv = TableView{c->table.p, P, wbits};
     guard.c = nullptr;
     *out = c;
     return DAPOL_OK;

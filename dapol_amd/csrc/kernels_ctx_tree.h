@@ -64,7 +64,7 @@ __global__ void k_ctx_points(int32_t* base_pts /*[rows][40]*/, const uint32_t* u
 }
 // PedersenGens::default(): B = ristretto basepoint, B_blinding = hash_from_bytes::<Sha3_512>(B.compress()).
 // Lane 0 -> 2^(W w) B_blinding rows, lane 1 -> 2^(W w) B rows.
-__global__ void k_ctx_pedersen(int32_t* base_pts, int P) {
+__global__ void k_ctx_pedersen(int32_t* base_pts, int P, int wbits, int nwin) {
     int t = threadIdx.x;
     if (t >= 2) return;
     ge_p3 p;
@@ -84,17 +84,17 @@ __global__ void k_ctx_pedersen(int32_t* base_pts, int P) {
         }
         ge_from_uniform(p, w);
     }
-    int row0 = 128 * P + (t == 0 ? 0 : NWIN);
-    for (int w = 0; w < NWIN; w++) {
+    int row0 = 128 * P + (t == 0 ? 0 : nwin);
+    for (int w = 0; w < nwin; w++) {
         st_p3(base_pts + (size_t)(row0 + w) * 40, p);
-        for (int d = 0; d < WBITS; d++) { ge_p3 q; ge_dbl(q, p, true); p = q; }
+        for (int d = 0; d < wbits; d++) { ge_p3 q; ge_dbl(q, p, true); p = q; }
     }
 }
 // One lane per table entry: k * base, normalised to affine niels form.
-__global__ void k_ctx_table(int32_t* table, const int32_t* base_pts, int n_rows) {
+__global__ void k_ctx_table(int32_t* table, const int32_t* base_pts, int n_rows, int wbits, int entries) {
     size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (size_t)n_rows * TBL_ENTRIES) return;
-    int row = (int)(gid / TBL_ENTRIES), k = (int)(gid % TBL_ENTRIES);
+    if (gid >= (size_t)n_rows * entries) return;
+    int row = (int)(gid / entries), k = (int)(gid % entries);
     ge_niels q;
     if (k == 0) {
         ge_niels_identity(q);
@@ -102,7 +102,7 @@ __global__ void k_ctx_table(int32_t* table, const int32_t* base_pts, int n_rows)
         ge_p3 base, acc, t;
         ld_p3(base, base_pts + (size_t)row * 40);
         ge_identity(acc);
-        for (int b = WBITS - 1; b >= 0; b--) {
+        for (int b = wbits - 1; b >= 0; b--) {
             ge_dbl(t, acc, true);
             acc = t;
             if ((k >> b) & 1) { ge_add(t, acc, base); acc = t; }
@@ -113,7 +113,7 @@ __global__ void k_ctx_table(int32_t* table, const int32_t* base_pts, int n_rows)
         fe_mul(y, acc.Y, zi);
         ge_to_niels(q, x, y);
     }
-    int32_t* e = table + (size_t)row * TBL_ROW_WORDS + (size_t)k * TBL_ENTRY_WORDS;
+    int32_t* e = table + ((size_t)row * entries + (size_t)k) * TBL_ENTRY_WORDS;
     for (int i = 0; i < 10; i++) { e[i] = q.ypx.v[i]; e[10 + i] = q.ymx.v[i]; e[20 + i] = q.xy2d.v[i]; }
     e[30] = 0; e[31] = 0;
 }

@@ -24,6 +24,7 @@ struct ProofState {             // per proof, lives in HBM between phase kernels
 
 struct RangeArgs {
     int n, m, N, lgN, TP;       // bits per party, parties, n*m, log2 N, digit-row length (>= 64)
+    int wbits, nwin;            // window width of the context's tables and windows per scalar
     size_t B;                   // proofs in this chunk
     // inputs
     const uint64_t* vals;       // [B][m]
@@ -36,7 +37,7 @@ struct RangeArgs {
     const uint32_t* tape;       // [B][m(2n+4)][16] or null
     // scratch
     sc* a; sc* b; sc* s1; sc* s2;       // [B][N] each
-    dig_t* dig;                         // [B][NWIN][TP] signed radix-2^WBITS digits
+    dig_t* dig;                         // [B][nwin][TP] signed radix-2^wbits digits
     ProofState* st;                     // [B]
     int32_t* PA; int32_t* P0; int32_t* P1;   // [B][40] partial points
     int32_t* tailT;                     // [B][64][8][40]  per-lane window tables of the materialised folded generators
@@ -74,13 +75,13 @@ __device__ __forceinline__ void st_sc(sc* p, const sc& r) {
 __device__ __forceinline__ void write_digits(const RangeArgs& A, size_t b, int pos, const sc& s_mont) {
     uint32_t c[8];
     sc_from_mont(c, s_mont);
-    dig_t* d = A.dig + (size_t)b * NWIN * A.TP + pos;
+    dig_t* d = A.dig + (size_t)b * A.nwin * A.TP + pos;
     const int TP = A.TP;
-    sc_recode_w<WBITS>(c, [&](int i, int digit) { d[(size_t)i * TP] = (dig_t)digit; });
+    sc_recode_w(A.wbits, c, [&](int i, int digit) { d[(size_t)i * TP] = (dig_t)digit; });
 }
 __device__ __forceinline__ void zero_digits(const RangeArgs& A, size_t b, int pos) {
-    dig_t* d = A.dig + (size_t)b * NWIN * A.TP + pos;
-    for (int i = 0; i < NWIN; i++) d[(size_t)i * A.TP] = 0;
+    dig_t* d = A.dig + (size_t)b * A.nwin * A.TP + pos;
+    for (int i = 0; i < A.nwin; i++) d[(size_t)i * A.TP] = 0;
 }
 
 // List position -> generator.  A digit row holds two lists of N terms each: lanes 0-31 of the MSM wave walk
@@ -102,7 +103,8 @@ __device__ __forceinline__ int term_generator(int round, int N, int lgN, int sid
     return (blk << (lgh + 1)) + off + (upper ? half : 0);
 }
 __device__ __forceinline__ int gen_row(const TableView& t, int n, int j, bool isH) {
-    int party = j / n, bit = j - party * n;
+    int lgn = 31 - __clz(n);                  // n is 8, 16, 32 or 64
+    int party = j >> lgn, bit = j & (n - 1);
     return isH ? t.row_H(party, bit) : t.row_G(party, bit);
 }
 
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(64) void k_rp_A(RangeArgs A, TableView tbl) {
 
 // ------------------------------------------------------------------- K2: the fixed-base MSM (dominant kernel)
 // One wavefront per proof.  Lane l owns the terms at positions 64*i + l of the digit rows (N/32 terms), walks
-// the NWIN signed WBITS-bit windows from the top with WBITS shared doublings per window (Straus), and looks every
+// the nwin signed W-bit windows from the top with W shared doublings per window (Straus), and looks every
 // digit up in the generator's row (one 128-byte cache line per lookup, L2 / Infinity-Cache resident).
 // Lanes 0-31 accumulate list 0, lanes 32-63 list 1; two 32-lane LDS tree reductions give P0 and P1.
 template <bool MATERIALIZE>
@@ -187,14 +189,15 @@ __global__ __launch_bounds__(64) void k_rp_msm(RangeArgs A, TableView tbl, int r
     size_t b = blockIdx.x;
     int l = threadIdx.x, side = l >> 5, ql = l & 31;
     int niter = (A.N + 31) >> 5;
-    const dig_t* dig = A.dig + b * NWIN * (size_t)A.TP;
+    const dig_t* dig = A.dig + b * A.nwin * (size_t)A.TP;
+    const int NW = A.nwin, W = A.wbits;
     ge_p3 acc;
     ge_identity(acc);
-    for (int w = NWIN - 1; w >= 0; w--) {
-        if (w != NWIN - 1) {
-            for (int d = 0; d < WBITS; d++) {
+    for (int w = NW - 1; w >= 0; w--) {
+        if (w != NW - 1) {
+            for (int d = 0; d < W; d++) {
                 ge_p3 t;
-                ge_dbl(t, acc, d == WBITS - 1);
+                ge_dbl(t, acc, d == W - 1);
                 acc = t;
             }
         }

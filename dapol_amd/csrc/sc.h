@@ -173,9 +173,9 @@ DAPOL_HD void sc_recode_s8(int16_t* d, const uint32_t* x) {
 
 // Signed radix-2^W recoding of a 255-bit integer: NW = ceil(255/W) digits in [-2^(W-1), 2^(W-1)] (the top digit
 // absorbs the last carry).  out(i, digit) is called for i = 0..NW-1.
-template <int W, typename F>
-DAPOL_HD void sc_recode_w(const uint32_t* x, F out) {
-    constexpr int NW = (255 + W - 1) / W;
+template <typename F>
+DAPOL_HD void sc_recode_w(int W, const uint32_t* x, F out) {
+    const int NW = (255 + W - 1) / W;
     int carry = 0;
     for (int i = 0; i < NW; i++) {
         int o = i * W, wd = o >> 5, sh = o & 31;

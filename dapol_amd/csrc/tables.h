@@ -1,13 +1,13 @@
 // Fixed-base window tables in HBM (L2 / Infinity-Cache resident) and the lookups the kernels use.
 //
-// Layout (W = DAPOL_WBITS-bit signed windows): a ROW holds the 2^(W-1)+1 multiples k*P, k = 0..2^(W-1), of one
+// Layout (W-bit signed windows): a ROW holds the 2^(W-1)+1 multiples k*P, k = 0..2^(W-1), of one
 // base point P as 128-byte entries
 // (affine niels form: y+x, y-x, 2dxy as 3 x 10 int32 limbs, 2 words of padding -> eight 16-byte loads per lookup,
 // one cache line).  Entry 0 is the identity so a zero digit needs no branch; digits are signed (-128..128).
 //   rows [0, 64*P)            G[party][bit]      (P = max_parties)       bulletproofs BulletproofGens G chain
 //   rows [64*P, 128*P)        H[party][bit]                              ... H chain
-//   rows [128*P, 128*P+NWIN)        2^(W w) * B_blinding, w = 0..NWIN-1   PedersenGens::default().B_blinding
-//   rows [128*P+NWIN, 128*P+2NWIN)  2^(W w) * B,          w = 0..NWIN-1   PedersenGens::default().B
+//   rows [128*P, 128*P+nwin)        2^(W w) * B_blinding, w = 0..nwin-1   PedersenGens::default().B_blinding
+//   rows [128*P+nwin, 128*P+2nwin)  2^(W w) * B,          w = 0..nwin-1   PedersenGens::default().B
 // The per-window rows of B / B_blinding make single-base commitments doubling-free (32 mixed adds); the G/H
 // rows are used Straus-style (shared doublings across the terms a lane owns).
 #pragma once
@@ -15,39 +15,33 @@
 
 namespace dapol {
 
-#ifndef DAPOL_WBITS
-#define DAPOL_WBITS 10         // window width of the fixed-base tables (table size doubles per bit).  Measured on
-                               // MI355X, 2^16 proofs n=64 m=32 (profiles/r01_wbits_ab.txt): k_rp_msm 178.8 / 164.5 / 151.2 ms
-                               // per launch at 8 / 9 / 10 bits; proofs byte-identical.  10 bits = 273 MB of tables.
-#endif
-enum {
-    WBITS = DAPOL_WBITS,
-    NWIN = (255 + WBITS - 1) / WBITS,             // windows per 255-bit scalar: 32 / 29 / 26
-    NWIN64 = (64 + WBITS - 1) / WBITS + 1,        // windows of a 64-bit value (+1 for the recoding carry)
-    TBL_ENTRIES = (1 << (WBITS - 1)) + 1,
-    TBL_ENTRY_WORDS = 32,
-    TBL_ROW_WORDS = TBL_ENTRIES * TBL_ENTRY_WORDS
-};
-#if DAPOL_WBITS > 8
+// The window width W is a property of the context (chosen at dapol_ctx_create from a table-memory budget, or the
+// DAPOL_WBITS environment variable): 8 <= W <= 15.  Measured on MI355X (profiles/r01_wbits_ab*.txt, 2^16 proofs
+// n=64 m=32, k_rp_msm per launch): 155 / 144 / 134 / 128 ms at W = 10 / 12 / 13 / 14, proofs byte-identical.  Past
+// W = 10 the tables (273 MB -> 4.4 GB at 14 bits) no longer fit the Infinity Cache and the lookups become ~4.7 TB/s of
+// random 128-byte HBM gathers: the kernel then sits between its VALU-issue roof and the HBM gather roof.
+enum { TBL_ENTRY_WORDS = 32, WBITS_MIN = 8, WBITS_MAX = 15 };
 typedef int16_t dig_t;
-#else
-typedef int8_t dig_t;
-#endif
 
 struct TableView {
     const int32_t* base;   // device pointer
     int32_t max_parties;
+    int32_t wbits;         // W
+    __host__ __device__ int nwin() const { return (255 + wbits - 1) / wbits; }          // windows per 255-bit scalar
+    __host__ __device__ int nwin64() const { return (64 + wbits - 1) / wbits + 1; }     // 64-bit value (+1: recoding carry)
+    __host__ __device__ int entries() const { return (1 << (wbits - 1)) + 1; }
+    __host__ __device__ size_t row_words() const { return (size_t)entries() * TBL_ENTRY_WORDS; }
     __host__ __device__ int row_G(int party, int bit) const { return party * 64 + bit; }
     __host__ __device__ int row_H(int party, int bit) const { return 64 * max_parties + party * 64 + bit; }
     __host__ __device__ int row_Bb(int w) const { return 128 * max_parties + w; }
-    __host__ __device__ int row_B(int w) const { return 128 * max_parties + NWIN + w; }
-    __host__ __device__ int n_rows() const { return 128 * max_parties + 2 * NWIN; }
+    __host__ __device__ int row_B(int w) const { return 128 * max_parties + nwin() + w; }
+    __host__ __device__ int n_rows() const { return 128 * max_parties + 2 * nwin(); }
 };
 
 #if defined(__HIPCC__)
 // Load entry |d| of `row`; the sign is applied by ge_madd.
 __device__ __forceinline__ void tbl_load(ge_niels& q, const TableView& t, int row, int absd) {
-    const int4* p = reinterpret_cast<const int4*>(t.base + (size_t)row * TBL_ROW_WORDS + (size_t)absd * TBL_ENTRY_WORDS);
+    const int4* p = reinterpret_cast<const int4*>(t.base + (size_t)row * t.row_words() + (size_t)absd * TBL_ENTRY_WORDS);
     int4 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3], a4 = p[4], a5 = p[5], a6 = p[6], a7 = p[7];
     q.ypx.v[0] = a0.x; q.ypx.v[1] = a0.y; q.ypx.v[2] = a0.z; q.ypx.v[3] = a0.w;
     q.ypx.v[4] = a1.x; q.ypx.v[5] = a1.y; q.ypx.v[6] = a1.z; q.ypx.v[7] = a1.w;
@@ -73,23 +67,25 @@ __device__ __forceinline__ void tbl_madd(ge_p3& acc, const TableView& t, int row
 // acc += s * Base for a 255-bit integer s (eight words), using the NWIN per-window rows starting at row0.
 __device__ __forceinline__ void tbl_fixed_mul_add(ge_p3& acc, const TableView& t, int row0, const uint32_t* s8) {
     int carry = 0;
-    for (int i = 0; i < NWIN; i++) {
-        int o = i * WBITS, wd = o >> 5, sh = o & 31;
+    const int W = t.wbits, NW = t.nwin();
+    for (int i = 0; i < NW; i++) {
+        int o = i * W, wd = o >> 5, sh = o & 31;
         uint32_t lo = s8[wd] >> sh;
         uint32_t hi = (sh && wd + 1 < 8) ? (s8[wd + 1] << (32 - sh)) : 0u;
-        int b = (int)((lo | hi) & ((1u << WBITS) - 1)) + carry;
-        carry = (b >= (1 << (WBITS - 1)) && i < NWIN - 1) ? 1 : 0;
-        tbl_madd(acc, t, row0 + i, b - (carry << WBITS));
+        int b = (int)((lo | hi) & ((1u << W) - 1)) + carry;
+        carry = (b >= (1 << (W - 1)) && i < NW - 1) ? 1 : 0;
+        tbl_madd(acc, t, row0 + i, b - (carry << W));
     }
 }
 // acc += v * B for a 64-bit v (NWIN64 signed windows)
 __device__ __forceinline__ void tbl_fixed_mul_add_u64(ge_p3& acc, const TableView& t, int row0, uint64_t v) {
     int carry = 0;
-    for (int i = 0; i < NWIN64; i++) {
-        int o = i * WBITS;
-        int b = (o < 64 ? (int)((v >> o) & ((1u << WBITS) - 1)) : 0) + carry;
-        carry = b >= (1 << (WBITS - 1)) ? 1 : 0;
-        tbl_madd(acc, t, row0 + i, b - (carry << WBITS));
+    const int W = t.wbits, NW = t.nwin64();
+    for (int i = 0; i < NW; i++) {
+        int o = i * W;
+        int b = (o < 64 ? (int)((v >> o) & ((1u << W) - 1)) : 0) + carry;
+        carry = b >= (1 << (W - 1)) ? 1 : 0;
+        tbl_madd(acc, t, row0 + i, b - (carry << W));
     }
 }
 #endif

@@ -107,9 +107,7 @@ void t_sc_recode(const uint8_t* in, int16_t* d) {
 void t_sc_recode_w(int w, const uint8_t* in, int* d) {
     uint32_t x[8];
     ld(x, in, 8);
-    if (w == 8) sc_recode_w<8>(x, [&](int i, int v) { d[i] = v; });
-    if (w == 9) sc_recode_w<9>(x, [&](int i, int v) { d[i] = v; });
-    if (w == 10) sc_recode_w<10>(x, [&](int i, int v) { d[i] = v; });
+    sc_recode_w(w, x, [&](int i, int v) { d[i] = v; });
 }
 void t_blake3_32(const uint8_t* in, uint8_t* out) {
     uint32_t w[8], o[8];

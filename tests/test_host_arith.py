@@ -85,11 +85,11 @@ def test_scalar_field(host_shim, pyref):
         d = (ctypes.c_int16 * 32)()
         host_shim.t_sc_recode(x.to_bytes(32, "little"), d)
         assert sum(int(d[i]) * 256**i for i in range(32)) == x and all(abs(int(v)) <= 128 for v in d)
-        for w in (8, 9, 10):
+        for w in (8, 9, 10, 12, 14, 15):
             nw = (255 + w - 1) // w
             dw = (ctypes.c_int * nw)()
             host_shim.t_sc_recode_w(w, x.to_bytes(32, "little"), dw)
-            assert sum(int(dw[i]) << (w * i) for i in range(nw)) == x and all(abs(int(v)) <= (1 << (w - 1)) for v in dw)
+            assert sum(int(dw[i]) << (w * i) for i in range(nw)) == x and all(abs(int(v)) <= (1 << (w - 1)) for v in dw) and all(abs(int(v)) < 32768 for v in dw)
 
 
 def test_hashes_and_transcript(host_shim, pyref):
