@@ -24,7 +24,7 @@ struct ProofState {             // per proof, lives in HBM between phase kernels
 
 struct RangeArgs {
     int n, m, N, lgN, TP;       // bits per party, parties, n*m, log2 N, digit-row length (>= 64)
-    int wbits, nwin;            // window width of the context's tables and windows per scalar
+    int wbits, nwin;            // window width of the context's tables; windows per CANONICAL scalar (tv.nwin_c())
     size_t B;                   // proofs in this chunk
     // inputs
     const uint64_t* vals;       // [B][m]
@@ -77,7 +77,7 @@ __device__ __forceinline__ void write_digits(const RangeArgs& A, size_t b, int p
     sc_from_mont(c, s_mont);
     dig_t* d = A.dig + (size_t)b * A.nwin * A.TP + pos;
     const int TP = A.TP;
-    sc_recode_w(A.wbits, c, [&](int i, int digit) { d[(size_t)i * TP] = (dig_t)digit; });
+    sc_recode_w(A.wbits, A.nwin, c, [&](int i, int digit) { d[(size_t)i * TP] = (dig_t)digit; });
 }
 __device__ __forceinline__ void zero_digits(const RangeArgs& A, size_t b, int pos) {
     dig_t* d = A.dig + (size_t)b * A.nwin * A.TP + pos;

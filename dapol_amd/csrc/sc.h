@@ -171,15 +171,15 @@ DAPOL_HD void sc_recode_s8(int16_t* d, const uint32_t* x) {
     }
 }
 
-// Signed radix-2^W recoding of a 255-bit integer: NW = ceil(255/W) digits in [-2^(W-1), 2^(W-1)] (the top digit
-// absorbs the last carry).  out(i, digit) is called for i = 0..NW-1.
+// Signed radix-2^W recoding into NW digits in [-2^(W-1), 2^(W-1)] (the top digit absorbs the last carry, so the
+// input must be < 2^(W(NW-1) + W-1): NW = 255/W + 1 for any 255-bit integer, 253/W + 1 for canonical scalars).
+// out(i, digit) is called for i = 0..NW-1.
 template <typename F>
-DAPOL_HD void sc_recode_w(int W, const uint32_t* x, F out) {
-    const int NW = (255 + W - 1) / W;
+DAPOL_HD void sc_recode_w(int W, int NW, const uint32_t* x, F out) {
     int carry = 0;
     for (int i = 0; i < NW; i++) {
         int o = i * W, wd = o >> 5, sh = o & 31;
-        uint32_t lo = x[wd] >> sh;
+        uint32_t lo = wd < 8 ? x[wd] >> sh : 0u;
         uint32_t hi = (sh && wd + 1 < 8) ? (x[wd + 1] << (32 - sh)) : 0u;
         int b = (int)((lo | hi) & ((1u << W) - 1)) + carry;
         carry = (b >= (1 << (W - 1)) && i < NW - 1) ? 1 : 0;

@@ -27,7 +27,11 @@ struct TableView {
     const int32_t* base;   // device pointer
     int32_t max_parties;
     int32_t wbits;         // W
-    __host__ __device__ int nwin() const { return (255 + wbits - 1) / wbits; }          // windows per 255-bit scalar
+    // Windows of an UNREDUCED 255-bit integer (Scalar::from_bits leaf blindings): the top window must hold its value
+    // plus the recoding carry within 2^(W-1), i.e. be at most W-1 bits wide -> 255/W + 1 windows.  Canonical scalars
+    // (< 2^253, everything in the digit matrices) need 253/W + 1.
+    __host__ __device__ int nwin() const { return 255 / wbits + 1; }
+    __host__ __device__ int nwin_c() const { return 253 / wbits + 1; }
     __host__ __device__ int nwin64() const { return (64 + wbits - 1) / wbits + 1; }     // 64-bit value (+1: recoding carry)
     __host__ __device__ int entries() const { return (1 << (wbits - 1)) + 1; }
     __host__ __device__ size_t row_words() const { return (size_t)entries() * TBL_ENTRY_WORDS; }
@@ -70,7 +74,7 @@ __device__ __forceinline__ void tbl_fixed_mul_add(ge_p3& acc, const TableView& t
     const int W = t.wbits, NW = t.nwin();
     for (int i = 0; i < NW; i++) {
         int o = i * W, wd = o >> 5, sh = o & 31;
-        uint32_t lo = s8[wd] >> sh;
+        uint32_t lo = wd < 8 ? s8[wd] >> sh : 0u;
         uint32_t hi = (sh && wd + 1 < 8) ? (s8[wd + 1] << (32 - sh)) : 0u;
         int b = (int)((lo | hi) & ((1u << W) - 1)) + carry;
         carry = (b >= (1 << (W - 1)) && i < NW - 1) ? 1 : 0;

@@ -104,10 +104,10 @@ void t_sc_recode(const uint8_t* in, int16_t* d) {
     ld(w, in, 8);
     sc_recode_s8(d, w);
 }
-void t_sc_recode_w(int w, const uint8_t* in, int* d) {
+void t_sc_recode_w(int w, int nw, const uint8_t* in, int* d) {
     uint32_t x[8];
     ld(x, in, 8);
-    sc_recode_w(w, x, [&](int i, int v) { d[i] = v; });
+    sc_recode_w(w, nw, x, [&](int i, int v) { d[i] = v; });
 }
 void t_blake3_32(const uint8_t* in, uint8_t* out) {
     uint32_t w[8], o[8];
