@@ -183,29 +183,33 @@ __global__ __launch_bounds__(64) void k_rp_A(RangeArgs A, TableView tbl) {
 // the nwin signed W-bit windows from the top with W shared doublings per window (Straus), and looks every
 // digit up in the generator's row (one 128-byte cache line per lookup, L2 / Infinity-Cache resident).
 // Lanes 0-31 accumulate list 0, lanes 32-63 list 1; two 32-lane LDS tree reductions give P0 and P1.
-template <bool MATERIALIZE>
-__global__ __launch_bounds__(64) void k_rp_msm(RangeArgs A, TableView tbl, int round) {
+template <bool MATERIALIZE, int LPL>
+__global__ __launch_bounds__(64, 3) void k_rp_msm(RangeArgs A, TableView tbl, int round) {
+    // LPL = lanes per list.  32: one proof per wavefront (64 terms per lane at N = 2048).  16 / 8: two / four proofs per
+    // wavefront with 128 / 256 terms per lane, which amortises the W * nwin shared doublings (22 % of the instructions
+    // at LPL = 32) over more mixed adds.  The digit layout is the same for every LPL.
     __shared__ int32_t lds[40 * 64];
-    size_t b = blockIdx.x;
-    int l = threadIdx.x, side = l >> 5, ql = l & 31;
-    int niter = (A.N + 31) >> 5;
-    const dig_t* dig = A.dig + b * A.nwin * (size_t)A.TP;
+    constexpr int PPW = 32 / LPL;
+    int l = threadIdx.x;
+    int sub = l / (2 * LPL), ll = l % (2 * LPL), side = ll / LPL, ql = ll % LPL;
+    size_t b = (size_t)blockIdx.x * PPW + sub;
+    bool valid = b < A.B;
+    if (!valid) b = A.B - 1;
+    int niter = (A.N + LPL - 1) / LPL;
+    const dig_t* dig = A.dig + b * A.nwin * (size_t)A.TP + 32 * side;
     const int NW = A.nwin, W = A.wbits;
     ge_p3 acc;
     ge_identity(acc);
     for (int w = NW - 1; w >= 0; w--) {
         if (w != NW - 1) {
-            for (int d = 0; d < W; d++) {
-                ge_p3 t;
-                ge_dbl(t, acc, d == W - 1);
-                acc = t;
-            }
+            for (int d = 0; d < W - 1; d++) ge_dbl(acc, acc, false);      // in place: every input is read before any output
+            ge_dbl(acc, acc, true);
         }
-        const dig_t* dw = dig + (size_t)w * A.TP + l;
+        const dig_t* dw = dig + (size_t)w * A.TP;
         for (int i = 0; i < niter; i++) {
-            int q = 32 * i + ql;
+            int q = LPL * i + ql;
             if (q < A.N) {
-                int d = dw[64 * i];
+                int d = dw[64 * (q >> 5) + (q & 31)];
                 bool isH;
                 int j = term_generator(round, A.N, A.lgN, side, q, isH);
                 tbl_madd(acc, tbl, gen_row(tbl, A.n, j, isH), d);
@@ -216,10 +220,11 @@ __global__ __launch_bounds__(64) void k_rp_msm(RangeArgs A, TableView tbl, int r
         // Hybrid IPA: with the S-layout lane l owns exactly the generators j = l mod 32 (mod 32), so fed with the
         // s-vector digits its accumulator IS the folded generator G'_(l&31) (lanes 0-31) / H'_(l&31) (lanes 32-63) of
         // the round whose vectors have length 32.  Keep it (k_rp_tail_table turns it into a window table).
+        static_assert(!MATERIALIZE || LPL == 32, "materialisation needs one proof per wavefront");
         st_p3(A.tailT + (b * 64 + l) * (size_t)(8 * 40), acc);
     } else {
-        wave_reduce_point(acc, lds, l, 32);
-        if (ql == 0) st_p3((side ? A.P1 : A.P0) + b * 40, acc);
+        wave_reduce_point(acc, lds, l, LPL);
+        if (ql == 0 && valid) st_p3((side ? A.P1 : A.P0) + b * 40, acc);
     }
 }
 

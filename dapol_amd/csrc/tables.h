@@ -63,9 +63,7 @@ __device__ __forceinline__ void tbl_madd(ge_p3& acc, const TableView& t, int row
     ge_niels q;
     int ad = d < 0 ? -d : d;
     tbl_load(q, t, row, ad);
-    ge_p3 r;
-    ge_madd(r, acc, q, d < 0);
-    acc = r;
+    ge_madd(acc, acc, q, d < 0);          // in place: ge_madd reads all of p before it writes r
 }
 
 // acc += s * Base for a 255-bit integer s (eight words), using the NWIN per-window rows starting at row0.
