@@ -202,8 +202,11 @@ __global__ __launch_bounds__(64, 3) void k_rp_msm(RangeArgs A, TableView tbl, in
     ge_identity(acc);
     for (int w = NW - 1; w >= 0; w--) {
         if (w != NW - 1) {
-            for (int d = 0; d < W - 1; d++) ge_dbl(acc, acc, false);      // in place: every input is read before any output
-            ge_dbl(acc, acc, true);
+            // ONE inlined copy of the doubling (T under a runtime flag).  Measured (profiles/r01_msm_variants.txt): a
+            // second, T-less copy made the launch 17 % SLOWER (127 vs 109 ms) -- the loop body is ~25 KB of code and
+            // the extra copy costs more in instruction-cache misses than the skipped multiplication saves.
+            // In place: ge_dbl reads every input before it writes any output.
+            for (int d = 0; d < W; d++) ge_dbl(acc, acc, d == W - 1);
         }
         const dig_t* dw = dig + (size_t)w * A.TP;
         for (int i = 0; i < niter; i++) {
