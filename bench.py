@@ -184,11 +184,19 @@ def main():
     roofline = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": None,
                 "kernel": "k_rp_msm", "launches": int(stats.msm_launches), "avg_launch_ms": msm_avg_ms,
                 "algorithmic_bytes_per_entity": ab,
-                "note": "integer-VALU bound by construction (255-bit modular multiply-adds); HBM fraction reported as north_star asks, see DESIGN.md"}
+                "note": "achieved/frac use the ALGORITHMIC bytes of SURVEY 8d (6,384 B per entity); the kernel itself is integer-VALU "
+                        "bound (255-bit modular multiply-adds) and deliberately spends HBM bandwidth on 15-bit window tables: see "
+                        "traffic (measured HBM bytes per launch) and DESIGN.md section 5"}
+    # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; tools/pmc_summary.py),
+    # measured on full 60,000-proof launches of this kernel; only quoted when this run's launches have that size too.
     pmc = os.path.join(ROOT, "profiles", "msm_pmc.json")
-    if os.path.exists(pmc):
+    if os.path.exists(pmc) and n_per_gpu >= 60000 and height == 32 and n_bits == 64:
         try:
-            roofline["traffic"] = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            pj = json.load(open(pmc))
+            roofline["traffic"] = pj.get("hbm_bytes_per_launch")
+            roofline["traffic_GBps"] = pj.get("hbm_GBps")
+            roofline["traffic_frac_of_peak"] = pj.get("hbm_GBps", 0.0) / PEAK_HBM_GBS
+            roofline["valu_cycles_per_inst"] = pj.get("cycles_per_valu_inst_per_simd")
         except Exception:
             pass
     cpu = None

@@ -1,6 +1,8 @@
 // libdapol_hip.so -- C ABI (include/dapol_hip.h) over the gfx950 kernels.  Host side only orchestrates: every
 // byte of arithmetic (generator derivation included) runs on the GPU; there is no CPU fallback.
+#include <cstring>
 #include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>          // radix sort only (plain library plumbing for the leaf-derivation sorts)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -12,6 +14,7 @@
 #include "kernels_ctx_tree.h"
 #include "kernels_range.h"
 #include "kernels_verify.h"
+#include "kernels_leaf.h"
 
 using namespace dapol;
 
@@ -538,3 +541,4 @@ int32_t dapol_tree_paths(dapol_tree* tree, size_t b, const uint64_t* leaf_idx, u
 }
 
 #include "host_range.inc"
+#include "host_leaf.inc"

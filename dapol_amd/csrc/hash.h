@@ -86,6 +86,91 @@ DAPOL_HD void seed_wide(uint32_t* out16, const uint32_t* seed8, uint32_t domain,
     blake3_compress(out16, seed8, m, 0, 20, B3_KEYED_HASH | B3_CHUNK_START | B3_CHUNK_END | B3_ROOT);
 }
 
+// Streaming digest D over a byte string assembled from parts (leaf derivation, src/dapol/mod.rs:323-441):
+// D = BLAKE3 (single chunk: at most 1024 bytes in total) or Blake2s-256 (the reference's KAT digest,
+// src/dapol/tests.rs:13,21).  Usage: dg_init, dg_update* (bytes), dg_final -> eight little-endian words.
+enum : int { DG_BLAKE3 = 0, DG_BLAKE2S = 1 };
+struct Digest {
+    uint32_t h[8];
+    uint32_t buf[16];
+    uint32_t buflen;      // bytes in buf
+    uint32_t total;       // bytes compressed so far (before buf)
+    int kind;
+    bool overflow;        // BLAKE3 input longer than one chunk (unsupported here)
+};
+DAPOL_HD void blake2s_compress(uint32_t* h, const uint32_t* m, uint32_t t, bool last) {
+    const uint32_t IV[8] = {0x6A09E667u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au, 0x510E527Fu, 0x9B05688Cu, 0x1F83D9ABu, 0x5BE0CD19u};
+    const uint8_t SIG[10][16] = {{0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+                                 {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+                                 {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+                                 {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+                                 {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0}};
+    uint32_t v[16];
+    for (int i = 0; i < 8; i++) { v[i] = h[i]; v[8 + i] = IV[i]; }
+    v[12] ^= t;
+    if (last) v[14] = ~v[14];
+#define B2G(a, b, c, d, x, y)                \
+    v[a] = v[a] + v[b] + (x);                \
+    v[d] = rotr32(v[d] ^ v[a], 16);          \
+    v[c] = v[c] + v[d];                      \
+    v[b] = rotr32(v[b] ^ v[c], 12);          \
+    v[a] = v[a] + v[b] + (y);                \
+    v[d] = rotr32(v[d] ^ v[a], 8);           \
+    v[c] = v[c] + v[d];                      \
+    v[b] = rotr32(v[b] ^ v[c], 7);
+    for (int r = 0; r < 10; r++) {
+        const uint8_t* s = SIG[r];
+        B2G(0, 4, 8, 12, m[s[0]], m[s[1]]) B2G(1, 5, 9, 13, m[s[2]], m[s[3]]) B2G(2, 6, 10, 14, m[s[4]], m[s[5]]) B2G(3, 7, 11, 15, m[s[6]], m[s[7]])
+        B2G(0, 5, 10, 15, m[s[8]], m[s[9]]) B2G(1, 6, 11, 12, m[s[10]], m[s[11]]) B2G(2, 7, 8, 13, m[s[12]], m[s[13]]) B2G(3, 4, 9, 14, m[s[14]], m[s[15]])
+    }
+#undef B2G
+    for (int i = 0; i < 8; i++) h[i] ^= v[i] ^ v[8 + i];
+}
+DAPOL_HD void dg_init(Digest& d, int kind) {
+    blake3_iv(d.h);                        // both digests start from the SHA-256 IV ...
+    if (kind == DG_BLAKE2S) d.h[0] ^= 0x01010020u;   // ... Blake2s xors the parameter block (digest 32, fanout 1, depth 1)
+    for (int i = 0; i < 16; i++) d.buf[i] = 0;
+    d.buflen = 0;
+    d.total = 0;
+    d.kind = kind;
+    d.overflow = false;
+}
+DAPOL_HD void dg_flush(Digest& d) {        // compress a FULL, non-final block
+    if (d.kind == DG_BLAKE3) {
+        uint32_t o[16];
+        if (d.total + 64 >= 1024) d.overflow = true;
+        blake3_compress(o, d.h, d.buf, 0, 64, d.total == 0 ? B3_CHUNK_START : 0u);
+        for (int i = 0; i < 8; i++) d.h[i] = o[i];
+    } else {
+        blake2s_compress(d.h, d.buf, d.total + 64, false);
+    }
+    d.total += 64;
+    d.buflen = 0;
+    for (int i = 0; i < 16; i++) d.buf[i] = 0;
+}
+DAPOL_HD void dg_update_byte(Digest& d, uint8_t b) {
+    if (d.buflen == 64) dg_flush(d);       // lazily, so that the last block stays in the buffer for dg_final
+    d.buf[d.buflen >> 2] |= (uint32_t)b << (8 * (d.buflen & 3));
+    d.buflen++;
+}
+DAPOL_HD void dg_update(Digest& d, const uint8_t* p, uint32_t n) {
+    for (uint32_t i = 0; i < n; i++) dg_update_byte(d, p[i]);
+}
+DAPOL_HD void dg_update_words(Digest& d, const uint32_t* w, int nwords) {
+    for (int i = 0; i < nwords; i++)
+        for (int k = 0; k < 4; k++) dg_update_byte(d, (uint8_t)(w[i] >> (8 * k)));
+}
+DAPOL_HD void dg_final(Digest& d, uint32_t* out8) {
+    if (d.kind == DG_BLAKE3) {
+        uint32_t o[16];
+        blake3_compress(o, d.h, d.buf, 0, d.buflen, (d.total == 0 ? B3_CHUNK_START : 0u) | B3_CHUNK_END | B3_ROOT);
+        for (int i = 0; i < 8; i++) out8[i] = o[i];
+    } else {
+        blake2s_compress(d.h, d.buf, d.total + d.buflen, true);
+        for (int i = 0; i < 8; i++) out8[i] = d.h[i];
+    }
+}
+
 // ------------------------------------------------------------------------------------------- Keccak-f[1600]
 DAPOL_HD uint64_t rotl64(uint64_t x, int n) {
     return (x << n) | (x >> (64 - n));

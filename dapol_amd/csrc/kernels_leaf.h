@@ -1,0 +1,177 @@
+// Leaf derivation on the device: build_leaf_nodes / shuffle_index (src/dapol/mod.rs:323-441).
+//   audit_id   = D(audit_seed || internal_id)                                   (:347-353)
+//   index_seed = D(audit_id || "index_seed" || external_id)                     (:361-368)
+//   index      = first of  idx_k = be64(D^k(index_seed)[..8]) >> (64 - height), k = 1..128, not taken yet (:408-441)
+//   blinding   = Scalar::from_bits(D(audit_id || "blind_seed" || external_id))  (:377-385)
+// The hashing is embarrassingly parallel.  "Not taken yet" is order dependent in the reference (an entity only
+// competes with the entities BEFORE it in the input), so the rare colliders are resolved by one lane in input
+// order -- exactly the sequential semantics -- while everybody else keeps its first candidate.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "hash.h"
+
+namespace dapol {
+
+enum { LEAF_MAX_RETRIES = 128 };            // MAX_INDEX_RETRIES, src/dapol/mod.rs:29
+
+struct LeafArgs {
+    size_t n;
+    int height, kind;
+    const uint8_t* seed; uint32_t seed_len;
+    const uint8_t* iid; const uint32_t* iid_off;     // [n+1] byte offsets
+    const uint8_t* eid; const uint32_t* eid_off;
+    uint32_t* audit_id;      // [n][8]
+    uint32_t* idx_state;     // [n][8]  D^k(index_seed) of the candidate currently held
+    uint64_t* cand;          // [n]     candidate / final index
+    uint32_t* blind;         // [n][8]
+    uint32_t* err;           // [0] = digest overflow flag, [1] = duplicate id flag, [2] = failed-to-map flag, [3] = offending entity
+};
+
+__device__ __forceinline__ uint64_t leaf_index_of(const uint32_t* st, int height) {
+    uint64_t be = ((uint64_t)__builtin_bswap32(st[0]) << 32) | (uint64_t)__builtin_bswap32(st[1]);
+    return be >> (64 - height);
+}
+
+__global__ __launch_bounds__(64) void k_leaf_hash(LeafArgs A) {
+    size_t e = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (e >= A.n) return;
+    Digest d;
+    uint32_t aid[8], st[8], bl[8];
+    dg_init(d, A.kind);
+    dg_update(d, A.seed, A.seed_len);
+    dg_update(d, A.iid + A.iid_off[e], A.iid_off[e + 1] - A.iid_off[e]);
+    bool ovf = d.overflow;
+    dg_final(d, aid);
+    const uint8_t t1[10] = {'i', 'n', 'd', 'e', 'x', '_', 's', 'e', 'e', 'd'};
+    const uint8_t t2[10] = {'b', 'l', 'i', 'n', 'd', '_', 's', 'e', 'e', 'd'};
+    dg_init(d, A.kind);
+    dg_update_words(d, aid, 8);
+    dg_update(d, t1, 10);
+    dg_update(d, A.eid + A.eid_off[e], A.eid_off[e + 1] - A.eid_off[e]);
+    ovf |= d.overflow;
+    dg_final(d, st);
+    dg_init(d, A.kind);                                  // first shuffle_index iteration: seed = D(seed)
+    dg_update_words(d, st, 8);
+    dg_final(d, st);
+    dg_init(d, A.kind);
+    dg_update_words(d, aid, 8);
+    dg_update(d, t2, 10);
+    dg_update(d, A.eid + A.eid_off[e], A.eid_off[e + 1] - A.eid_off[e]);
+    ovf |= d.overflow;
+    dg_final(d, bl);
+    bl[7] &= 0x7fffffffu;                                // Scalar::from_bits
+    for (int i = 0; i < 8; i++) { A.audit_id[e * 8 + i] = aid[i]; A.idx_state[e * 8 + i] = st[i]; A.blind[e * 8 + i] = bl[i]; }
+    A.cand[e] = leaf_index_of(st, A.height);
+    if (ovf) atomicOr(&A.err[0], 1u);
+}
+
+// Duplicate internal ids (src/dapol/mod.rs:341-343): entities sorted by the first 8 bytes of audit_id; equal
+// neighbours are compared in full (audit id, then the id bytes themselves).
+__global__ void k_leaf_dup_keys(size_t n, const uint32_t* audit_id, uint64_t* key, uint32_t* ord) {
+    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    key[e] = ((uint64_t)audit_id[e * 8 + 1] << 32) | audit_id[e * 8];
+    ord[e] = (uint32_t)e;
+}
+__global__ void k_leaf_dup_check(LeafArgs A, const uint64_t* key, const uint32_t* ord) {
+    size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p == 0 || p >= A.n || key[p] != key[p - 1]) return;
+    uint32_t a = ord[p - 1], b = ord[p];
+    uint32_t la = A.iid_off[a + 1] - A.iid_off[a], lb = A.iid_off[b + 1] - A.iid_off[b];
+    if (la != lb) return;
+    for (uint32_t i = 0; i < la; i++)
+        if (A.iid[A.iid_off[a] + i] != A.iid[A.iid_off[b] + i]) return;
+    atomicOr(&A.err[1], 1u);
+    atomicMax(&A.err[3], a > b ? a : b);
+}
+
+// Collision bookkeeping.  After sorting (cand, input order) pairs: the first entity of every equal-candidate group
+// holds the slot; the others are "losers".
+__global__ void k_leaf_mark(size_t n, const uint64_t* skey, const uint32_t* sord, uint32_t* losers, uint32_t* n_losers) {
+    size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p == 0 || p >= n || skey[p] != skey[p - 1]) return;
+    uint32_t k = atomicAdd(n_losers, 1u);
+    losers[k] = sord[p];
+}
+
+struct LeafResolve {
+    size_t n;
+    const uint64_t* skey;      // [n] sorted first candidates
+    const uint32_t* sord;      // [n] their owners
+    uint32_t* heap;            // [n] min-heap of unresolved entities keyed by input order (starts as the losers, unsorted)
+    uint32_t heap_n;
+    uint8_t* evicted;          // [n] by sorted position: the holder lost its slot to an earlier entity
+    uint64_t* tab_key;         // open-addressing set of slots taken by resolved colliders
+    uint8_t* tab_used;
+    uint32_t tab_mask;
+};
+__device__ inline void heap_push(uint32_t* h, uint32_t& n, uint32_t v) {
+    uint32_t i = n++;
+    h[i] = v;
+    while (i > 0) {
+        uint32_t p = (i - 1) >> 1;
+        if (h[p] <= h[i]) break;
+        uint32_t t = h[p]; h[p] = h[i]; h[i] = t;
+        i = p;
+    }
+}
+__device__ inline uint32_t heap_pop(uint32_t* h, uint32_t& n) {
+    uint32_t top = h[0];
+    h[0] = h[--n];
+    uint32_t i = 0;
+    for (;;) {
+        uint32_t l = 2 * i + 1, r = l + 1, m = i;
+        if (l < n && h[l] < h[m]) m = l;
+        if (r < n && h[r] < h[m]) m = r;
+        if (m == i) break;
+        uint32_t t = h[m]; h[m] = h[i]; h[i] = t;
+        i = m;
+    }
+    return top;
+}
+// One lane, input order: every unresolved entity re-hashes until it finds a slot that no EARLIER entity holds;
+// a later entity sitting on that slot is evicted and re-queued (it comes later in the order, so it is still ahead).
+__global__ void k_leaf_resolve(LeafArgs A, LeafResolve R) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    uint32_t hn = 0;
+    uint32_t n0 = R.heap_n;
+    // heapify by successive pushes (the loser list arrives unsorted in R.heap)
+    for (uint32_t i = 0; i < n0; i++) { uint32_t v = R.heap[i]; heap_push(R.heap, hn, v); }
+    while (hn > 0) {
+        uint32_t e = heap_pop(R.heap, hn);
+        uint32_t st[8];
+        for (int i = 0; i < 8; i++) st[i] = A.idx_state[(size_t)e * 8 + i];
+        bool placed = false;
+        for (int tries = 1; tries < LEAF_MAX_RETRIES && !placed; tries++) {      // the first try was the sorted candidate
+            Digest d;
+            dg_init(d, A.kind);
+            dg_update_words(d, st, 8);
+            dg_final(d, st);
+            uint64_t x = leaf_index_of(st, A.height);
+            // (a) slot taken by an already resolved collider (all of them precede e)
+            bool taken = false;
+            uint32_t hp = (uint32_t)((x * 0x9E3779B97F4A7C15ull) >> 32) & R.tab_mask;
+            while (R.tab_used[hp]) {
+                if (R.tab_key[hp] == x) { taken = true; break; }
+                hp = (hp + 1) & R.tab_mask;
+            }
+            if (taken) continue;
+            // (b) slot held by the first entity of a first-candidate group
+            size_t lo = 0, hi = R.n;
+            while (lo < hi) { size_t mid = (lo + hi) >> 1; if (R.skey[mid] < x) lo = mid + 1; else hi = mid; }
+            if (lo < R.n && R.skey[lo] == x && !R.evicted[lo]) {
+                uint32_t holder = R.sord[lo];
+                if (holder < e) continue;                    // an earlier entity owns it
+                R.evicted[lo] = 1;                           // e precedes the holder: e gets the slot, the holder re-queues
+                heap_push(R.heap, hn, holder);
+            }
+            R.tab_used[hp] = 1;
+            R.tab_key[hp] = x;
+            A.cand[e] = x;
+            placed = true;
+        }
+        if (!placed) { A.err[2] = 1; A.err[3] = e; return; }  // DapolError::FailedToMapIndex
+    }
+}
+
+}  // namespace dapol

@@ -56,7 +56,7 @@ typedef struct dapol_ctx dapol_ctx;
 typedef struct dapol_tree dapol_tree;
 
 enum { DAPOL_POLICY_PADDING = 0, DAPOL_POLICY_SPLITTING = 1 };  /* RangeProofPadding / RangeProofSplitting */
-enum { DAPOL_DIGEST_BLAKE3 = 0 };                               /* D = blake3::Hasher (benches/dapol.rs:38) */
+enum { DAPOL_DIGEST_BLAKE3 = 0, DAPOL_DIGEST_BLAKE2S = 1 };     /* D = blake3::Hasher (benches/dapol.rs:38); Blake2s only for leaf derivation */
 
 /* Replaces the per-call PedersenGens::default() (src/dapol/node.rs:31, src/range/mod.rs:49,65,84,103) and
  * BulletproofGens::new(64, m) (src/range/mod.rs:50,66,85,104): generators and their window tables are derived
@@ -72,6 +72,20 @@ const char* dapol_last_error(void);
  * r may be an unreduced Scalar::from_bits value (bit 255 clear; src/dapol/mod.rs:385). */
 int32_t dapol_commit_hash_batch(dapol_ctx* ctx, size_t n, const uint64_t* v, const uint8_t* r32, uint8_t* C_out32,
                                 uint8_t* H_out32);
+
+/* build_leaf_nodes + shuffle_index (src/dapol/mod.rs:323-441), the leaf half of Dapol::new: liabilities in INPUT order
+ * (ids as concatenated bytes with n+1 offsets) -> for every liability its tree index and blinding factor, returned both
+ * per input entity (idx_by_entity, may be NULL = the id_to_idx_map of mod.rs:388) and sorted by index, ready for
+ * dapol_tree_build (mod.rs:396): leaf_idx_sorted / v_sorted / r32_sorted, with order_sorted[p] = input position of the
+ * p-th leaf.  digest_id: DAPOL_DIGEST_BLAKE3 (ids up to one 1024-byte chunk per hash input) or DAPOL_DIGEST_BLAKE2S (the
+ * digest of the reference's known-answer tests, src/dapol/tests.rs:13,21).  Collisions are resolved exactly as the
+ * reference does (an entity competes only with the entities before it in the input; up to 128 re-hashes).
+ * Errors: DAPOL_ERR_TREE_HEIGHT_TOO_BIG, DAPOL_ERR_SPARSITY_TOO_SMALL (2^height < 2n), DAPOL_ERR_DUPLICATED_INTERNAL_ID,
+ * DAPOL_ERR_FAILED_TO_MAP_INDEX. */
+int32_t dapol_build_leaf_nodes(dapol_ctx* ctx, int32_t digest_id, const uint8_t* audit_seed, size_t audit_seed_len, int32_t height,
+                               size_t n, const uint8_t* internal_ids, const uint32_t* internal_off, const uint8_t* external_ids,
+                               const uint32_t* external_off, const uint64_t* values, uint64_t* leaf_idx_sorted, uint64_t* v_sorted,
+                               uint8_t* r32_sorted, uint32_t* order_sorted, uint64_t* idx_by_entity);
 
 /* Dapol::new_blank + Dapol::build (src/dapol/mod.rs:196-208 -> smtree SparseMerkleTree::build) with the leaf
  * nodes made by DapolNode::new; also the build half of Dapol::new (src/dapol/mod.rs:100-128).

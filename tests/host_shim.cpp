@@ -137,6 +137,14 @@ void t_merlin(const char* app, int app_len, const char* label, int ll, const cha
     merlin_challenge_wide(s, cl, cll, w);
     st(out64, w, 16);
 }
+void t_digest(int kind, const uint8_t* in, int n, uint8_t* out) {
+    Digest d;
+    dg_init(d, kind);
+    dg_update(d, in, (uint32_t)n);
+    uint32_t o[8];
+    dg_final(d, o);
+    st(out, o, 8);
+}
 // SHAKE256 / SHA3-512 through the generic sponge
 void t_sponge(int rate, int domain, const uint8_t* in, int n, uint8_t* out, int outlen) {
     Sponge sp;

@@ -118,6 +118,13 @@ def test_hashes_and_transcript(host_shim, pyref):
         o = buf(64)
         host_shim.t_sponge(72, 0x06, m * 3, n, o, 64)
         assert o.raw == hashlib.sha3_512((m * 3)[:n]).digest()
+    for n in list(range(0, 70)) + [127, 128, 129, 191, 192, 193, 500, 1000, 1024]:
+        m = bytes(rnd.randrange(256) for _ in range(n))
+        o = buf(32)
+        host_shim.t_digest(1, m, n, o)
+        assert o.raw == hashlib.blake2s(m).digest(), n
+        host_shim.t_digest(0, m, n, o)
+        assert o.raw == R.blake3(m), n
     o = buf(64)
     host_shim.t_merlin(b"test protocol", 13, b"some label", 10, b"some data", 9, b"challenge", 9, o)
     t = R.Transcript(b"test protocol")
