@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DAPOL_HIP_LIB", os.path.join(_HERE, "libdapol_hip.so"))   # override only for A/B builds
 
 POLICY_PADDING, POLICY_SPLITTING = 0, 1
-DIGEST_BLAKE3 = 0
+DIGEST_BLAKE3, DIGEST_BLAKE2S = 0, 1
 
 
 class DapolError(RuntimeError):
@@ -35,6 +35,8 @@ _SIG = {
     "dapol_strerror": (ctypes.c_char_p, [ctypes.c_int32]),
     "dapol_last_error": (ctypes.c_char_p, []),
     "dapol_commit_hash_batch": (ctypes.c_int32, [_P, ctypes.c_size_t, _P, _P, _P, _P]),
+    "dapol_build_leaf_nodes": (ctypes.c_int32, [_P, ctypes.c_int32, _P, ctypes.c_size_t, ctypes.c_int32, ctypes.c_size_t, _P, _P, _P, _P, _P, _P, _P, _P,
+                                                _P, _P]),
     "dapol_tree_build": (ctypes.c_int32, [_P, ctypes.c_int32, ctypes.c_size_t, _P, _P, _P, _P, ctypes.c_int32, ctypes.POINTER(_P)]),
     "dapol_tree_build_shard": (ctypes.c_int32, [_P, ctypes.c_int32, ctypes.c_int32, ctypes.c_size_t, _P, _P, _P, _P, ctypes.POINTER(_P)]),
     "dapol_merge_batch": (ctypes.c_int32, [_P, ctypes.c_size_t] + [_P] * 12),
@@ -130,6 +132,26 @@ class Context:
         C, H = np.zeros((n, 32), np.uint8), np.zeros((n, 32), np.uint8)
         _chk(lib().dapol_commit_hash_batch(self.h, n, _ptr(v), _ptr(r32), _ptr(C), _ptr(H)))
         return C, H
+
+    def build_leaf_nodes(self, liabilities, audit_seed, height, digest=DIGEST_BLAKE3):
+        """build_leaf_nodes (src/dapol/mod.rs:323-399): liabilities = [(internal_id bytes, external_id bytes, value)] in
+        input order -> dict(leaf_idx, v, r (sorted by index), order (input position per sorted leaf), idx_by_entity)."""
+        n = len(liabilities)
+        iid = b"".join(l[0] for l in liabilities)
+        eid = b"".join(l[1] for l in liabilities)
+        ioff = np.zeros(n + 1, np.uint32)
+        eoff = np.zeros(n + 1, np.uint32)
+        ioff[1:] = np.cumsum([len(l[0]) for l in liabilities])
+        eoff[1:] = np.cumsum([len(l[1]) for l in liabilities])
+        vals = _u64([l[2] for l in liabilities])
+        ib = _u8(np.frombuffer(iid, np.uint8)) if iid else np.zeros(1, np.uint8)
+        eb = _u8(np.frombuffer(eid, np.uint8)) if eid else np.zeros(1, np.uint8)
+        sd = _u8(np.frombuffer(audit_seed, np.uint8)) if audit_seed else None
+        idx, v, order, by_e = np.zeros(n, np.uint64), np.zeros(n, np.uint64), np.zeros(n, np.uint32), np.zeros(n, np.uint64)
+        r = np.zeros((n, 32), np.uint8)
+        _chk(lib().dapol_build_leaf_nodes(self.h, digest, _ptr(sd), len(audit_seed), height, n, _ptr(ib), _ptr(ioff), _ptr(eb), _ptr(eoff),
+                                          _ptr(vals), _ptr(idx), _ptr(v), _ptr(r), _ptr(order), _ptr(by_e)))
+        return dict(leaf_idx=idx, v=v, r=r, order=order, idx_by_entity=by_e)
 
     def merge_batch(self, CL, HL, CR, HR, vL=None, rL=None, vR=None, rR=None):
         """Mergeable::merge on compressed records; returns (C, H) or (C, H, v, r) when the secrets are given."""

@@ -388,3 +388,62 @@ def test_out_of_range_value_is_rejected(gpu_ctx, pyref):
     pr = pyref.range_prove([256, 1], bl, 8, pyref.Tape(seed=SEED, stream_id=7))
     Vs = np.array([list(pyref.pedersen_commit(v, b).compress()) for v, b in zip([256, 1], bl)], np.uint8).reshape(1, 2, 32)
     assert list(gpu_ctx.range_verify_batch(8, 2, np.frombuffer(pr, np.uint8).reshape(1, -1), Vs, verify_seed=SEED)) == [0]
+
+
+# ------------------------------------------------------------------------------------------------ leaf derivation (8f #1)
+def test_leaf_derivation_reference_kats(gpu_ctx, hip_lib):
+    """src/dapol/tests.rs:30-85: ids a,b,c,d (external w,x,y,z), seed "test", Blake2s, height 4 -> leaves 7, 12, 2, 4;
+    :24: root value 26 -- through the GPU."""
+    kat = load_golden("kat.json")
+    liab = [(i.encode(), e.encode(), v) for i, e, v in kat["liabilities"]]
+    out = gpu_ctx.build_leaf_nodes(liab, b"test", 4, hip_lib.DIGEST_BLAKE2S)
+    assert list(map(int, out["idx_by_entity"])) == [7, 12, 2, 4]
+    assert list(map(int, out["leaf_idx"])) == [2, 4, 7, 12] and list(map(int, out["order"])) == [2, 3, 0, 1]
+    by_id = {l["id"]: l for l in kat["blake2s"]["leaves"]}
+    for p, e in enumerate(out["order"]):
+        exp = by_id[kat["liabilities"][int(e)][0]]
+        assert out["r"][p].tobytes().hex() == exp["r"] and int(out["v"][p]) == exp["v"]
+    # the same liabilities under BLAKE3 feed the tree builder and give the golden root
+    out3 = gpu_ctx.build_leaf_nodes(liab, b"test", 4, hip_lib.DIGEST_BLAKE3)
+    assert {kat["liabilities"][i][0]: int(x) for i, x in enumerate(out3["idx_by_entity"])} == kat["blake3"]["index"]
+    tr = hip_lib.Tree(gpu_ctx, 4, out3["leaf_idx"], out3["v"], out3["r"], bytes(range(32)), enforce_sparsity=True)
+    C, H, v, r = tr.root()
+    assert (C.hex(), H.hex(), v) == (kat["blake3"]["root"]["C"], kat["blake3"]["root"]["H"], 26)
+
+
+@pytest.mark.parametrize("height,n,digest", [(6, 30, "blake3"), (8, 100, "blake2s"), (5, 16, "blake3"), (20, 3000, "blake3"), (7, 64, "blake2s")])
+def test_leaf_derivation_vs_oracle_with_collisions(gpu_ctx, hip_lib, pyref, height, n, digest):
+    """Small heights force many index collisions: the order-dependent retry semantics of shuffle_index must match exactly."""
+    rng = np.random.default_rng(height * 7 + n)
+    liab = []
+    for i in range(n):
+        iid = b"id-%06d" % i + bytes(rng.integers(0, 256, size=int(rng.integers(0, 90)), dtype=np.uint8))
+        eid = bytes(rng.integers(0, 256, size=int(rng.integers(0, 70)), dtype=np.uint8))
+        liab.append((iid, eid, int(rng.integers(0, 2**32))))
+    seed = b"audit seed " + bytes(rng.integers(0, 256, size=40, dtype=np.uint8))
+    leaves, idm = pyref.build_leaf_nodes(liab, seed, height, digest)
+    first = [pyref.shuffle_index(pyref.digest(digest, pyref.digest(digest, seed, i_), b"index_seed", e_), height, set(), digest) for i_, e_, _ in liab]
+    assert height > 12 or len(set(first)) < n, "test should exercise collisions"
+    out = gpu_ctx.build_leaf_nodes(liab, seed, height, hip_lib.DIGEST_BLAKE3 if digest == "blake3" else hip_lib.DIGEST_BLAKE2S)
+    assert [int(x) for x in out["idx_by_entity"]] == [idm[l[0]] for l in liab]
+    assert [int(x) for x in out["leaf_idx"]] == [i for i, _ in leaves]
+    for p, (i, nd) in enumerate(leaves):
+        assert int(out["v"][p]) == nd.v and out["r"][p].tobytes() == nd.r.to_bytes(32, "little")
+
+
+def test_leaf_derivation_errors(gpu_ctx, hip_lib):
+    E = hip_lib.DapolError
+    with pytest.raises(E) as e:
+        gpu_ctx.build_leaf_nodes([(b"a", b"w", 1), (b"b", b"x", 2), (b"a", b"y", 3)], b"test", 8)
+    assert e.value.code == 4                                          # DapolError::DuplicatedInternalId
+    with pytest.raises(E) as e:
+        gpu_ctx.build_leaf_nodes([(bytes([i]), b"e", 1) for i in range(9)], b"test", 4)
+    assert e.value.code == 2                                          # DapolError::SparsityTooSmall (2^4 < 2*9)
+    with pytest.raises(E) as e:
+        gpu_ctx.build_leaf_nodes([(b"a", b"w", 1)], b"test", 65)
+    assert e.value.code == 1                                          # DapolError::TreeHeightTooBig
+    with pytest.raises(E) as e:
+        gpu_ctx.build_leaf_nodes([(b"a" * 1100, b"w", 1)], b"test", 8)
+    assert e.value.code == 8                                          # beyond one BLAKE3 chunk: documented limit of this path
+    out = gpu_ctx.build_leaf_nodes([(b"a" * 1100, b"w", 1)], b"test", 8, hip_lib.DIGEST_BLAKE2S)      # Blake2s has no such limit
+    assert len(out["leaf_idx"]) == 1
