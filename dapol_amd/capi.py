@@ -50,6 +50,8 @@ _SIG = {
     "dapol_range_proof_size": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32]),
     "dapol_range_verify_batch": (ctypes.c_int32, [_P, ctypes.c_int32, ctypes.c_int32, ctypes.c_size_t, _P, _P, _P, _P]),
     "dapol_prove_entities": (ctypes.c_int32, [_P, _P, ctypes.c_size_t, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P, _P, _P, _P]),
+    "dapol_verify_entities": (ctypes.c_int32, [_P, ctypes.c_int32, ctypes.c_size_t, _P, _P, _P, _P, _P, _P, _P, ctypes.c_int32, ctypes.c_int32,
+                                               ctypes.c_int32, _P, _P, _P]),
     "dapol_entity_proof_size": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     "dapol_prove_entities_upper": (ctypes.c_int32, [_P, _P, ctypes.c_size_t, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P, ctypes.c_int32,
                                                     _P, _P, _P, _P, _P, _P, _P]),
@@ -179,6 +181,21 @@ class Context:
         tp = _u8(tape) if tape is not None else None
         _chk(lib().dapol_range_prove_batch(self.h, n_bits, m, b, _ptr(v), _ptr(r32), _ptr(seed), _ptr(sid), slot_base, _ptr(tp), _ptr(out)))
         return out
+
+    def verify_entities(self, height, leaf_idx, leaf_C, leaf_H, path_C, path_H, root_C, root_H, policy, aggregation_factor, n_bits, range_proofs,
+                        verify_seed=bytes(32)):
+        """DapolProof::verify for single-leaf proofs (Merkle re-merge + policy range verification)."""
+        leaf_idx = _u64(leaf_idx)
+        b = leaf_idx.shape[0]
+        lC, lH = _u8(leaf_C, b, 32), _u8(leaf_H, b, 32)
+        pC, pH = _u8(path_C).reshape(b, height, 32), _u8(path_H).reshape(b, height, 32)
+        rp = _u8(range_proofs).reshape(b, -1)
+        rC, rH = _u8(np.frombuffer(root_C, np.uint8)), _u8(np.frombuffer(root_H, np.uint8))
+        seed = _u8(np.frombuffer(verify_seed, np.uint8))
+        ok = np.zeros(b, np.uint8)
+        _chk(lib().dapol_verify_entities(self.h, height, b, _ptr(leaf_idx), _ptr(lC), _ptr(lH), _ptr(pC), _ptr(pH), _ptr(rC), _ptr(rH), policy,
+                                         aggregation_factor, n_bits, _ptr(rp), _ptr(seed), _ptr(ok)))
+        return ok
 
     def range_verify_batch(self, n_bits, m, proofs, V32, verify_seed=bytes(32)):
         proofs = _u8(proofs)

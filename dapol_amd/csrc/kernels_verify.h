@@ -227,4 +227,49 @@ __global__ __launch_bounds__(64) void k_rv_finish(VerifyArgs V, TableView tbl) {
     V.verdict[b] = (vs.ok && words_zero(c8)) ? 1 : 0;
 }
 
+// MerkleProof::verify for single leaves with DapolProofNode::merge (src/proof/node.rs:56-69, src/proof/mod.rs:41-47):
+// re-merge the leaf with its siblings (root side first in `pC/pH`) and compare with the root.  One lane per entity.
+__global__ __launch_bounds__(64) void k_verify_paths(size_t b, int height, const uint64_t* leaf_idx, const uint32_t* leafC, const uint32_t* leafH,
+                                                    const uint32_t* pC, const uint32_t* pH, const uint32_t* rootC, const uint32_t* rootH,
+                                                    uint8_t* ok) {
+    size_t e = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (e >= b) return;
+    uint32_t c[8], h[8], sc_[8], sh[8], hn[8];
+    ld8(c, leafC + e * 8);
+    ld8(h, leafH + e * 8);
+    ge_p3 acc, sp;
+    bool good = ge_decompress(acc, c);
+    uint64_t idx = leaf_idx[e];
+    for (int k = 0; k < height; k++) {
+        size_t slot = e * (size_t)height + (size_t)(height - 1 - k);
+        ld8(sc_, pC + slot * 8);
+        ld8(sh, pH + slot * 8);
+        good &= ge_decompress(sp, sc_);                      // deserialisation rejects non-canonical points (proof/node.rs:88-94)
+        if ((idx >> k) & 1) blake3_hash128(hn, sc_, c, sh, h);
+        else blake3_hash128(hn, c, sc_, h, sh);
+        ge_p3 t;
+        ge_add(t, acc, sp);
+        acc = t;
+        ge_compress(c, acc);
+        for (int i = 0; i < 8; i++) h[i] = hn[i];
+    }
+    for (int i = 0; i < 8; i++) good &= (c[i] == rootC[i]) & (h[i] == rootH[i]);
+    ok[e] = good ? 1 : 0;
+}
+// commitments of one sub-proof from the path (pad parties: commit(0, 1) = B_blinding, src/range/padding.rs:176-180)
+__global__ void k_gather_commitments(size_t b, int height, int start, int count, int m, const uint32_t* pC, const uint32_t* Bb_comp, uint32_t* Vc) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= b * (size_t)m) return;
+    size_t e = t / m;
+    int j = (int)(t - e * m);
+    uint32_t c[8];
+    if (j < count) ld8(c, pC + (e * (size_t)height + (size_t)(start + j)) * 8);
+    else for (int i = 0; i < 8; i++) c[i] = Bb_comp[i];
+    st8(Vc + t * 8, c);
+}
+__global__ void k_and_bytes(size_t n, uint8_t* acc, const uint8_t* x) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) acc[i] = acc[i] & x[i];
+}
+
 }  // namespace dapol

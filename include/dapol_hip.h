@@ -156,6 +156,15 @@ int32_t dapol_prove_entities_upper(dapol_ctx* ctx, dapol_tree* tree, size_t b, c
                                    const uint8_t* up_C32, const uint8_t* up_H32, const uint64_t* up_v, const uint8_t* up_r32,
                                    uint8_t* path_C32, uint8_t* path_H32, uint8_t* range_out);
 
+/* DapolProof::verify (src/proof/mod.rs:41-47 + :89-95) for b single-leaf inclusion proofs as produced by
+ * dapol_prove_entities: MerkleProof::verify by re-merging the leaf proof node with its siblings (DapolProofNode::merge,
+ * src/proof/node.rs:56-69; a sibling commitment that is not a canonical point fails like deserialisation does, :88-94)
+ * and then RangeVerifiable::verify of the policy over the sibling commitments.  ok[i] = 1 iff both hold. */
+int32_t dapol_verify_entities(dapol_ctx* ctx, int32_t height, size_t b, const uint64_t* leaf_idx, const uint8_t* leaf_C32,
+                              const uint8_t* leaf_H32, const uint8_t* path_C32, const uint8_t* path_H32, const uint8_t root_C32[32],
+                              const uint8_t root_H32[32], int32_t policy, int32_t aggregation_factor, int32_t n_bits,
+                              const uint8_t* range_proofs, const uint8_t verify_seed32[32], uint8_t* ok);
+
 /* Bench / roofline support: device-resident variant of build + prove-all used by bench.py so that the timed
  * region starts with inputs already in HBM and nothing is copied back.  Handles are opaque device buffers. */
 typedef struct dapol_workload dapol_workload;

@@ -447,3 +447,49 @@ def test_leaf_derivation_errors(gpu_ctx, hip_lib):
     assert e.value.code == 8                                          # beyond one BLAKE3 chunk: documented limit of this path
     out = gpu_ctx.build_leaf_nodes([(b"a" * 1100, b"w", 1)], b"test", 8, hip_lib.DIGEST_BLAKE2S)      # Blake2s has no such limit
     assert len(out["leaf_idx"]) == 1
+
+
+# ------------------------------------------------------------------------------------------------ DapolProof::verify (8f #3)
+@pytest.mark.parametrize("height,policy,agg", [(8, 0, 8), (8, 1, 5), (6, 0, 3), (9, 1, 9), (5, 0, 0)])
+def test_prove_then_verify_entities(gpu_ctx, hip_lib, height, policy, agg):
+    """The reference's round trip (src/tests.rs:66-93, 108-127): every proof verifies against root and leaf; tampering fails."""
+    rng = np.random.default_rng(height * 31 + agg)
+    idx, v, r = _rand_leaves(rng, height, 12, vmax=8)
+    tr = hip_lib.Tree(gpu_ctx, height, idx, v, r, SEED)
+    rC, rH, _, _ = tr.root()
+    pC, pH, proofs = tr.prove_entities(idx, policy, agg, 8, SEED)
+    lC, lH = gpu_ctx.commit_hash_batch(v, r)                              # the leaves' proof nodes
+    ok = gpu_ctx.verify_entities(height, idx, lC, lH, pC, pH, rC, rH, policy, agg, 8, proofs, verify_seed=SEED)
+    assert ok.all()
+    bad_hash = pH.copy()
+    bad_hash[0, height - 1, 5] ^= 1                                       # sibling hash of entity 0
+    bad_range = proofs.copy()
+    bad_range[1, 70] ^= 1                                                 # range proof of entity 1
+    wrong_leaf = lC.copy()
+    wrong_leaf[2] = lC[3]                                                 # entity 2 presented with another leaf commitment
+    assert list(gpu_ctx.verify_entities(height, idx, lC, lH, pC, bad_hash, rC, rH, policy, agg, 8, proofs, verify_seed=SEED)) == [0] + [1] * 11
+    assert list(gpu_ctx.verify_entities(height, idx, lC, lH, pC, pH, rC, rH, policy, agg, 8, bad_range, verify_seed=SEED)) == [1, 0] + [1] * 10
+    assert list(gpu_ctx.verify_entities(height, idx, wrong_leaf, lH, pC, pH, rC, rH, policy, agg, 8, proofs, verify_seed=SEED)) == [1, 1, 0] + [1] * 9
+    other_root = bytes([rH[0] ^ 1]) + rH[1:]
+    assert not gpu_ctx.verify_entities(height, idx, lC, lH, pC, pH, rC, other_root, policy, agg, 8, proofs, verify_seed=SEED).any()
+    swapped = idx.copy()
+    swapped[[4, 5]] = swapped[[5, 4]]                                     # proofs presented for the wrong positions
+    okp = gpu_ctx.verify_entities(height, swapped, lC, lH, pC, pH, rC, rH, policy, agg, 8, proofs, verify_seed=SEED)
+    assert okp[:4].all() and okp[6:].all()
+
+
+def test_full_size_roundtrip_config1(gpu_ctx, hip_lib):
+    """BASELINE configs[0] shape: 2^10 entities, height 16, 64-bit proofs -- every inclusion proof verifies (encode -> verify)."""
+    height, n = 16, 1 << 10
+    idx = (np.arange(n, dtype=np.uint64) * np.uint64((1 << height) // n))
+    rng = np.random.default_rng(16)
+    v = rng.integers(0, 2**32, size=n, dtype=np.uint64)
+    r = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    r[:, 31] &= 0x0F
+    tr = hip_lib.Tree(gpu_ctx, height, idx, v, r, SEED)
+    rC, rH, rv, _ = tr.root()
+    assert rv == int(v.sum())
+    pC, pH, proofs = tr.prove_entities(idx, hip_lib.POLICY_PADDING, height, 64, SEED)
+    assert proofs.shape[1] == 32 * (9 + 2 * 10)                            # 928 bytes: m = 16 parties of 64 bits
+    lC, lH = gpu_ctx.commit_hash_batch(v, r)
+    assert gpu_ctx.verify_entities(height, idx, lC, lH, pC, pH, rC, rH, hip_lib.POLICY_PADDING, height, 64, proofs, verify_seed=SEED).all()
