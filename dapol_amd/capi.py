@@ -50,6 +50,9 @@ _SIG = {
     "dapol_range_proof_size": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32]),
     "dapol_range_verify_batch": (ctypes.c_int32, [_P, ctypes.c_int32, ctypes.c_int32, ctypes.c_size_t, _P, _P, _P, _P]),
     "dapol_prove_entities": (ctypes.c_int32, [_P, _P, ctypes.c_size_t, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P, _P, _P, _P]),
+    "dapol_range_proofs_wire_size": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
+    "dapol_range_proofs_serialize": (ctypes.c_int32, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P, _P]),
+    "dapol_range_proofs_deserialize": (ctypes.c_int32, [ctypes.c_int32, ctypes.c_int32, _P, ctypes.c_size_t, _P, ctypes.c_size_t, _P, _P, _P, _P]),
     "dapol_verify_entities": (ctypes.c_int32, [_P, ctypes.c_int32, ctypes.c_size_t, _P, _P, _P, _P, _P, _P, _P, ctypes.c_int32, ctypes.c_int32,
                                                ctypes.c_int32, _P, _P, _P]),
     "dapol_entity_proof_size": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
@@ -101,6 +104,32 @@ def _u8(a, *shape):
 
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(_P)
+
+
+def range_proofs_serialize(height, policy, aggregation_factor, n_bits, blob):
+    """R::serialize() of one entity's proofs (host-only)."""
+    blob = _u8(np.frombuffer(bytes(blob), np.uint8))
+    n = lib().dapol_range_proofs_wire_size(height, policy, aggregation_factor, n_bits)
+    out = np.zeros(max(n, 1), np.uint8)
+    _chk(lib().dapol_range_proofs_serialize(height, policy, aggregation_factor, n_bits, _ptr(blob), _ptr(out)))
+    return out[:n].tobytes()
+
+
+def range_proofs_deserialize(policy, n_bits, wire):
+    """R::deserialize(): returns (aggregated [bytes], individual [bytes], consumed)."""
+    w = _u8(np.frombuffer(bytes(wire), np.uint8)) if len(wire) else np.zeros(1, np.uint8)
+    blob = np.zeros(len(wire) + 1, np.uint8)
+    nagg, nind, cons = ctypes.c_uint32(), ctypes.c_uint64(), ctypes.c_size_t()
+    sizes = np.zeros(16, np.uint64)
+    _chk(lib().dapol_range_proofs_deserialize(policy, n_bits, _ptr(w), len(wire), _ptr(blob), len(blob), ctypes.byref(nagg), _ptr(sizes),
+                                              ctypes.byref(nind), ctypes.byref(cons)))
+    b, pos, agg = blob.tobytes(), 0, []
+    for i in range(nagg.value):
+        agg.append(b[pos:pos + int(sizes[i])])
+        pos += int(sizes[i])
+    ps1 = lib().dapol_range_proof_size(n_bits, 1)
+    ind = [b[pos + i * ps1:pos + (i + 1) * ps1] for i in range(nind.value)]
+    return agg, ind, cons.value
 
 
 class Context:

@@ -285,10 +285,13 @@ DAPOL_HD bool fe_equal(const fe& f, const fe& g) {
     fe_sub(d, f, g);
     return fe_iszero(d);
 }
+// |f| as a REDUCED value (non-negative limbs): a bare negation would leave negative limbs, and a later Y - X with
+// such an X is no longer tight (this bit ge_add on decompressed points before the carry was added).
 DAPOL_HD void fe_abs(fe& h, const fe& f) {
     bool n = fe_isnegative(f);
     fe m;
     fe_neg(m, f);
+    fe_carry(m, m);
     h = f;
     fe_cmov(h, m, n);
 }

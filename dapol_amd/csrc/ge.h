@@ -8,7 +8,7 @@
 
 namespace dapol {
 
-struct ge_p3 {  // extended coordinates, x = X/Z, y = Y/Z, T = XY/Z; all four reduced
+struct ge_p3 {  // extended coordinates, x = X/Z, y = Y/Z, T = XY/Z; all four REDUCED (non-negative limbs)
     fe X, Y, Z, T;
 };
 struct ge_niels {  // affine precomputed point: (y+x, y-x, 2dxy), reduced
@@ -27,10 +27,13 @@ DAPOL_HD void ge_niels_identity(ge_niels& r) {
     fe_0(r.xy2d);
 }
 DAPOL_HD void ge_neg(ge_p3& r, const ge_p3& p) {
-    fe_neg(r.X, p.X);
+    fe t;
+    fe_neg(t, p.X);
+    fe_carry(r.X, t);               // keep the coordinates reduced
     r.Y = p.Y;
     r.Z = p.Z;
-    fe_neg(r.T, p.T);
+    fe_neg(t, p.T);
+    fe_carry(r.T, t);
 }
 
 // r = p + (neg ? -q : q), q affine precomputed.  7 mul + 1 carry.

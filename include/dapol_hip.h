@@ -156,6 +156,17 @@ int32_t dapol_prove_entities_upper(dapol_ctx* ctx, dapol_tree* tree, size_t b, c
                                    const uint8_t* up_C32, const uint8_t* up_H32, const uint64_t* up_v, const uint8_t* up_r32,
                                    uint8_t* path_C32, uint8_t* path_H32, uint8_t* range_out);
 
+/* Serializable for RangeProofPadding / RangeProofSplitting (src/range/padding.rs:38-69, src/range/splitting.rs:36-84):
+ * the range-proof blob of ONE entity as written by dapol_prove_entities <-> R::serialize() bytes
+ * ((aggregated_num ||) (size || proof)... || individual_num || proofs...; field widths src/range/mod.rs:18-21).
+ * Host-only.  Deserialisation applies RangeProof::from_bytes' framing / canonical-scalar checks and returns
+ * DAPOL_ERR_BYTES_NOT_ENOUGH / DAPOL_ERR_VALUE_DECODING like deserialize_range_proof (src/range/mod.rs:124-139). */
+size_t dapol_range_proofs_wire_size(int32_t height, int32_t policy, int32_t aggregation_factor, int32_t n_bits);
+int32_t dapol_range_proofs_serialize(int32_t height, int32_t policy, int32_t aggregation_factor, int32_t n_bits, const uint8_t* blob,
+                                     uint8_t* wire_out);
+int32_t dapol_range_proofs_deserialize(int32_t policy, int32_t n_bits, const uint8_t* wire, size_t wire_len, uint8_t* blob_out, size_t blob_cap,
+                                       uint32_t* n_aggregated, uint64_t* agg_sizes, uint64_t* n_individual, size_t* consumed);
+
 /* DapolProof::verify (src/proof/mod.rs:41-47 + :89-95) for b single-leaf inclusion proofs as produced by
  * dapol_prove_entities: MerkleProof::verify by re-merging the leaf proof node with its siblings (DapolProofNode::merge,
  * src/proof/node.rs:56-69; a sibling commitment that is not a canonical point fails like deserialisation does, :88-94)

@@ -22,6 +22,9 @@ void t_fe_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out) {
     if (op == 3) { fe t; fe_add(t, x, y); fe_add(t, t, x); fe_mul(r, t, y); }
     if (op == 4) { fe t; fe_sub(t, x, y); fe_sq(r, t); }
     if (op == 5) { fe t; fe_sub(t, x, y); fe_sub(t, t, y); fe_neg(t, t); fe_carry(r, t); }
+    if (op == 6) { fe_add(r, x, y); }                       // canonical encoding of an UNCARRIED sum of two reduced values
+    if (op == 7) { fe t; fe_neg(t, y); fe_sub(r, x, t); }   // x - (-y): what fe_equal(check, -u) encodes
+    if (op == 8) { fe t; fe_neg(t, x); fe_sub(r, t, y); }   // -x - y
     fe_tobytes(out, r);
 }
 // k*B by double-and-add over ge_dbl / ge_add, k = 256-bit little-endian integer
@@ -144,6 +147,40 @@ void t_digest(int kind, const uint8_t* in, int n, uint8_t* out) {
     uint32_t o[8];
     dg_final(d, o);
     st(out, o, 8);
+}
+// decompress(a) + decompress(b) (general addition of two decoded points), compressed
+void t_add_compressed(const uint8_t* a, const uint8_t* b, uint8_t* out) {
+    uint32_t wa[8], wb[8], o[8];
+    ld(wa, a, 8); ld(wb, b, 8);
+    ge_p3 p, q, r;
+    ge_decompress(p, wa);
+    ge_decompress(q, wb);
+    ge_add(r, p, q);
+    ge_compress(o, r);
+    st(out, o, 8);
+}
+// the body of k_verify_paths (kernels_verify.h) for one entity, on the host
+int t_verify_path(int height, uint64_t idx, const uint8_t* leafC, const uint8_t* leafH, const uint8_t* pC, const uint8_t* pH,
+                  const uint8_t* rootC, const uint8_t* rootH) {
+    uint32_t c[8], h[8], sc_[8], sh[8], hn[8], rc[8], rh[8];
+    ld(c, leafC, 8); ld(h, leafH, 8); ld(rc, rootC, 8); ld(rh, rootH, 8);
+    ge_p3 acc, sp;
+    bool good = ge_decompress(acc, c);
+    for (int k = 0; k < height; k++) {
+        size_t slot = (size_t)(height - 1 - k);
+        ld(sc_, pC + 32 * slot, 8);
+        ld(sh, pH + 32 * slot, 8);
+        good &= ge_decompress(sp, sc_);
+        if ((idx >> k) & 1) blake3_hash128(hn, sc_, c, sh, h);
+        else blake3_hash128(hn, c, sc_, h, sh);
+        ge_p3 t;
+        ge_add(t, acc, sp);
+        acc = t;
+        ge_compress(c, acc);
+        for (int i = 0; i < 8; i++) h[i] = hn[i];
+    }
+    for (int i = 0; i < 8; i++) good &= (c[i] == rc[i]) & (h[i] == rh[i]);
+    return good;
 }
 // SHAKE256 / SHA3-512 through the generic sponge
 void t_sponge(int rate, int domain, const uint8_t* in, int n, uint8_t* out, int outlen) {

@@ -53,3 +53,29 @@ def test_error_strings_and_no_device_behaviour(hip_lib):
         rc = lib.dapol_ctx_create(0, 32, 0, ctypes.byref(h))
         assert rc == 16 and not h.value              # fails loudly: no CPU fallback
         assert b"no usable HIP device" in lib.dapol_last_error()
+
+
+def test_wire_format_matches_reference_layout(hip_lib, pyref):
+    """Serializable for RangeProofPadding / RangeProofSplitting (src/range/padding.rs:38-69, splitting.rs:36-84) against the
+    golden serialisations made by the oracle; decoding errors mirror DecodingError."""
+    import pytest
+    from conftest import load_golden
+    for c in load_golden("dapol.json"):
+        pol = 0 if c["policy"] == "padding" else 1
+        blob = bytes.fromhex("".join(c["aggregated"]) + "".join(c["individual"]))
+        wire = hip_lib.range_proofs_serialize(c["height"], pol, c["agg"], c["n_bits"], blob)
+        assert wire.hex() == c["serialized"]
+        agg, ind, used = hip_lib.range_proofs_deserialize(pol, c["n_bits"], wire + b"trailing")
+        assert [a.hex() for a in agg] == c["aggregated"] and [i.hex() for i in ind] == c["individual"] and used == len(wire)
+        with pytest.raises(hip_lib.DapolError) as e:
+            hip_lib.range_proofs_deserialize(pol, c["n_bits"], wire[:-3])
+        assert e.value.code == 6                                      # DecodingError::BytesNotEnough
+        bad = bytearray(wire)
+        off = (2 if pol else 0) + 8 + 32 * 4                          # t_x of the first aggregated proof := 2^256 - 1 (not canonical)
+        bad[off:off + 32] = b"\\xff" * 32
+        with pytest.raises(hip_lib.DapolError) as e:
+            hip_lib.range_proofs_deserialize(pol, c["n_bits"], bytes(bad))
+        assert e.value.code == 7                                      # DecodingError::ValueDecodingError
+    lib = hip_lib.lib()
+    assert lib.dapol_range_proofs_wire_size(32, 0, 32, 64) == 8 + 992 + 8
+    assert lib.dapol_range_proofs_wire_size(32, 1, 24, 64) == 2 + (8 + 928) + (8 + 864) + 8 + 8 * 672

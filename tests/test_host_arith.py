@@ -26,6 +26,9 @@ def test_field_ops(host_shim, pyref):
         assert op(3, a, b) == (2 * a + b) * b % P          # loose f operand
         assert op(4, a, b) == (a - b) ** 2 % P             # tight difference squared
         assert op(5, a, b) == (-(a - 2 * b)) % P           # carry of a negative loose value
+        assert op(6, a, b) == (a + b) % P                  # fe_tobytes on uncarried two-term sums / differences
+        assert op(7, a, b) == (a + b) % P
+        assert op(8, a, b) == (-a - b) % P
         if it < 100 and a % P:
             assert op(2, a, b) == pow(a, P - 2, P)
 
@@ -60,6 +63,19 @@ def test_group_law_and_codec(host_shim, pyref):
         o = buf(32)
         host_shim.t_from_uniform(u, o)
         assert o.raw == R.from_uniform_bytes(u).compress()
+
+
+def test_add_of_decompressed_points(host_shim, pyref):
+    """Regression: decompress returns |x|; the general addition must stay within the limb bounds for such inputs
+    (Mergeable::merge on compressed records, Merkle path re-merge)."""
+    R = pyref
+    rnd = random.Random(11)
+    pts = [rnd.randrange(R.L) * R.BASEPOINT for _ in range(40)]
+    for i in range(400):
+        a, b = rnd.choice(pts), rnd.choice(pts)
+        o = buf(32)
+        host_shim.t_add_compressed(a.compress(), b.compress(), o)
+        assert o.raw == (a + b).compress(), i
 
 
 def test_scalar_field(host_shim, pyref):
