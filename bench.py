@@ -209,6 +209,16 @@ def main():
         cpu, cpu_bytes, ns, ps = cpu_baseline(ref, height, n_bits, idx, v, r, (sv, sr, sample_ids))
         gpu_bytes = prover.sample_proofs(sample_ids[:ns], ps)
         parity = {"proofs_compared": ns, "bit_exact": bool(gpu_bytes.tobytes() == cpu_bytes)}
+    # encode -> verify round trip at full size: sampled inclusion proofs of the timed run through DapolProof::verify on the GPU
+    nv = min(2048, n_per_gpu)
+    vids = np.ascontiguousarray(idx[:: max(1, n_per_gpu // nv)][:nv])
+    vpos = np.searchsorted(idx, vids)
+    _, _, vC, vH = prover.sample_paths(vids, PAD_SEED, with_nodes=True)
+    lC, lH = ctx.commit_hash_batch(v[vpos], r[vpos])
+    vproofs = prover.sample_proofs(vids, int(stats.proof_bytes // max(1, stats.proofs)))
+    rC, rH = prover.root[0], prover.root[1]
+    okv = ctx.verify_entities(height, vids, lC, lH, vC, vH, rC, rH, capi.POLICY_PADDING, height, n_bits, vproofs, verify_seed=PAD_SEED)
+    parity = dict(parity or {}, inclusion_proofs_verified_on_gpu=int(okv.sum()), inclusion_proofs_checked=int(len(okv)))
     line = {
         "metric": "entities/sec (tree build + 64-bit range-proof gen), 2^20 leaves, 1/2/4/8 GPU",
         "value": value, "unit": "entities/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

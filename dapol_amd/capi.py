@@ -63,7 +63,7 @@ _SIG = {
     "dapol_workload_build": (ctypes.c_int32, [_P, _P, _P, _P, _P, _P, ctypes.POINTER(WorkloadStats)]),
     "dapol_workload_prove": (ctypes.c_int32, [_P, _P, ctypes.c_int32, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int32, _P, _P, _P, _P,
                                               ctypes.POINTER(WorkloadStats)]),
-    "dapol_workload_paths": (ctypes.c_int32, [_P, ctypes.c_size_t, _P, ctypes.c_int32, _P, _P, _P, _P]),
+    "dapol_workload_paths": (ctypes.c_int32, [_P, ctypes.c_size_t, _P, ctypes.c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dapol_workload_destroy": (ctypes.c_int32, [_P]),
     "dapol_workload_run": (ctypes.c_int32, [_P, _P, _P, ctypes.c_int32, ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(WorkloadStats)]),
     "dapol_workload_proofs": (ctypes.c_int32, [_P, ctypes.c_size_t, ctypes.c_size_t, _P]),
@@ -356,15 +356,19 @@ class Workload:
         _, st = self.build(pad_seed)
         return self.prove(nonce_seed, n_bits, first, count, stats=st)
 
-    def paths(self, leaf_idx, upper=None):
+    def paths(self, leaf_idx, upper=None, with_nodes=False):
+        """Siblings of sampled leaves of the last build: (v, r) and, with_nodes, also the proof nodes (C, H)."""
         leaf_idx = _u64(leaf_idx)
         b = leaf_idx.shape[0]
         nu = 0 if upper is None else len(upper[2])
         sv, sr = np.zeros((b, self.height), np.uint64), np.zeros((b, self.height, 32), np.uint8)
+        sC, sH = (np.zeros((b, self.height, 32), np.uint8), np.zeros((b, self.height, 32), np.uint8)) if with_nodes else (None, None)
+        uC = _u8(upper[0], nu, 32) if nu else None
+        uH = _u8(upper[1], nu, 32) if nu else None
         uv = _u64(upper[2]) if nu else None
         ur = _u8(upper[3], nu, 32) if nu else None
-        _chk(lib().dapol_workload_paths(self.h, b, _ptr(leaf_idx), nu, _ptr(uv), _ptr(ur), _ptr(sv), _ptr(sr)))
-        return sv, sr
+        _chk(lib().dapol_workload_paths(self.h, b, _ptr(leaf_idx), nu, _ptr(uv), _ptr(ur), _ptr(uC), _ptr(uH), _ptr(sv), _ptr(sr), _ptr(sC), _ptr(sH)))
+        return (sv, sr, sC, sH) if with_nodes else (sv, sr)
 
     def proofs(self, first, count, proof_size):
         out = np.zeros((count, proof_size), np.uint8)

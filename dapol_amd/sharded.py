@@ -87,8 +87,8 @@ class ShardedProver:
             st.checksum = (int(cs[0].item()) + (int(cs[1].item()) << 32)) & 0xFFFFFFFFFFFFFFFF
         return st
 
-    def sample_paths(self, leaf_ids, pad_seed):
-        return self.w.paths(leaf_ids, upper=self.upper)
+    def sample_paths(self, leaf_ids, pad_seed, with_nodes=False):
+        return self.w.paths(leaf_ids, upper=self.upper, with_nodes=with_nodes)
 
     def sample_proofs(self, leaf_ids, proof_size):
         """Proofs of the given leaves from the last step (leaf_ids must be leaves of this rank, any order)."""

@@ -203,9 +203,11 @@ int32_t dapol_workload_build(dapol_workload* w, const uint8_t pad_seed32[32], ui
 int32_t dapol_workload_prove(dapol_workload* w, const uint8_t nonce_seed32[32], int32_t n_bits, size_t first_entity, size_t n_entities,
                              int32_t n_upper, const uint8_t* up_C32, const uint8_t* up_H32, const uint64_t* up_v, const uint8_t* up_r32,
                              dapol_workload_stats* stats);
-/* Siblings (v, r) of sampled leaves of the last build, with the upper siblings prepended: [b][n_upper+levels]. */
+/* Siblings of sampled leaves of the last build, with the upper siblings prepended: [b][n_upper+levels].  (v, r) are the
+ * secrets handed to the range prover; (C, H) the Merkle path proof nodes.  Output / upper pointers may be NULL in pairs. */
 int32_t dapol_workload_paths(dapol_workload* w, size_t b, const uint64_t* leaf_idx, int32_t n_upper, const uint64_t* up_v,
-                             const uint8_t* up_r32, uint64_t* sib_v, uint8_t* sib_r32);
+                             const uint8_t* up_r32, const uint8_t* up_C32, const uint8_t* up_H32, uint64_t* sib_v, uint8_t* sib_r32,
+                             uint8_t* sib_C32, uint8_t* sib_H32);
 /* Copies back the proofs of entities [first, first+count) of the last run (count*proof_size bytes). */
 int32_t dapol_workload_proofs(dapol_workload* w, size_t first, size_t count, uint8_t* out);
 

@@ -101,7 +101,7 @@ def test_scalar_field(host_shim, pyref):
         d = (ctypes.c_int16 * 32)()
         host_shim.t_sc_recode(x.to_bytes(32, "little"), d)
         assert sum(int(d[i]) * 256**i for i in range(32)) == x and all(abs(int(v)) <= 128 for v in d)
-        for w in range(8, 16):
+        for w in range(8, 17):
             nw = 255 // w + 1                                      # any 255-bit integer (unreduced leaf blindings)
             dw = (ctypes.c_int * nw)()
             host_shim.t_sc_recode_w(w, nw, x.to_bytes(32, "little"), dw)
@@ -110,7 +110,7 @@ def test_scalar_field(host_shim, pyref):
             nwc = 253 // w + 1                                     # canonical scalars (digit matrices)
             dc = (ctypes.c_int * nwc)()
             host_shim.t_sc_recode_w(w, nwc, xc.to_bytes(32, "little"), dc)
-            assert sum(int(dc[i]) << (w * i) for i in range(nwc)) == xc and all(abs(int(v)) <= (1 << (w - 1)) for v in dc)
+            assert sum(int(dc[i]) << (w * i) for i in range(nwc)) == xc and all(-32768 <= int(v) <= 32767 for v in dc)
 
 
 def test_hashes_and_transcript(host_shim, pyref):
