@@ -211,16 +211,16 @@ DAPOL_HD void fe_tobytes(uint8_t* s, const fe& f) {
     q = (h5 + q) >> 25; q = (h6 + q) >> 26; q = (h7 + q) >> 25; q = (h8 + q) >> 26; q = (h9 + q) >> 25;
     h0 += 19 * q;
     int32_t c;
-    c = h0 >> 26; h1 += c; h0 -= c << 26;
-    c = h1 >> 25; h2 += c; h1 -= c << 25;
-    c = h2 >> 26; h3 += c; h2 -= c << 26;
-    c = h3 >> 25; h4 += c; h3 -= c << 25;
-    c = h4 >> 26; h5 += c; h4 -= c << 26;
-    c = h5 >> 25; h6 += c; h5 -= c << 25;
-    c = h6 >> 26; h7 += c; h6 -= c << 26;
-    c = h7 >> 25; h8 += c; h7 -= c << 25;
-    c = h8 >> 26; h9 += c; h8 -= c << 26;
-    c = h9 >> 25; h9 -= c << 25;
+    c = h0 >> 26; h1 += c; h0 -= c * (1 << 26);
+    c = h1 >> 25; h2 += c; h1 -= c * (1 << 25);
+    c = h2 >> 26; h3 += c; h2 -= c * (1 << 26);
+    c = h3 >> 25; h4 += c; h3 -= c * (1 << 25);
+    c = h4 >> 26; h5 += c; h4 -= c * (1 << 26);
+    c = h5 >> 25; h6 += c; h5 -= c * (1 << 25);
+    c = h6 >> 26; h7 += c; h6 -= c * (1 << 26);
+    c = h7 >> 25; h8 += c; h7 -= c * (1 << 25);
+    c = h8 >> 26; h9 += c; h8 -= c * (1 << 26);
+    c = h9 >> 25; h9 -= c * (1 << 25);
     uint32_t w[8];
     w[0] = (uint32_t)h0 | ((uint32_t)h1 << 26);
     w[1] = ((uint32_t)h1 >> 6) | ((uint32_t)h2 << 19);
