@@ -38,6 +38,7 @@ struct RangeArgs {
     // scratch
     sc* a; sc* b; sc* s1; sc* s2;       // [B][N] each
     dig_t* dig;                         // [B][nwin][TP] signed radix-2^wbits digits
+    int nsplit;                         // MSM term-range splits per proof (0/1 = none); partial points at [b * nsplit + s]
     ProofState* st;                     // [B]
     int32_t* PA; int32_t* P0; int32_t* P1;   // [B][40] partial points
     int32_t* tailT;                     // [B][64][8][40]  per-lane window tables of the materialised folded generators
@@ -192,10 +193,15 @@ __global__ __launch_bounds__(64, 3) void k_rp_msm(RangeArgs A, TableView tbl, in
     constexpr int PPW = 32 / LPL;
     int l = threadIdx.x;
     int sub = l / (2 * LPL), ll = l % (2 * LPL), side = ll / LPL, ql = ll % LPL;
-    size_t b = (size_t)blockIdx.x * PPW + sub;
+    // Large proofs (1024-party verification) are split over nsplit wavefronts per proof, each taking a slice of the
+    // term range; the partial points are summed by the consumer.
+    const int nsplit = A.nsplit > 1 ? A.nsplit : 1;
+    const int split = (int)(blockIdx.x % nsplit);
+    size_t b = (size_t)(blockIdx.x / nsplit) * PPW + sub;
     bool valid = b < A.B;
     if (!valid) b = A.B - 1;
-    int niter = (A.N + LPL - 1) / LPL;
+    int niter_all = (A.N + LPL - 1) / LPL;
+    int i_begin = (int)((long long)niter_all * split / nsplit), niter = (int)((long long)niter_all * (split + 1) / nsplit);
     const dig_t* dig = A.dig + b * A.nwin * (size_t)A.TP + 32 * side;
     const int NW = A.nwin, W = A.wbits;
     ge_p3 acc;
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(64, 3) void k_rp_msm(RangeArgs A, TableView tbl, in
             for (int d = 0; d < W; d++) ge_dbl(acc, acc, d == W - 1);
         }
         const dig_t* dw = dig + (size_t)w * A.TP;
-        for (int i = 0; i < niter; i++) {
+        for (int i = i_begin; i < niter; i++) {
             int q = LPL * i + ql;
             if (q < A.N) {
                 int d = dw[64 * (q >> 5) + (q & 31)];
@@ -227,7 +233,7 @@ __global__ __launch_bounds__(64, 3) void k_rp_msm(RangeArgs A, TableView tbl, in
         st_p3(A.tailT + (b * 64 + l) * (size_t)(8 * 40), acc);
     } else {
         wave_reduce_point(acc, lds, l, LPL);
-        if (ql == 0 && valid) st_p3((side ? A.P1 : A.P0) + b * 40, acc);
+        if (ql == 0 && valid) st_p3((side ? A.P1 : A.P0) + (b * nsplit + split) * 40, acc);
     }
 }
 

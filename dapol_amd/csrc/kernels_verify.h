@@ -198,17 +198,25 @@ __global__ __launch_bounds__(64) void k_rv_finish(VerifyArgs V, TableView tbl) {
     size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (b >= A.B) return;
     const VerifyState& vs = V.vs[b];
-    ge_p3 p0, p1, p2, t;
-    ld_p3(p0, A.P0 + b * 40);
-    ld_p3(p1, A.P1 + b * 40);
-    ld_p3(p2, A.PA + b * 40);
-    ge_add(t, p0, p1);
-    ge_add(p0, t, p2);
+    ge_p3 p0, p1, t;
+    const int nsplit = A.nsplit > 1 ? A.nsplit : 1;
+    ld_p3(p0, A.PA + b * 40);
+    for (int sidx = 0; sidx < nsplit; sidx++) {            // partial sums of the (possibly split) fixed-base MSM
+        ld_p3(p1, A.P0 + (b * nsplit + sidx) * 40);
+        ge_add(t, p0, p1);
+        ld_p3(p1, A.P1 + (b * nsplit + sidx) * 40);
+        ge_add(p0, t, p1);
+    }
     sc one, zz, sumy, py, sumz, pz, sum2, delta, s1, s2, bb, bs;
     sc_one_mont(one);
     sc_montmul(zz, vs.z, vs.z);
-    sc_zero(sumy); py = one;
-    for (int i = 0; i < A.N; i++) { sc_add(sumy, sumy, py); sc_montmul(py, py, vs.y); }
+    // sum_{i<N} y^i = (y^N - 1) / (y - 1)   (N a power of two: lgN squarings; y = 1 has probability 2^-252)
+    py = vs.y;
+    for (int i = 0; i < A.lgN; i++) sc_montmul(py, py, py);
+    sc ym1, ym1_inv;
+    sc_sub(ym1, vs.y, one);
+    if (sc_is_zero(ym1)) { sc_from_u64_mont(sumy, (uint64_t)A.N); }
+    else { sc_invert_mont(ym1_inv, ym1); sc_sub(py, py, one); sc_montmul(sumy, py, ym1_inv); }
     sc_zero(sumz); pz = one;
     for (int j = 0; j < A.m; j++) { sc_add(sumz, sumz, pz); sc_montmul(pz, pz, vs.z); }
     sc_zero(sum2);
