@@ -104,11 +104,11 @@ int32_t dapol_ctx_create(int32_t device, int32_t max_parties, int32_t digest_id,
     struct Guard { dapol_ctx* c; ~Guard() { if (c) dapol_ctx_destroy(c); } } guard{c};
     HIPCHK(hipStreamCreate(&c->stream));
     const int P = max_parties;
-    // window width: the widest (<= 16 bits) whose tables fit the budget (DAPOL_TABLE_GB, default 20 GB), or DAPOL_WBITS
+    // window width: the widest (<= 20 bits) whose tables fit the budget (DAPOL_TABLE_GB, default 40 GB), or DAPOL_WBITS
     int wbits = WBITS_MIN;
     {
         const char* eb = getenv("DAPOL_TABLE_GB");
-        double budget = (eb ? atof(eb) : 20.0) * 1e9;
+        double budget = (eb ? atof(eb) : 40.0) * 1e9;
         for (int w = WBITS_MIN; w <= WBITS_MAX; w++) {
             TableView t{nullptr, P, w};
             if ((double)t.n_rows() * (double)t.row_words() * 4.0 <= budget) wbits = w;
@@ -116,7 +116,7 @@ int32_t dapol_ctx_create(int32_t device, int32_t max_parties, int32_t digest_id,
         const char* ew = getenv("DAPOL_WBITS");
         if (ew) {
             int w = atoi(ew);
-            if (w < WBITS_MIN || w > WBITS_MAX) return fail(DAPOL_ERR_INVALID_ARGUMENT, "DAPOL_WBITS must be in [8, 16]");
+            if (w < WBITS_MIN || w > WBITS_MAX) return fail(DAPOL_ERR_INVALID_ARGUMENT, "DAPOL_WBITS must be in [8, 20]");
             wbits = w;
         }
     }

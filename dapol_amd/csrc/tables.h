@@ -16,12 +16,13 @@
 namespace dapol {
 
 // The window width W is a property of the context (chosen at dapol_ctx_create from a table-memory budget, or the
-// DAPOL_WBITS environment variable): 8 <= W <= 16.  Measured on MI355X (profiles/r01_wbits_ab*.txt, 2^16 proofs
+// DAPOL_WBITS environment variable): 8 <= W <= 20.  Measured on MI355X (profiles/r01_wbits_ab*.txt, 2^16 proofs
 // n=64 m=32, k_rp_msm per launch): 155 / 144 / 134 / 128 ms at W = 10 / 12 / 13 / 14, proofs byte-identical.  Past
-// W = 10 the tables (273 MB -> 4.4 GB at 14 bits) no longer fit the Infinity Cache and the lookups become ~4.7 TB/s of
-// random 128-byte HBM gathers: the kernel then sits between its VALU-issue roof and the HBM gather roof.
-enum { TBL_ENTRY_WORDS = 32, WBITS_MIN = 8, WBITS_MAX = 16 };   // 16: canonical digits stay within int16 ([-2^15, 2^15-1], top window small)
-typedef int16_t dig_t;
+// W = 10 the tables (273 MB -> 4.4 GB at 14 bits) no longer fit the Infinity Cache and the lookups become random
+// 128-byte HBM gathers (~3 TB/s).  With the final kernel: 96 / 91 / 102 ms at W = 16 / 17 / 19 -- 17 bits (15 windows,
+// 34.6 GB of tables for 32 parties) is the sweet spot; at 19 bits the 138 GB of tables cost more than the saved window.
+enum { TBL_ENTRY_WORDS = 32, WBITS_MIN = 8, WBITS_MAX = 20 };
+typedef int32_t dig_t;       // digits of up to 20 bits (int16 would cap the width at 16)
 
 struct TableView {
     const int32_t* base;   // device pointer
