@@ -43,6 +43,7 @@ _SIG = {
     "dapol_tree_destroy": (ctypes.c_int32, [_P]),
     "dapol_tree_root": (ctypes.c_int32, [_P, _P, _P, _P, _P]),
     "dapol_tree_node_count": (ctypes.c_int32, [_P, _P, _P]),
+    "dapol_tree_update": (ctypes.c_int32, [_P, ctypes.c_size_t, _P, _P, _P]),
     "dapol_tree_level_size": (ctypes.c_int32, [_P, ctypes.c_int32, _P, _P]),
     "dapol_tree_level_nodes": (ctypes.c_int32, [_P, ctypes.c_int32, _P, _P, _P, _P, _P, _P]),
     "dapol_tree_paths": (ctypes.c_int32, [_P, ctypes.c_size_t, _P, _P, _P, _P, _P]),
@@ -268,6 +269,11 @@ class Tree:
         v = np.zeros(1, np.uint64)
         _chk(lib().dapol_tree_root(self.h, _ptr(C), _ptr(H), _ptr(v), _ptr(r)))
         return C.tobytes(), H.tobytes(), int(v[0]), r.tobytes()
+
+    def update(self, leaf_idx, v, r32):
+        """Dapol::update for a batch of leaves (insert or replace), applied in order."""
+        leaf_idx, v, r32 = _u64(leaf_idx), _u64(v), _u8(r32)
+        _chk(lib().dapol_tree_update(self.h, leaf_idx.shape[0], _ptr(leaf_idx), _ptr(v), _ptr(r32)))
 
     def node_count(self):
         a, b = np.zeros(1, np.uint64), np.zeros(1, np.uint64)

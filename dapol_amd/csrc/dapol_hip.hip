@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -104,12 +105,13 @@ int32_t dapol_ctx_create(int32_t device, int32_t max_parties, int32_t digest_id,
     struct Guard { dapol_ctx* c; ~Guard() { if (c) dapol_ctx_destroy(c); } } guard{c};
     HIPCHK(hipStreamCreate(&c->stream));
     const int P = max_parties;
-    // window width: the widest (<= 20 bits) whose tables fit the budget (DAPOL_TABLE_GB, default 40 GB), or DAPOL_WBITS
+    // window width: the widest (<= 17 bits: wider measured slower, profiles/r01_wbits_ab4.txt) whose tables fit the budget
+    // (DAPOL_TABLE_GB, default 40 GB), or DAPOL_WBITS (up to 20)
     int wbits = WBITS_MIN;
     {
         const char* eb = getenv("DAPOL_TABLE_GB");
         double budget = (eb ? atof(eb) : 40.0) * 1e9;
-        for (int w = WBITS_MIN; w <= WBITS_MAX; w++) {
+        for (int w = WBITS_MIN; w <= WBITS_AUTO_MAX; w++) {
             TableView t{nullptr, P, w};
             if ((double)t.n_rows() * (double)t.row_words() * 4.0 <= budget) wbits = w;
         }
@@ -221,6 +223,8 @@ struct dapol_tree {
     uint64_t* leaf_v = nullptr;
     uint32_t* leaf_r = nullptr;
     uint64_t n_pad = 0, n_real = 0;
+    int index_bits = 0, shard_bits = 0;          // what the tree was built with (dapol_tree_update rebuilds with the same)
+    uint8_t pad_seed[32] = {0};
     LevelView view(int k, int32_t* ext) {
         LevelBuf& L = levels[k];
         LevelView lv;
@@ -243,6 +247,8 @@ static int32_t tree_build_device(dapol_ctx* ctx, int index_bits, int shard_bits,
     t->ctx = ctx;
     t->height = height;
     t->leaf_idx = d_idx; t->leaf_v = d_v; t->leaf_r = d_r;
+    t->index_bits = index_bits; t->shard_bits = shard_bits;
+    memcpy(t->pad_seed, pad_seed32, 32);
     t->levels.clear();
     t->levels.resize((size_t)height + 1);
     t->n_pad = 0;
@@ -299,7 +305,7 @@ struct OwnedLeaves {
     DevBuf<uint32_t> r;
 };
 struct dapol_tree_owned : dapol_tree {
-    OwnedLeaves leaves;
+    OwnedLeaves leaves;          // empty when level 0 borrows the caller's device arrays (workload trees)
 };
 
 int32_t dapol_tree_build(dapol_ctx* ctx, int32_t height, size_t n, const uint64_t* leaf_idx, const uint64_t* v, const uint8_t* r32,
@@ -343,6 +349,64 @@ int32_t dapol_tree_build_shard(dapol_ctx* ctx, int32_t total_height, int32_t sha
     if (rc != DAPOL_OK) return rc;
     guard.t = nullptr;
     *out = t;
+    return DAPOL_OK;
+}
+
+// Dapol::update (src/dapol/mod.rs:211-213) for k leaves, applied in input order: a leaf is inserted, or replaces the
+// one already at its index.  Padding nodes are keyed by position, so the updated tree is exactly what
+// dapol_tree_build gives for the resulting leaf set; the host merges the (small) update into the sorted leaf arrays
+// and the level-parallel build runs again -- one pass for the whole batch instead of k root-to-leaf walks.
+int32_t dapol_tree_update(dapol_tree* tree, size_t k, const uint64_t* leaf_idx, const uint64_t* v, const uint8_t* r32) {
+    if (!tree || (k && (!leaf_idx || !v || !r32))) return fail(DAPOL_ERR_INVALID_ARGUMENT, "null argument");
+    if (k == 0) return DAPOL_OK;
+    dapol_tree_owned* own = static_cast<dapol_tree_owned*>(tree);
+    if (!own->leaves.idx.p) return fail(DAPOL_ERR_INVALID_ARGUMENT, "tree does not own its leaves (workload tree): rebuild the workload instead");
+    dapol_ctx* ctx = tree->ctx;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const size_t n0 = tree->levels[0].n;
+    std::vector<uint64_t> oi(n0), ov(n0);
+    std::vector<uint8_t> orr(n0 * 32);
+    HIPCHK(hipMemcpyAsync(oi.data(), tree->leaf_idx, n0 * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(ov.data(), tree->leaf_v, n0 * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(orr.data(), tree->leaf_r, n0 * 32, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    std::vector<uint32_t> ord(k);
+    for (size_t i = 0; i < k; i++) ord[i] = (uint32_t)i;
+    std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return leaf_idx[a] < leaf_idx[b]; });
+    std::vector<uint64_t> ni, nv;
+    std::vector<uint8_t> nr;
+    ni.reserve(n0 + k); nv.reserve(n0 + k); nr.reserve((n0 + k) * 32);
+    size_t a = 0, b = 0;
+    while (a < n0 || b < k) {
+        if (b < k) {                                        // later updates of the same index win
+            while (b + 1 < k && leaf_idx[ord[b + 1]] == leaf_idx[ord[b]]) b++;
+        }
+        bool take_new = b < k && (a >= n0 || leaf_idx[ord[b]] <= oi[a]);
+        if (take_new) {
+            uint32_t u = ord[b];
+            if (a < n0 && oi[a] == leaf_idx[u]) a++;         // replaces
+            ni.push_back(leaf_idx[u]); nv.push_back(v[u]);
+            nr.insert(nr.end(), r32 + (size_t)u * 32, r32 + (size_t)u * 32 + 32);
+            b++;
+        } else {
+            ni.push_back(oi[a]); nv.push_back(ov[a]);
+            nr.insert(nr.end(), orr.begin() + a * 32, orr.begin() + a * 32 + 32);
+            a++;
+        }
+    }
+    const size_t n = ni.size();
+    if (n > (size_t)1 << 24) return fail(DAPOL_ERR_INVALID_ARGUMENT, "at most 2^24 leaves per GPU");
+    dapol_tree_owned fresh;
+    HIPCHK(fresh.leaves.idx.alloc(n)); HIPCHK(fresh.leaves.v.alloc(n)); HIPCHK(fresh.leaves.r.alloc(n * 8));
+    HIPCHK(hipMemcpyAsync(fresh.leaves.idx.p, ni.data(), n * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(fresh.leaves.v.p, nv.data(), n * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(fresh.leaves.r.p, nr.data(), n * 32, hipMemcpyHostToDevice, st));
+    uint8_t seed[32];
+    memcpy(seed, tree->pad_seed, 32);
+    int32_t rc = tree_build_device(ctx, tree->index_bits, tree->shard_bits, n, fresh.leaves.idx.p, fresh.leaves.v.p, fresh.leaves.r.p, seed, &fresh);
+    if (rc != DAPOL_OK) return rc;                          // the old tree stays as it was
+    *own = std::move(fresh);
     return DAPOL_OK;
 }
 

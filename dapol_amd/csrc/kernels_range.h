@@ -41,11 +41,19 @@ struct RangeArgs {
     int nsplit;                         // MSM term-range splits per proof (0/1 = none); partial points at [b * nsplit + s]
     ProofState* st;                     // [B]
     int32_t* PA; int32_t* P0; int32_t* P1;   // [B][40] partial points
-    int32_t* tailT;                     // [B][64][8][40]  per-lane window tables of the materialised folded generators
-    sc* tailS;                          // [B][64]         running u^{+-1} coefficients of those generators
+    int32_t* tailT;                     // [B][64][TAIL_ENTRIES][32]  per-proof window tables of the materialised folded generators
+    sc* tail_a; sc* tail_b; sc* tail_s1; sc* tail_s2;   // [B][32] each: the vectors / coefficients of the tail argument
     uint32_t* out;                      // [B][out_words]
     int out_words;
+    int out_round0;                     // rounds already written before this argument's round 0 (tail: lgN - 5)
 };
+
+// The tail of the hybrid inner-product argument is itself a never-fold argument of length 32
+// over the 64 materialised generators, served by a per-proof table of signed 4-bit windows in the same 128-byte
+// affine-niels format as the context tables.
+enum { TAIL_N = 32, TAIL_LGN = 5, TAIL_WBITS = 4, TAIL_NWIN = 253 / TAIL_WBITS + 1, TAIL_ENTRIES = (1 << (TAIL_WBITS - 1)) + 1,
+       TAIL_ROW_WORDS = TAIL_ENTRIES * 32, TAIL_TABLE_WORDS = 64 * TAIL_ROW_WORDS };
+enum { MSM_PLAIN = 0, MSM_MATERIALIZE = 1, MSM_TAIL = 2 };
 
 __device__ __forceinline__ void tape_wide(uint32_t* w16, const RangeArgs& A, size_t b, uint32_t slot) {
     if (A.tape) {
@@ -184,11 +192,13 @@ __global__ __launch_bounds__(64) void k_rp_A(RangeArgs A, TableView tbl) {
 // the nwin signed W-bit windows from the top with W shared doublings per window (Straus), and looks every
 // digit up in the generator's row (one 128-byte cache line per lookup, L2 / Infinity-Cache resident).
 // Lanes 0-31 accumulate list 0, lanes 32-63 list 1; two 32-lane LDS tree reductions give P0 and P1.
-template <bool MATERIALIZE, int LPL>
+template <int MODE, int LPL>
 __global__ __launch_bounds__(64, 3) void k_rp_msm(RangeArgs A, TableView tbl, int round) {
     // LPL = lanes per list.  32: one proof per wavefront (64 terms per lane at N = 2048).  16 / 8: two / four proofs per
     // wavefront with 128 / 256 terms per lane, which amortises the W * nwin shared doublings (22 % of the instructions
     // at LPL = 32) over more mixed adds.  The digit layout is the same for every LPL.
+    // MODE: MSM_PLAIN -> P0 / P1;  MSM_MATERIALIZE -> the 64 per-lane sums are kept (folded generators);  MSM_TAIL ->
+    // the table is the PROOF's own (64 rows at tbl.base + b * TAIL_TABLE_WORDS), rows = G'_0..31, H'_0..31.
     __shared__ int32_t lds[40 * 64];
     constexpr int PPW = 32 / LPL;
     int l = threadIdx.x;
@@ -200,6 +210,7 @@ __global__ __launch_bounds__(64, 3) void k_rp_msm(RangeArgs A, TableView tbl, in
     size_t b = (size_t)(blockIdx.x / nsplit) * PPW + sub;
     bool valid = b < A.B;
     if (!valid) b = A.B - 1;
+    if constexpr (MODE == MSM_TAIL) tbl.base += b * (size_t)TAIL_TABLE_WORDS;
     int niter_all = (A.N + LPL - 1) / LPL;
     int i_begin = (int)((long long)niter_all * split / nsplit), niter = (int)((long long)niter_all * (split + 1) / nsplit);
     const dig_t* dig = A.dig + b * A.nwin * (size_t)A.TP + 32 * side;
@@ -221,44 +232,70 @@ __global__ __launch_bounds__(64, 3) void k_rp_msm(RangeArgs A, TableView tbl, in
                 int d = dw[64 * (q >> 5) + (q & 31)];
                 bool isH;
                 int j = term_generator(round, A.N, A.lgN, side, q, isH);
-                tbl_madd(acc, tbl, gen_row(tbl, A.n, j, isH), d);
+                int row;
+                if constexpr (MODE == MSM_TAIL) row = j + (isH ? TAIL_N : 0);
+                else row = gen_row(tbl, A.n, j, isH);
+                tbl_madd(acc, tbl, row, d);
             }
         }
     }
-    if constexpr (MATERIALIZE) {
+    if constexpr (MODE == MSM_MATERIALIZE) {
         // Hybrid IPA: with the S-layout lane l owns exactly the generators j = l mod 32 (mod 32), so fed with the
         // s-vector digits its accumulator IS the folded generator G'_(l&31) (lanes 0-31) / H'_(l&31) (lanes 32-63) of
-        // the round whose vectors have length 32.  Keep it (k_rp_tail_table turns it into a window table).
-        static_assert(!MATERIALIZE || LPL == 32, "materialisation needs one proof per wavefront");
-        st_p3(A.tailT + (b * 64 + l) * (size_t)(8 * 40), acc);
+        // the round whose vectors have length 32.  Keep it at the head of its table row (k_rp_tail_table builds the row).
+        static_assert(MODE != MSM_MATERIALIZE || LPL == 32, "materialisation needs one proof per wavefront");
+        st_p3(A.tailT + b * (size_t)TAIL_TABLE_WORDS + (size_t)l * TAIL_ROW_WORDS, acc);
     } else {
         wave_reduce_point(acc, lds, l, LPL);
         if (ql == 0 && valid) st_p3((side ? A.P1 : A.P0) + (b * nsplit + split) * 40, acc);
     }
 }
 
-// Per-lane table of the multiples 1..8 of each materialised folded generator, in cached form; coefficient := 1.
+// One lane per materialised generator P: its table row 0*P .. 8*P in affine niels form (one inversion per row by
+// Montgomery's trick; the projective multiples wait in the row's own entry slots), and the tail argument's vectors:
+// a, b = the first 32 entries of the folded vectors, coefficients s = 1.
 __global__ __launch_bounds__(64) void k_rp_tail_table(RangeArgs A) {
-    size_t g = (size_t)blockIdx.x * 64 + threadIdx.x;          // (proof, lane) flattened
-    if (g >= A.B * 64) return;
-    int32_t* T = A.tailT + g * (size_t)(8 * 40);
+    size_t b = blockIdx.x;
+    int l = threadIdx.x;
+    int32_t* row = A.tailT + b * (size_t)TAIL_TABLE_WORDS + (size_t)l * TAIL_ROW_WORDS;
     ge_p3 base, mul;
-    ld_p3(base, T);
+    ld_p3(base, row);
     mul = base;
-    ge_cached c1;
-    ge_to_cached(c1, base);
-    for (int e = 0; e < 8; e++) {
-        ge_cached c;
-        ge_to_cached(c, mul);
-        int32_t w[40];
-        for (int i = 0; i < 10; i++) { w[i] = c.YpX.v[i]; w[10 + i] = c.YmX.v[i]; w[20 + i] = c.Z.v[i]; w[30 + i] = c.T2d.v[i]; }
-        int4* q4 = reinterpret_cast<int4*>(T + e * 40);
-        for (int i = 0; i < 10; i++) q4[i] = make_int4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
-        if (e < 7) { ge_p3 t; ge_add_cached(t, mul, c1, false); mul = t; }
+    fe pre[TAIL_ENTRIES - 1];
+#pragma unroll
+    for (int e = 1; e < TAIL_ENTRIES; e++) {
+        if (e > 1) { ge_p3 t; ge_add(t, mul, base); mul = t; }
+        int32_t* slot = row + e * 32;
+        for (int i = 0; i < 10; i++) { slot[i] = mul.X.v[i]; slot[10 + i] = mul.Y.v[i]; slot[20 + i] = mul.Z.v[i]; }
+        if (e == 1) pre[0] = mul.Z;
+        else fe_mul(pre[e - 1], pre[e - 2], mul.Z);
     }
-    sc one;
+    fe inv;
+    fe_invert(inv, pre[TAIL_ENTRIES - 2]);
+#pragma unroll
+    for (int e = TAIL_ENTRIES - 1; e >= 1; e--) {
+        int32_t* slot = row + e * 32;
+        fe X, Y, Z, zi, x, y;
+        for (int i = 0; i < 10; i++) { X.v[i] = slot[i]; Y.v[i] = slot[10 + i]; Z.v[i] = slot[20 + i]; }
+        if (e > 1) { fe_mul(zi, inv, pre[e - 2]); fe t; fe_mul(t, inv, Z); inv = t; }
+        else zi = inv;
+        fe_mul(x, X, zi);
+        fe_mul(y, Y, zi);
+        ge_niels q;
+        ge_to_niels(q, x, y);
+        for (int i = 0; i < 10; i++) { slot[i] = q.ypx.v[i]; slot[10 + i] = q.ymx.v[i]; slot[20 + i] = q.xy2d.v[i]; }
+        slot[30] = 0; slot[31] = 0;
+    }
+    ge_niels id;
+    ge_niels_identity(id);
+    for (int i = 0; i < 10; i++) { row[i] = id.ypx.v[i]; row[10 + i] = id.ymx.v[i]; row[20 + i] = id.xy2d.v[i]; }
+    row[30] = 0; row[31] = 0;
+    sc one, v;
     sc_one_mont(one);
-    st_sc(A.tailS + g, one);
+    int i = l & 31;
+    st_sc((l < 32 ? A.tail_s1 : A.tail_s2) + b * TAIL_N + i, one);
+    ld_sc(v, (l < 32 ? A.a : A.b) + b * A.N + i);
+    st_sc((l < 32 ? A.tail_a : A.tail_b) + b * TAIL_N + i, v);
 }
 
 // Digits of the s-vectors themselves, in the S layout (list 0 = s_G over G, list 1 = s_H over H): input of the
@@ -271,97 +308,6 @@ __global__ __launch_bounds__(64) void k_rp_mat_prep(RangeArgs A) {
     sc s;
     ld_sc(s, (side ? A.s2 : A.s1) + b * A.N + q);
     write_digits(A, b, pos, s);
-}
-
-// Tail round k (vector length n = N >> k <= 32): every lane multiplies ITS folded generator by its round scalar
-// (a or b entry times the running coefficient) -- one variable-base scalar multiplication per lane with signed 4-bit
-// windows over the lane's own table -- and two masked wave reductions give L_k and R_k (without the c*Q terms).
-__global__ __launch_bounds__(64) void k_rp_tail_mul(RangeArgs A, int round) {
-    __shared__ int32_t lds[40 * 64];
-    size_t b = blockIdx.x;
-    int l = threadIdx.x, isH = l >> 5, i = l & 31;
-    int lgh = A.lgN - 1 - round, half = 1 << lgh;
-    int off = i & (half - 1);
-    bool upper = (i >> lgh) & 1;
-    int vi = upper ? off : off + half;
-    sc v, cf, p;
-    ld_sc(v, (isH ? A.b : A.a) + b * A.N + vi);
-    ld_sc(cf, A.tailS + b * 64 + l);
-    sc_montmul(p, v, cf);
-    uint32_t k[8];
-    sc_from_mont(k, p);
-    const int32_t* T = A.tailT + (b * 64 + l) * (size_t)(8 * 40);
-    ge_p3 acc;
-    ge_identity(acc);
-    // signed radix-16 digits, most significant first (64 digits cover 256 bits; canonical scalars < 2^253)
-    int dig[64];
-    {
-        int carry = 0;
-        for (int j = 0; j < 64; j++) {
-            int x = (int)((k[j >> 3] >> (4 * (j & 7))) & 15) + carry;
-            carry = (x > 8 && j < 63) ? 1 : 0;
-            dig[j] = x - (carry << 4);
-        }
-    }
-    for (int j = 63; j >= 0; j--) {
-        if (j != 63) {
-            for (int d = 0; d < 4; d++) {
-                ge_p3 t;
-                ge_dbl(t, acc, d == 3);
-                acc = t;
-            }
-        }
-        int d = dig[j];
-        int ad = d < 0 ? -d : d;
-        int e = ad ? ad - 1 : 0;
-        const int4* q4 = reinterpret_cast<const int4*>(T + e * 40);
-        int32_t w[40];
-        for (int t = 0; t < 10; t++) { int4 x = q4[t]; w[4 * t] = x.x; w[4 * t + 1] = x.y; w[4 * t + 2] = x.z; w[4 * t + 3] = x.w; }
-        ge_cached c;
-        for (int t = 0; t < 10; t++) { c.YpX.v[t] = w[t]; c.YmX.v[t] = w[10 + t]; c.Z.v[t] = w[20 + t]; c.T2d.v[t] = w[30 + t]; }
-        ge_p3 r;
-        ge_add_cached(r, acc, c, d < 0);
-        if (ad) acc = r;
-    }
-    // L takes G upper / H lower, R takes G lower / H upper
-    bool toL = isH ? !upper : upper;
-    ge_p3 id, part;
-    ge_identity(id);
-    part = toL ? acc : id;
-    wave_reduce_point(part, lds, l, 64);
-    if (l == 0) st_p3(A.P0 + b * 40, part);
-    part = toL ? id : acc;
-    wave_reduce_point(part, lds, l, 64);
-    if (l == 0) st_p3(A.P1 + b * 40, part);
-}
-
-// After challenge u_k of a tail round: fold a, b and update the 64 running coefficients (one block of 64 per proof).
-__global__ __launch_bounds__(64) void k_rp_tail_fold(RangeArgs A, int round) {
-    size_t b = blockIdx.x;
-    int l = threadIdx.x, isH = l >> 5, i = l & 31;
-    const ProofState& ps = A.st[b];
-    sc u = ps.u, ui = ps.u_inv;
-    int lgh = A.lgN - 1 - round, half = 1 << lgh;
-    bool upper = (i >> lgh) & 1;
-    sc s, t;
-    ld_sc(s, A.tailS + b * 64 + l);
-    sc_montmul(t, s, isH ? (upper ? ui : u) : (upper ? u : ui));
-    st_sc(A.tailS + b * 64 + l, t);
-    if (l < half) {
-        sc lo, hi, r;
-        ld_sc(lo, A.a + b * A.N + l);
-        ld_sc(hi, A.a + b * A.N + half + l);
-        sc_montmul(lo, lo, u);
-        sc_montmul(hi, hi, ui);
-        sc_add(r, lo, hi);
-        st_sc(A.a + b * A.N + l, r);
-        ld_sc(lo, A.b + b * A.N + l);
-        ld_sc(hi, A.b + b * A.N + half + l);
-        sc_montmul(lo, lo, ui);
-        sc_montmul(hi, hi, u);
-        sc_add(r, lo, hi);
-        st_sc(A.b + b * A.N + l, r);
-    }
 }
 
 // --------------------------------------------------------------------------------------- transcript helpers
@@ -660,7 +606,7 @@ __global__ __launch_bounds__(64) void k_rp_round_finish(RangeArgs A, TableView t
     sc_from_mont(c, t);
     tbl_fixed_mul_add(p, tbl, tbl.row_B(0), c);
     ge_compress(Rc, p);
-    uint32_t* out = A.out + b * A.out_words + 56 + 16 * round;
+    uint32_t* out = A.out + b * A.out_words + 56 + 16 * (A.out_round0 + round);
     st8(out, Lc);
     st8(out + 8, Rc);
     Strobe s;
@@ -716,7 +662,7 @@ __global__ __launch_bounds__(64) void k_rp_final(RangeArgs A, uint32_t* err_flag
     uint32_t c[8];
     ld_sc(a, A.a + b * A.N);
     ld_sc(bb, A.b + b * A.N);
-    uint32_t* out = A.out + b * A.out_words + 56 + 16 * A.lgN;
+    uint32_t* out = A.out + b * A.out_words + 56 + 16 * (A.out_round0 + A.lgN);
     sc_from_mont(c, a);
     st8(out, c);
     sc_from_mont(c, bb);

@@ -21,7 +21,7 @@ namespace dapol {
 // W = 10 the tables (273 MB -> 4.4 GB at 14 bits) no longer fit the Infinity Cache and the lookups become random
 // 128-byte HBM gathers (~3 TB/s).  With the final kernel: 96 / 91 / 102 ms at W = 16 / 17 / 19 -- 17 bits (15 windows,
 // 34.6 GB of tables for 32 parties) is the sweet spot; at 19 bits the 138 GB of tables cost more than the saved window.
-enum { TBL_ENTRY_WORDS = 32, WBITS_MIN = 8, WBITS_MAX = 20 };
+enum { TBL_ENTRY_WORDS = 32, WBITS_MIN = 8, WBITS_MAX = 20, WBITS_AUTO_MAX = 17 };
 typedef int32_t dig_t;       // digits of up to 20 bits (int16 would cap the width at 16)
 
 struct TableView {

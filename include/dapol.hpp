@@ -137,6 +137,24 @@ class Dapol {
                                pad_seed.data(), enforce_sparsity ? 1 : 0, &t));
         tree_.reset(t, [](dapol_tree* p) { dapol_tree_destroy(p); });
     }
+    // Dapol::update (mod.rs:211-213): inserts the liability at idx or replaces the one already there.  On a blank
+    // Dapol the first update creates the tree with pad_seed; later calls ignore pad_seed (a tree has one seed).
+    void update(uint64_t idx, uint64_t value, const Bytes32& blinding, const Bytes32& pad_seed = Bytes32{}) {
+        if (!tree_) return build({idx}, {value}, {blinding}, pad_seed);
+        check(dapol_tree_update(tree_.get(), 1, &idx, &value, blinding.data()));
+    }
+    // The batched form: k updates applied in order by one level-parallel rebuild.
+    void update(const std::vector<uint64_t>& idx, const std::vector<uint64_t>& values, const std::vector<Bytes32>& blindings,
+                const Bytes32& pad_seed = Bytes32{}) {
+        if (idx.size() != values.size() || idx.size() != blindings.size()) throw DapolError(DAPOL_ERR_INVALID_ARGUMENT);
+        if (idx.empty()) return;
+        if (!tree_) {
+            update(idx[0], values[0], blindings[0], pad_seed);
+            if (idx.size() > 1) check(dapol_tree_update(tree_.get(), idx.size() - 1, idx.data() + 1, values.data() + 1, blindings[1].data()));
+            return;
+        }
+        check(dapol_tree_update(tree_.get(), idx.size(), idx.data(), values.data(), blindings[0].data()));
+    }
     // Dapol::root_raw / Dapol::root (mod.rs:134-141)
     DapolNode root_raw() const {
         DapolNode n;

@@ -108,6 +108,12 @@ int32_t dapol_merge_batch(dapol_ctx* ctx, size_t n, const uint8_t* CL32, const u
                           const uint8_t* CR32, const uint8_t* HR32, const uint64_t* vR, const uint8_t* rR32, uint8_t* C32,
                           uint8_t* H32, uint64_t* v, uint8_t* r32);
 int32_t dapol_tree_destroy(dapol_tree* tree);
+/* Dapol::update (src/dapol/mod.rs:211-213 -> SparseMerkleTree::update), batched: the k leaves are applied in input
+ * order -- a leaf is inserted, or replaces the liability already at its index (the last of several updates of one
+ * index wins).  Afterwards the tree equals dapol_tree_build of the resulting leaf set bit for bit (padding nodes
+ * are keyed by position, so the reference test's build-vs-update root equality, src/tests.rs:48, holds exactly).
+ * Only for trees from dapol_tree_build / dapol_tree_build_shard.  On error the tree is unchanged. */
+int32_t dapol_tree_update(dapol_tree* tree, size_t k, const uint64_t* leaf_idx, const uint64_t* v, const uint8_t* r32);
 /* Dapol::root_raw / Dapol::root (src/dapol/mod.rs:134-141). Any out pointer may be NULL. */
 int32_t dapol_tree_root(dapol_tree* tree, uint8_t C32[32], uint8_t H32[32], uint64_t* v, uint8_t r32[32]);
 int32_t dapol_tree_node_count(dapol_tree* tree, uint64_t* real_nodes, uint64_t* padding_nodes);
