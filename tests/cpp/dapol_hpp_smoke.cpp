@@ -48,6 +48,15 @@ int main(int argc, char** argv) {
     } catch (const DapolError& e) {
         if (e.code != DAPOL_ERR_INVALID_ARGUMENT) { std::printf("FAIL code %d\n", e.code); return 1; }
     }
+    {   // src/tests.rs:41-48: a blank Dapol grown by update() has the same root as build()
+        Dapol u = Dapol::new_blank(ctx, height, height, Policy::Padding);
+        u.update(idx[2], vals[2], bl[2], seed);
+        u.update(idx[0], vals[0], bl[0]);
+        u.update(idx[1], 1, bl[0]);
+        u.update(idx[1], vals[1], bl[1]);                          // replaces
+        DapolNode ur = u.root_raw();
+        if (ur.com != root.com || ur.hash != root.hash || ur.get_value() != root.get_value()) { std::printf("FAIL update\n"); return 1; }
+    }
     std::printf("OK proof_bytes=%zu\n", proof->range_proofs.size());
     return 0;
 }

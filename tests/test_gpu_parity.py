@@ -226,6 +226,45 @@ def test_single_leaf_and_full_level(gpu_ctx, hip_lib, ref):
         ref.ref_tree_free(t)
 
 
+def test_update_equals_build(gpu_ctx, hip_lib, ref):
+    """src/tests.rs:41-48: a tree grown by update() has the root of build() over the same liabilities -- here bit for
+    bit, every level, because padding nodes are keyed by position.  Also: replacing a liability, the last of several
+    updates of one index winning, and the reference's one-leaf-at-a-time loop."""
+    rng = np.random.default_rng(77)
+    height, n = 10, 100                                     # the reference test's shape
+    idx, v, r = _rand_leaves(rng, height, n)
+    full = hip_lib.Tree(gpu_ctx, height, idx, v, r, SEED)
+    perm = rng.permutation(n)
+    first, rest = np.sort(perm[:40]), perm[40:]             # `rest` arrives unsorted
+    tr = hip_lib.Tree(gpu_ctx, height, idx[first], v[first], r[first], SEED)
+    tr.update(idx[rest], v[rest], r[rest])
+    assert tr.root() == full.root() and tr.node_count() == full.node_count()
+    for level in range(height + 1):
+        for a, b in zip(tr.level_nodes(level), full.level_nodes(level)):
+            assert np.array_equal(a, b)
+    one = hip_lib.Tree(gpu_ctx, height, idx[:1], v[:1], r[:1], SEED)
+    for i in range(1, 12):
+        one.update(idx[i:i + 1], v[i:i + 1], r[i:i + 1])
+    t = _ref_tree(ref, height, idx[:12], v[:12], r[:12])
+    assert one.root() == _ref_root(ref, t)
+    ref.ref_tree_free(t)
+    # replace: new value and blinding at an occupied index; a duplicate inside the batch -> the last one wins
+    v2, r2 = v.copy(), r.copy()
+    v2[5], r2[5] = 123456, r[6]
+    tr.update(np.array([idx[5], idx[5]], np.uint64), np.array([999, 123456], np.uint64), np.stack([r[7], r[6]]))
+    t = _ref_tree(ref, height, idx, v2, r2)
+    assert tr.root() == _ref_root(ref, t)
+    ref.ref_tree_free(t)
+    assert tr.root()[2] == int(v2.sum())
+    # errors leave the tree as it was: index beyond 2^height
+    before = tr.root()
+    with pytest.raises(hip_lib.DapolError):
+        tr.update(np.array([1 << height], np.uint64), np.array([1], np.uint64), r[:1])
+    assert tr.root() == before
+    C, H, pv, pr = tr.paths(idx[:3])                        # the updated tree serves proofs
+    assert C.shape == (3, height, 32)
+
+
 def test_value_sum_wraps_like_release_rust(gpu_ctx, hip_lib, ref):
     idx = np.array([0, 1], np.uint64)
     v = np.array([2**64 - 1, 5], np.uint64)
