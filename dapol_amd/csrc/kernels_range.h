@@ -41,18 +41,18 @@ struct RangeArgs {
     int nsplit;                         // MSM term-range splits per proof (0/1 = none); partial points at [b * nsplit + s]
     ProofState* st;                     // [B]
     int32_t* PA; int32_t* P0; int32_t* P1;   // [B][40] partial points
-    int32_t* tailT;                     // [B][64][TAIL_ENTRIES][32]  per-proof window tables of the materialised folded generators
-    sc* tail_a; sc* tail_b; sc* tail_s1; sc* tail_s2;   // [B][32] each: the vectors / coefficients of the tail argument
+    int tail_n;                         // T = length of the tail argument (32 / 64 / 128): 2T generators are materialised
+    int32_t* tailT;                     // [B][2T][TAIL_ENTRIES][32]  per-proof window tables of the materialised folded generators
+    sc* tail_a; sc* tail_b; sc* tail_s1; sc* tail_s2;   // [B][T] each: the vectors / coefficients of the tail argument
     uint32_t* out;                      // [B][out_words]
     int out_words;
     int out_round0;                     // rounds already written before this argument's round 0 (tail: lgN - 5)
 };
 
-// The tail of the hybrid inner-product argument is itself a never-fold argument of length 32
-// over the 64 materialised generators, served by a per-proof table of signed 4-bit windows in the same 128-byte
-// affine-niels format as the context tables.
-enum { TAIL_N = 32, TAIL_LGN = 5, TAIL_WBITS = 4, TAIL_NWIN = 253 / TAIL_WBITS + 1, TAIL_ENTRIES = (1 << (TAIL_WBITS - 1)) + 1,
-       TAIL_ROW_WORDS = TAIL_ENTRIES * 32, TAIL_TABLE_WORDS = 64 * TAIL_ROW_WORDS };
+// The tail of the hybrid inner-product argument is itself a never-fold argument of length T
+// over the 2T materialised generators, served by a per-proof table of signed 4-bit windows in the same 128-byte
+// affine-niels format as the context tables (rows G'_0..T-1, H'_0..T-1).
+enum { TAIL_WBITS = 4, TAIL_NWIN = 253 / TAIL_WBITS + 1, TAIL_ENTRIES = (1 << (TAIL_WBITS - 1)) + 1, TAIL_ROW_WORDS = TAIL_ENTRIES * 32 };
 enum { MSM_PLAIN = 0, MSM_MATERIALIZE = 1, MSM_TAIL = 2 };
 
 __device__ __forceinline__ void tape_wide(uint32_t* w16, const RangeArgs& A, size_t b, uint32_t slot) {
@@ -197,8 +197,8 @@ __global__ __launch_bounds__(64, 3) void k_rp_msm(RangeArgs A, TableView tbl, in
     // LPL = lanes per list.  32: one proof per wavefront (64 terms per lane at N = 2048).  16 / 8: two / four proofs per
     // wavefront with 128 / 256 terms per lane, which amortises the W * nwin shared doublings (22 % of the instructions
     // at LPL = 32) over more mixed adds.  The digit layout is the same for every LPL.
-    // MODE: MSM_PLAIN -> P0 / P1;  MSM_MATERIALIZE -> the 64 per-lane sums are kept (folded generators);  MSM_TAIL ->
-    // the table is the PROOF's own (64 rows at tbl.base + b * TAIL_TABLE_WORDS), rows = G'_0..31, H'_0..31.
+    // MODE: MSM_PLAIN -> P0 / P1;  MSM_MATERIALIZE -> the 64 per-lane sums are kept (folded generators; T / 32 blocks
+    // per proof, block c taking every (T/32)-th term);  MSM_TAIL -> the table is the PROOF's own (2N rows).
     __shared__ int32_t lds[40 * 64];
     constexpr int PPW = 32 / LPL;
     int l = threadIdx.x;
@@ -208,11 +208,20 @@ __global__ __launch_bounds__(64, 3) void k_rp_msm(RangeArgs A, TableView tbl, in
     const int nsplit = A.nsplit > 1 ? A.nsplit : 1;
     const int split = (int)(blockIdx.x % nsplit);
     size_t b = (size_t)(blockIdx.x / nsplit) * PPW + sub;
-    bool valid = b < A.B;
-    if (!valid) b = A.B - 1;
-    if constexpr (MODE == MSM_TAIL) tbl.base += b * (size_t)TAIL_TABLE_WORDS;
     int niter_all = (A.N + LPL - 1) / LPL;
     int i_begin = (int)((long long)niter_all * split / nsplit), niter = (int)((long long)niter_all * (split + 1) / nsplit);
+    int i_step = 1;
+    if constexpr (MODE == MSM_MATERIALIZE) {
+        // Folded generator i of the length-T argument collects the original generators j = i (mod T).  Lane ql owns
+        // the terms 32 * i + ql, so the class of term i is ql + 32 * (i mod K), K = T / 32: block c walks i = c (mod K).
+        i_step = A.tail_n >> 5;
+        b = blockIdx.x / i_step;
+        i_begin = (int)(blockIdx.x % i_step);
+        niter = niter_all;
+    }
+    bool valid = b < A.B;
+    if (!valid) b = A.B - 1;
+    if constexpr (MODE == MSM_TAIL) tbl.base += b * (size_t)(2 * A.N) * TAIL_ROW_WORDS;
     const dig_t* dig = A.dig + b * A.nwin * (size_t)A.TP + 32 * side;
     const int NW = A.nwin, W = A.wbits;
     ge_p3 acc;
@@ -226,25 +235,26 @@ __global__ __launch_bounds__(64, 3) void k_rp_msm(RangeArgs A, TableView tbl, in
             for (int d = 0; d < W; d++) ge_dbl(acc, acc, d == W - 1);
         }
         const dig_t* dw = dig + (size_t)w * A.TP;
-        for (int i = i_begin; i < niter; i++) {
+        for (int i = i_begin; i < niter; i += i_step) {
             int q = LPL * i + ql;
             if (q < A.N) {
                 int d = dw[64 * (q >> 5) + (q & 31)];
                 bool isH;
                 int j = term_generator(round, A.N, A.lgN, side, q, isH);
                 int row;
-                if constexpr (MODE == MSM_TAIL) row = j + (isH ? TAIL_N : 0);
+                if constexpr (MODE == MSM_TAIL) row = j + (isH ? A.N : 0);
                 else row = gen_row(tbl, A.n, j, isH);
                 tbl_madd(acc, tbl, row, d);
             }
         }
     }
     if constexpr (MODE == MSM_MATERIALIZE) {
-        // Hybrid IPA: with the S-layout lane l owns exactly the generators j = l mod 32 (mod 32), so fed with the
-        // s-vector digits its accumulator IS the folded generator G'_(l&31) (lanes 0-31) / H'_(l&31) (lanes 32-63) of
-        // the round whose vectors have length 32.  Keep it at the head of its table row (k_rp_tail_table builds the row).
+        // Hybrid IPA: fed with the s-vector digits the lane's accumulator IS the folded generator G'_i (lanes 0-31) /
+        // H'_i (lanes 32-63), i = ql + 32 c, of the round whose vectors have length T.  Keep it at the head of its table
+        // row (k_rp_tail_table builds the row).
         static_assert(MODE != MSM_MATERIALIZE || LPL == 32, "materialisation needs one proof per wavefront");
-        st_p3(A.tailT + b * (size_t)TAIL_TABLE_WORDS + (size_t)l * TAIL_ROW_WORDS, acc);
+        const int T = A.tail_n;
+        st_p3(A.tailT + (b * (size_t)(2 * T) + (size_t)(side * T + ql + 32 * i_begin)) * TAIL_ROW_WORDS, acc);
     } else {
         wave_reduce_point(acc, lds, l, LPL);
         if (ql == 0 && valid) st_p3((side ? A.P1 : A.P0) + (b * nsplit + split) * 40, acc);
@@ -253,11 +263,12 @@ __global__ __launch_bounds__(64, 3) void k_rp_msm(RangeArgs A, TableView tbl, in
 
 // One lane per materialised generator P: its table row 0*P .. 8*P in affine niels form (one inversion per row by
 // Montgomery's trick; the projective multiples wait in the row's own entry slots), and the tail argument's vectors:
-// a, b = the first 32 entries of the folded vectors, coefficients s = 1.
+// a, b = the first T entries of the folded vectors, coefficients s = 1.
 __global__ __launch_bounds__(64) void k_rp_tail_table(RangeArgs A) {
-    size_t b = blockIdx.x;
-    int l = threadIdx.x;
-    int32_t* row = A.tailT + b * (size_t)TAIL_TABLE_WORDS + (size_t)l * TAIL_ROW_WORDS;
+    const int T = A.tail_n, bpp = (2 * T) >> 6;                  // blocks per proof
+    size_t b = blockIdx.x / bpp;
+    int g = (int)(blockIdx.x % bpp) * 64 + threadIdx.x;          // row: G'_g (g < T) or H'_(g-T)
+    int32_t* row = A.tailT + (b * (size_t)(2 * T) + g) * TAIL_ROW_WORDS;
     ge_p3 base, mul;
     ld_p3(base, row);
     mul = base;
@@ -292,10 +303,10 @@ __global__ __launch_bounds__(64) void k_rp_tail_table(RangeArgs A) {
     row[30] = 0; row[31] = 0;
     sc one, v;
     sc_one_mont(one);
-    int i = l & 31;
-    st_sc((l < 32 ? A.tail_s1 : A.tail_s2) + b * TAIL_N + i, one);
-    ld_sc(v, (l < 32 ? A.a : A.b) + b * A.N + i);
-    st_sc((l < 32 ? A.tail_a : A.tail_b) + b * TAIL_N + i, v);
+    int i = g < T ? g : g - T;
+    st_sc((g < T ? A.tail_s1 : A.tail_s2) + b * T + i, one);
+    ld_sc(v, (g < T ? A.a : A.b) + b * A.N + i);
+    st_sc((g < T ? A.tail_a : A.tail_b) + b * T + i, v);
 }
 
 // Digits of the s-vectors themselves, in the S layout (list 0 = s_G over G, list 1 = s_H over H): input of the
