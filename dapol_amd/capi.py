@@ -56,6 +56,10 @@ _SIG = {
     "dapol_range_proofs_deserialize": (ctypes.c_int32, [ctypes.c_int32, ctypes.c_int32, _P, ctypes.c_size_t, _P, ctypes.c_size_t, _P, _P, _P, _P]),
     "dapol_verify_entities": (ctypes.c_int32, [_P, ctypes.c_int32, ctypes.c_size_t, _P, _P, _P, _P, _P, _P, _P, ctypes.c_int32, ctypes.c_int32,
                                                ctypes.c_int32, _P, _P, _P]),
+    "dapol_batch_siblings": (ctypes.c_int32, [ctypes.c_int32, ctypes.c_size_t, _P, _P, _P, _P]),
+    "dapol_prove_batch": (ctypes.c_int32, [_P, _P, ctypes.c_size_t, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P, _P, _P, _P]),
+    "dapol_verify_batch": (ctypes.c_int32, [_P, ctypes.c_int32, ctypes.c_size_t, _P, _P, _P, ctypes.c_size_t, _P, _P, _P, _P, ctypes.c_int32,
+                                            ctypes.c_int32, ctypes.c_int32, _P, _P, _P]),
     "dapol_entity_proof_size": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     "dapol_prove_entities_upper": (ctypes.c_int32, [_P, _P, ctypes.c_size_t, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P, ctypes.c_int32,
                                                     _P, _P, _P, _P, _P, _P, _P]),
@@ -227,6 +231,21 @@ class Context:
                                          aggregation_factor, n_bits, _ptr(rp), _ptr(seed), _ptr(ok)))
         return ok
 
+    def verify_batch(self, height, leaf_idx, leaf_C, leaf_H, sib_C, sib_H, root_C, root_H, policy, aggregation_factor, n_bits, range_proofs,
+                     verify_seed=bytes(32)):
+        """DapolProof::verify_batch: one proof covering k leaves."""
+        leaf_idx = _u64(leaf_idx)
+        k = leaf_idx.shape[0]
+        lC, lH = _u8(leaf_C, k, 32), _u8(leaf_H, k, 32)
+        sC, sH = _u8(sib_C).reshape(-1, 32), _u8(sib_H).reshape(-1, 32)
+        rp = _u8(np.frombuffer(bytes(range_proofs), np.uint8))
+        rC, rH = _u8(np.frombuffer(root_C, np.uint8)), _u8(np.frombuffer(root_H, np.uint8))
+        seed = _u8(np.frombuffer(verify_seed, np.uint8))
+        ok = np.zeros(1, np.uint8)
+        _chk(lib().dapol_verify_batch(self.h, height, k, _ptr(leaf_idx), _ptr(lC), _ptr(lH), sC.shape[0], _ptr(sC), _ptr(sH), _ptr(rC), _ptr(rH),
+                                      policy, aggregation_factor, n_bits, _ptr(rp), _ptr(seed), _ptr(ok)))
+        return bool(ok[0])
+
     def range_verify_batch(self, n_bits, m, proofs, V32, verify_seed=bytes(32)):
         proofs = _u8(proofs)
         b = proofs.shape[0]
@@ -235,6 +254,16 @@ class Context:
         seed = _u8(np.frombuffer(verify_seed, np.uint8))
         _chk(lib().dapol_range_verify_batch(self.h, n_bits, m, b, _ptr(proofs), _ptr(V32), _ptr(seed), _ptr(ok)))
         return ok
+
+
+def batch_siblings(height, leaf_idx):
+    """Positions (level, index) of the siblings of a batched Merkle proof, in proof order (host-only)."""
+    leaf_idx = _u64(leaf_idx)
+    n = ctypes.c_size_t(0)
+    _chk(lib().dapol_batch_siblings(height, leaf_idx.shape[0], _ptr(leaf_idx), ctypes.byref(n), None, None))
+    level, index = np.zeros(n.value, np.uint8), np.zeros(n.value, np.uint64)
+    _chk(lib().dapol_batch_siblings(height, leaf_idx.shape[0], _ptr(leaf_idx), ctypes.byref(n), _ptr(level), _ptr(index)))
+    return level, index
 
 
 class Tree:
@@ -297,6 +326,22 @@ class Tree:
         v = np.zeros((b, h), np.uint64)
         _chk(lib().dapol_tree_paths(self.h, b, _ptr(leaf_idx), _ptr(C), _ptr(H), _ptr(v), _ptr(r)))
         return C, H, v, r
+
+    def prove_batch(self, leaf_idx, policy, aggregation_factor, n_bits, nonce_seed):
+        """Dapol::generate_proof_batch: one proof for all the leaves.  Returns (sib_level, sib_index, sib_C, sib_H, range blob)."""
+        leaf_idx = _u64(leaf_idx)
+        k = leaf_idx.shape[0]
+        level, index = batch_siblings(self.height, leaf_idx)
+        S = level.shape[0]
+        es = lib().dapol_entity_proof_size(S, policy, aggregation_factor, n_bits)
+        if es == 0:
+            raise DapolError(8, "bad policy / aggregation_factor / n_bits")
+        C, H = np.zeros((S, 32), np.uint8), np.zeros((S, 32), np.uint8)
+        out = np.zeros(es, np.uint8)
+        seed = _u8(np.frombuffer(nonce_seed, np.uint8))
+        _chk(lib().dapol_prove_batch(self.ctx.h, self.h, k, _ptr(leaf_idx), policy, aggregation_factor, n_bits, _ptr(seed), _ptr(C), _ptr(H),
+                                     _ptr(out)))
+        return level, index, C, H, out.tobytes()
 
     def prove_entities(self, leaf_idx, policy, aggregation_factor, n_bits, nonce_seed, upper=None):
         """upper = (C[u,32], H[u,32], v[u], r[u,32]) siblings above a shard root, root side first."""

@@ -607,3 +607,4 @@ int32_t dapol_tree_paths(dapol_tree* tree, size_t b, const uint64_t* leaf_idx, u
 #include "host_range.inc"
 #include "host_leaf.inc"
 #include "host_wire.inc"
+#include "host_batch.inc"

@@ -115,6 +115,28 @@ struct DapolProof {
     std::vector<DapolProofNode> merkle_siblings;
     std::vector<uint8_t> range_proofs;           // aggregated proofs then individual proofs, concatenated
 };
+// DapolProof<D, R> made by generate_proof_batch: MerkleProof::new_batch(leaf indexes) + the deduplicated siblings
+// (level by level from the root side, left to right) + the range proofs over exactly those siblings.
+struct DapolBatchProof {
+    std::vector<uint64_t> leaf_indexes;
+    std::vector<DapolProofNode> merkle_siblings;
+    std::vector<uint8_t> range_proofs;
+    Policy policy = Policy::Padding;
+    size_t aggregation_factor = 0;
+    int n_bits = 64, height = 0;
+    // DapolProof::verify_batch (src/proof/mod.rs:49-54)
+    bool verify_batch(const Context& ctx, const DapolProofNode& root, const std::vector<DapolProofNode>& leaves, const Bytes32& verify_seed) const {
+        if (leaves.size() != leaf_indexes.size()) return false;
+        size_t k = leaves.size(), S = merkle_siblings.size();
+        std::vector<uint8_t> lC(k * 32), lH(k * 32), sC(S * 32 + 1), sH(S * 32 + 1);
+        for (size_t i = 0; i < k; i++) { std::memcpy(&lC[i * 32], leaves[i].com.data(), 32); std::memcpy(&lH[i * 32], leaves[i].hash.data(), 32); }
+        for (size_t i = 0; i < S; i++) { std::memcpy(&sC[i * 32], merkle_siblings[i].com.data(), 32); std::memcpy(&sH[i * 32], merkle_siblings[i].hash.data(), 32); }
+        uint8_t ok = 0;
+        check(dapol_verify_batch(ctx.get(), height, k, leaf_indexes.data(), lC.data(), lH.data(), S, sC.data(), sH.data(), root.com.data(),
+                                 root.hash.data(), (int)policy, (int)aggregation_factor, n_bits, range_proofs.data(), verify_seed.data(), &ok));
+        return ok != 0;
+    }
+};
 
 // Dapol<D, R> (src/dapol/mod.rs:78-83)
 class Dapol {
@@ -167,6 +189,29 @@ class Dapol {
         auto v = generate_proofs({leaf_idx}, nonce_seed, n_bits);
         if (!v) return std::nullopt;
         return std::move((*v)[0]);
+    }
+    // Dapol::generate_proof_batch (mod.rs:172-190): ONE proof for all the leaves (strictly increasing indexes); None
+    // when there is no liability at one of them.
+    std::optional<DapolBatchProof> generate_proof_batch(const std::vector<uint64_t>& leaves, const Bytes32& nonce_seed, int n_bits = 64) const {
+        size_t S = 0;
+        check(dapol_batch_siblings(height_, leaves.size(), leaves.data(), &S, nullptr, nullptr));
+        size_t es = dapol_entity_proof_size((int)S, (int)policy_, (int)aggregation_factor_, n_bits);
+        if (es == 0) throw DapolError(DAPOL_ERR_INVALID_ARGUMENT);
+        std::vector<uint8_t> C(S * 32 + 1), H(S * 32 + 1);
+        DapolBatchProof out;
+        out.range_proofs.resize(es);
+        int32_t rc = dapol_prove_batch(ctx_->get(), tree_.get(), leaves.size(), leaves.data(), (int)policy_, (int)aggregation_factor_, n_bits,
+                                       nonce_seed.data(), C.data(), H.data(), out.range_proofs.data());
+        if (rc == DAPOL_ERR_UNKNOWN_LEAF) return std::nullopt;
+        check(rc);
+        out.leaf_indexes = leaves;
+        out.merkle_siblings.resize(S);
+        for (size_t s = 0; s < S; s++) {
+            std::memcpy(out.merkle_siblings[s].com.data(), &C[s * 32], 32);
+            std::memcpy(out.merkle_siblings[s].hash.data(), &H[s * 32], 32);
+        }
+        out.policy = policy_; out.aggregation_factor = aggregation_factor_; out.n_bits = n_bits; out.height = height_;
+        return out;
     }
     // Many single-leaf proofs in one GPU batch (the throughput path).
     std::optional<std::vector<DapolProof>> generate_proofs(const std::vector<uint64_t>& leaves, const Bytes32& nonce_seed, int n_bits = 64) const {

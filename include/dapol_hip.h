@@ -182,6 +182,30 @@ int32_t dapol_verify_entities(dapol_ctx* ctx, int32_t height, size_t b, const ui
                               const uint8_t root_H32[32], int32_t policy, int32_t aggregation_factor, int32_t n_bits,
                               const uint8_t* range_proofs, const uint8_t verify_seed32[32], uint8_t* ok);
 
+/* Batched inclusion proofs -- Dapol::generate_proof_batch for k >= 1 leaves (src/dapol/mod.rs:172-190) and
+ * DapolProof::verify_batch (src/proof/mod.rs:49-54): ONE proof for all k leaves = the deduplicated siblings of the
+ * batched Merkle paths + one R::generate_proof over exactly those siblings (values / blindings in sibling order).
+ * leaf_idx must be strictly increasing.  Sibling order: level by level from the root side, left to right within a
+ * level (for k = 1 this is dapol_tree_paths' order; smtree's own order is not pinned by the reference repository).
+ *
+ * dapol_batch_siblings: number of siblings and, optionally, their positions (sib_level: 0 = leaf level; sib_index:
+ * node index within its level).  Pure index arithmetic -- no GPU, no tree.
+ * dapol_prove_batch: sib_C32 / sib_H32: [n_siblings][32] (may be NULL); range_out:
+ * dapol_entity_proof_size(n_siblings, policy, aggregation_factor, n_bits) bytes in dapol_prove_entities' blob layout.
+ * aggregation_factor > n_siblings -> DAPOL_ERR_INVALID_ARGUMENT (the reference panics, src/range/padding.rs:95-98).
+ * For k > 1 the nonce stream is keyed by the seed chained through the leaf list, so a batch never shares nonces with
+ * a single-leaf proof made from the same seed; k = 1 gives exactly dapol_prove_entities' bytes.
+ * dapol_verify_batch: *ok = 1 iff the leaves and siblings re-merge to the root and R::verify accepts. */
+int32_t dapol_batch_siblings(int32_t height, size_t k, const uint64_t* leaf_idx, size_t* n_siblings, uint8_t* sib_level,
+                             uint64_t* sib_index);
+int32_t dapol_prove_batch(dapol_ctx* ctx, dapol_tree* tree, size_t k, const uint64_t* leaf_idx, int32_t policy,
+                          int32_t aggregation_factor, int32_t n_bits, const uint8_t nonce_seed32[32], uint8_t* sib_C32,
+                          uint8_t* sib_H32, uint8_t* range_out);
+int32_t dapol_verify_batch(dapol_ctx* ctx, int32_t height, size_t k, const uint64_t* leaf_idx, const uint8_t* leaf_C32,
+                           const uint8_t* leaf_H32, size_t n_siblings, const uint8_t* sib_C32, const uint8_t* sib_H32,
+                           const uint8_t root_C32[32], const uint8_t root_H32[32], int32_t policy, int32_t aggregation_factor,
+                           int32_t n_bits, const uint8_t* range_proofs, const uint8_t verify_seed32[32], uint8_t* ok);
+
 /* Bench / roofline support: device-resident variant of build + prove-all used by bench.py so that the timed
  * region starts with inputs already in HBM and nothing is copied back.  Handles are opaque device buffers. */
 typedef struct dapol_workload dapol_workload;

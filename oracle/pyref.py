@@ -976,6 +976,68 @@ def dapol_new(liabilities, audit_seed, height, pad_seed, dg="blake3"):
     return Tree(height, leaves, pad_seed, dg), id_map
 
 
+def batch_siblings(height, leaf_idxs):
+    """Positions [(level, index)] of the siblings of a batched Merkle proof (smtree MerkleProof::new_batch): level by
+    level from the root side, left to right within a level (UNPINNED -- smtree's order is not fixed by the reference
+    repository; for one leaf this is path_siblings' order).  level 0 = leaves."""
+    assert list(leaf_idxs) == sorted(set(leaf_idxs)) and leaf_idxs
+    out = []
+    for level in range(height - 1, -1, -1):
+        anc = sorted({i >> level for i in leaf_idxs})
+        out += [(level, x ^ 1) for x in anc if (x ^ 1) not in anc]
+    return out
+
+
+def batch_nonce_seed(nonce_seed, leaf_idxs):
+    """Seed of a batch's nonce stream: the caller's seed chained through the leaf list (domain 4)."""
+    s = nonce_seed
+    for i, leaf in enumerate(leaf_idxs):
+        s = seed_wide(s, 4, leaf, i)[:32]
+    return s
+
+
+def dapol_prove_batch(tree, leaf_idxs, policy, agg, nonce_seed, n=BIT_SIZE):
+    """Dapol::generate_proof_batch (mod.rs:172-190): (sibling positions, siblings, aggregated, individual)."""
+    if any(i not in tree.levels[0] or i in tree.pad[0] for i in leaf_idxs):
+        return None
+    pos = batch_siblings(tree.height, leaf_idxs)
+    sibs = [tree.levels[level][index] for level, index in pos]
+    seed = nonce_seed if len(leaf_idxs) == 1 else batch_nonce_seed(nonce_seed, leaf_idxs)
+    tape = Tape(seed=seed, domain=DOMAIN_NONCE, stream_id=leaf_idxs[0])
+    aggregated, individual = policy_prove(policy, [s.v for s in sibs], [s.r for s in sibs], agg, tape, n)
+    return pos, sibs, aggregated, individual
+
+
+def verify_batch_paths(root_C, root_H, height, leaves, siblings, dg="blake3"):
+    """MerkleProof::verify_batch restated.  leaves: [(idx, C, H)] sorted; siblings: [(C, H)] in batch_siblings order."""
+    pos = batch_siblings(height, [i for i, _, _ in leaves])
+    if len(pos) != len(siblings):
+        return False
+    cur = {}
+    for i, C, Hh in leaves:
+        pt = decompress(C)
+        if pt is None:
+            return False
+        cur[i] = (pt, C, Hh)
+    sib_at = {}
+    for (level, index), (C, Hh) in zip(pos, siblings):
+        pt = decompress(C)
+        if pt is None:
+            return False
+        sib_at[(level, index)] = (pt, C, Hh)
+    for level in range(height):
+        nxt = {}
+        for x in sorted(cur):
+            if (x >> 1) in nxt:
+                continue
+            other = cur.get(x ^ 1) or sib_at[(level, x ^ 1)]
+            l, r = (cur[x], other) if not x & 1 else (other, cur[x])
+            pt = l[0] + r[0]
+            nxt[x >> 1] = (pt, pt.compress(), digest(dg, l[1], r[1], l[2], r[2]))
+        cur = nxt
+    return cur[0][1] == root_C and cur[0][2] == root_H
+
+
 def dapol_prove(tree, leaf_idx, policy, agg, nonce_seed, n=BIT_SIZE):
     """Dapol::generate_proof (mod.rs:167-190) for one leaf: (siblings, aggregated, individual)."""
     sibs = tree.path_siblings(leaf_idx)

@@ -57,6 +57,17 @@ int main(int argc, char** argv) {
         DapolNode ur = u.root_raw();
         if (ur.com != root.com || ur.hash != root.hash || ur.get_value() != root.get_value()) { std::printf("FAIL update\n"); return 1; }
     }
+    {   // src/tests.rs:50-70: one proof for a batch of leaves verifies against root and leaves
+        Dapol bd = Dapol::new_blank(ctx, height, 2, Policy::Splitting);
+        bd.build(idx, vals, bl, seed);
+        auto bp = bd.generate_proof_batch({3, 40}, seed, 8);
+        if (!bp || bp->merkle_siblings.empty()) { std::printf("FAIL batch\n"); return 1; }
+        std::vector<DapolProofNode> lv = {ctx->node_new(5, bl[0]).get_proof_node(), ctx->node_new(11, bl[2]).get_proof_node()};
+        if (!bp->verify_batch(*ctx, bd.root(), lv, seed)) { std::printf("FAIL batch verify\n"); return 1; }
+        std::swap(lv[0], lv[1]);
+        if (bp->verify_batch(*ctx, bd.root(), lv, seed)) { std::printf("FAIL batch verify accepted swapped leaves\n"); return 1; }
+        if (bd.generate_proof_batch({3, 41}, seed, 8)) { std::printf("FAIL batch none\n"); return 1; }
+    }
     std::printf("OK proof_bytes=%zu\n", proof->range_proofs.size());
     return 0;
 }

@@ -79,3 +79,24 @@ def test_wire_format_matches_reference_layout(hip_lib, pyref):
     lib = hip_lib.lib()
     assert lib.dapol_range_proofs_wire_size(32, 0, 32, 64) == 8 + 992 + 8
     assert lib.dapol_range_proofs_wire_size(32, 1, 24, 64) == 2 + (8 + 928) + (8 + 864) + 8 + 8 * 672
+
+
+def test_batch_sibling_plan_is_host_only_and_matches_oracle(hip_lib, pyref):
+    """Positions of the siblings of a batched Merkle proof (generate_proof_batch, src/dapol/mod.rs:172-190): index
+    arithmetic only, so it runs without a GPU; checked against the Python restatement, heights up to 64."""
+    import numpy as np
+    import pytest
+    rng = np.random.default_rng(11)
+    for height, k in [(1, 1), (1, 2), (3, 8), (6, 4), (10, 10), (16, 40), (33, 7), (64, 9), (64, 1)]:
+        hi = (1 << height) if height < 64 else (1 << 64)
+        leaves = sorted({int(x) % hi for x in rng.integers(0, 2**63, size=k, dtype=np.uint64) * 2 + rng.integers(0, 2, size=k, dtype=np.uint64)})
+        if height <= 3:
+            leaves = list(range(min(k, 1 << height)))
+        level, index = hip_lib.batch_siblings(height, leaves)
+        assert list(zip(map(int, level), map(int, index))) == pyref.batch_siblings(height, leaves)
+        assert len(level) <= len(leaves) * height
+    assert len(hip_lib.batch_siblings(5, [7])[0]) == 5                       # one leaf: its whole path
+    for bad in ([2, 1], [3, 3], [32], []):
+        with pytest.raises(hip_lib.DapolError) as e:
+            hip_lib.batch_siblings(5, bad)
+        assert e.value.code == 8

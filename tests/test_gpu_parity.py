@@ -517,6 +517,81 @@ def test_prove_then_verify_entities(gpu_ctx, hip_lib, height, policy, agg):
     assert okp[:4].all() and okp[6:].all()
 
 
+@pytest.mark.parametrize("height,policy,agg,pick", [(6, 0, 4, [0, 2, 3]), (7, 1, 7, [1, 4]), (5, 0, 0, [0, 1, 2, 3, 4]), (8, 1, 3, [2]), (6, 0, None, [0, 4])])
+def test_batch_proofs_vs_python_oracle(gpu_ctx, hip_lib, pyref, height, policy, agg, pick):
+    """Dapol::generate_proof_batch for several leaves (src/dapol/mod.rs:172-190): deduplicated siblings and one policy
+    proof over them, byte for byte against the Python restatement; agg = None -> aggregate every sibling."""
+    rng = np.random.default_rng(height * 7 + len(pick))
+    idx, v, r = _rand_leaves(rng, height, 5, vmax=8)
+    tr = hip_lib.Tree(gpu_ctx, height, idx, v, r, SEED)
+    leaves = [(int(i), pyref.node_new(int(vv), int.from_bytes(rr.tobytes(), "little"))) for i, vv, rr in zip(idx, v, r)]
+    pt = pyref.Tree(height, leaves, SEED)
+    name = "padding" if policy == 0 else "splitting"
+    sel = [int(idx[i]) for i in pick]
+    pos = pyref.batch_siblings(height, sel)
+    if agg is None:
+        agg = len(pos)
+    level, index, sC, sH, blob = tr.prove_batch(sel, policy, agg, 8, SEED)
+    assert list(zip(map(int, level), map(int, index))) == pos
+    _, sibs, aggregated, individual = pyref.dapol_prove_batch(pt, sel, name, agg, SEED, n=8)
+    assert [c.tobytes() for c in sC] == [x.C for x in sibs] and [h.tobytes() for h in sH] == [x.H for x in sibs]
+    assert blob == b"".join(aggregated) + b"".join(individual)
+    lv = [(i, pt.levels[0][i].C, pt.levels[0][i].H) for i in sel]
+    assert pyref.verify_batch_paths(pt.root.C, pt.root.H, height, lv, [(x.C, x.H) for x in sibs])
+    assert pyref.policy_verify(name, aggregated, individual, [x.C for x in sibs], n=8)
+    if len(sel) == 1:                                                      # k = 1 is exactly generate_proof
+        pC, pH, out = tr.prove_entities(sel, policy, agg, 8, SEED)
+        assert out[0].tobytes() == blob and pC[0].tobytes() == sC.tobytes()
+
+
+@pytest.mark.parametrize("policy", [0, 1])
+def test_batch_prove_then_verify(gpu_ctx, hip_lib, policy):
+    """src/tests.rs:50-70: batches of 10 of the 100 leaves of a height-10 tree verify against the root; tampering fails.
+    16-bit proofs: an upper sibling holds the sum of up to 100 liabilities below 200."""
+    rng = np.random.default_rng(5 + policy)
+    height, n = 10, 100
+    idx, v, r = _rand_leaves(rng, height, n, vmax=200)
+    tr = hip_lib.Tree(gpu_ctx, height, idx, v, r, SEED)
+    rC, rH, _, _ = tr.root()
+    lC, lH = gpu_ctx.commit_hash_batch(v, r)
+    for i in (0, 3, 9):
+        sl = slice(10 * i, 10 * i + 10)
+        S = len(hip_lib.batch_siblings(height, idx[sl])[0])
+        agg = min(S, 5 + i)
+        level, index, sC, sH, blob = tr.prove_batch(idx[sl], policy, agg, 16, SEED)
+        assert len(level) == S and len(blob) == hip_lib.lib().dapol_entity_proof_size(S, policy, agg, 16)
+        args = (policy, agg, 16, blob)
+        assert gpu_ctx.verify_batch(height, idx[sl], lC[sl], lH[sl], sC, sH, rC, rH, *args, verify_seed=SEED)
+        bad = sC.copy(); bad[S // 2] = sC[(S // 2 + 1) % S]
+        assert not gpu_ctx.verify_batch(height, idx[sl], lC[sl], lH[sl], bad, sH, rC, rH, *args, verify_seed=SEED)
+        bad = sH.copy(); bad[0, 0] ^= 1
+        assert not gpu_ctx.verify_batch(height, idx[sl], lC[sl], lH[sl], sC, bad, rC, rH, *args, verify_seed=SEED)
+        bad = bytearray(blob); bad[40] ^= 1
+        assert not gpu_ctx.verify_batch(height, idx[sl], lC[sl], lH[sl], sC, sH, rC, rH, policy, agg, 16, bytes(bad), verify_seed=SEED)
+        wl = lC[sl].copy(); wl[1] = wl[2]
+        assert not gpu_ctx.verify_batch(height, idx[sl], wl, lH[sl], sC, sH, rC, rH, *args, verify_seed=SEED)
+        assert not gpu_ctx.verify_batch(height, idx[sl], lC[sl], lH[sl], sC[:-1], sH[:-1], rC, rH, *args, verify_seed=SEED)   # a sibling short
+        other = idx[sl].copy(); other[-1] = idx[(10 * i + 10) % n] if i < 9 else idx[0]
+        other = np.sort(other)
+        if len(hip_lib.batch_siblings(height, other)[0]) == S:                # same shape, different leaf set
+            assert not gpu_ctx.verify_batch(height, other, lC[sl], lH[sl], sC, sH, rC, rH, *args, verify_seed=SEED)
+    E = hip_lib.DapolError
+    with pytest.raises(E) as e:
+        tr.prove_batch(idx[[3, 2]], policy, 1, 16, SEED)                       # unsorted leaf list
+    assert e.value.code == 8
+    with pytest.raises(E) as e:
+        free = next(i for i in range(1 << height) if i not in set(map(int, idx)))
+        tr.prove_batch(np.sort(np.array([int(idx[0]), free], np.uint64)), policy, 1, 16, SEED)   # no liability there -> None
+    assert e.value.code == 9
+    with pytest.raises(E) as e:
+        tr.prove_batch(idx[:2], policy, 10**6, 16, SEED)                       # aggregation_factor > #siblings: reference panics
+    assert e.value.code == 8
+    # nonce hygiene: a batch and the single-leaf proof of its first leaf draw from different streams
+    _, _, _, _, b2 = tr.prove_batch(idx[:2], policy, 0, 16, SEED)
+    _, _, _, _, b1 = tr.prove_batch(idx[:1], policy, 0, 16, SEED)
+    assert b2[:64] != b1[:64]
+
+
 def test_full_size_roundtrip_config1(gpu_ctx, hip_lib):
     """BASELINE configs[0] shape: 2^10 entities, height 16, 64-bit proofs -- every inclusion proof verifies (encode -> verify)."""
     height, n = 16, 1 << 10
