@@ -50,9 +50,12 @@ struct RangeArgs {
 };
 
 // The tail of the hybrid inner-product argument is itself a never-fold argument of length T
-// over the 2T materialised generators, served by a per-proof table of signed 4-bit windows in the same 128-byte
+// over the 2T materialised generators, served by a per-proof table of signed 5-bit windows in the same 128-byte
 // affine-niels format as the context tables (rows G'_0..T-1, H'_0..T-1).
-enum { TAIL_WBITS = 4, TAIL_NWIN = 253 / TAIL_WBITS + 1, TAIL_ENTRIES = (1 << (TAIL_WBITS - 1)) + 1, TAIL_ROW_WORDS = TAIL_ENTRIES * 32 };
+#ifndef DAPOL_TAIL_WBITS
+#define DAPOL_TAIL_WBITS 5        // measured 4 vs 5 bits at 2^20 proofs: 39.5K vs 40.5K entities/s (profiles/r01_tail_wbits_ab.txt)
+#endif
+enum { TAIL_WBITS = DAPOL_TAIL_WBITS, TAIL_NWIN = 253 / TAIL_WBITS + 1, TAIL_ENTRIES = (1 << (TAIL_WBITS - 1)) + 1, TAIL_ROW_WORDS = TAIL_ENTRIES * 32 };
 enum { MSM_PLAIN = 0, MSM_MATERIALIZE = 1, MSM_TAIL = 2 };
 
 __device__ __forceinline__ void tape_wide(uint32_t* w16, const RangeArgs& A, size_t b, uint32_t slot) {
