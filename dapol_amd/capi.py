@@ -140,9 +140,10 @@ def range_proofs_deserialize(policy, n_bits, wire):
 class Context:
     """dapol_ctx: generators + window tables on one GPU."""
 
-    def __init__(self, device=0, max_parties=32):
+    def __init__(self, device=0, max_parties=32, digest=DIGEST_BLAKE3):
+        """digest: the node hash D of Dapol<D, R> (DIGEST_BLAKE3 or DIGEST_BLAKE2S)."""
         self.h = _P()
-        _chk(lib().dapol_ctx_create(device, max_parties, DIGEST_BLAKE3, ctypes.byref(self.h)))
+        _chk(lib().dapol_ctx_create(device, max_parties, digest, ctypes.byref(self.h)))
         self.max_parties = max_parties
 
     def close(self):

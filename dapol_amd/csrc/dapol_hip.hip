@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -60,6 +61,9 @@ static inline unsigned nblk(size_t n, unsigned bs) { return (unsigned)((n + bs -
 
 // ------------------------------------------------------------------------------------------------ context
 struct dapol_ctx {
+    // One reference for the caller's handle plus one per tree / workload built on the context: dapol_ctx_destroy only
+    // drops the caller's, so handles may be destroyed in any order (garbage-collected language bindings do exactly that).
+    std::atomic<int> refs{1};
     int device = 0;
     int max_parties = 0;
     hipStream_t stream = nullptr;
@@ -92,7 +96,8 @@ const char* dapol_last_error(void) { return g_last_error.c_str(); }
 int32_t dapol_ctx_create(int32_t device, int32_t max_parties, int32_t digest_id, dapol_ctx** out) {
     if (!out) return fail(DAPOL_ERR_INVALID_ARGUMENT, "out is null");
     *out = nullptr;
-    if (digest_id != DAPOL_DIGEST_BLAKE3) return fail(DAPOL_ERR_INVALID_DIGEST_SIZE, "only BLAKE3 (32-byte) node hashes on the GPU path");
+    if (digest_id != DAPOL_DIGEST_BLAKE3 && digest_id != DAPOL_DIGEST_BLAKE2S)
+        return fail(DAPOL_ERR_INVALID_DIGEST_SIZE, "node digest must be BLAKE3 or Blake2s-256 (32-byte output, DapolError::InvalidDigestSize)");
     if (max_parties < 1 || max_parties > 1024 || (max_parties & (max_parties - 1)))
         return fail(DAPOL_ERR_INVALID_ARGUMENT, "max_parties must be a power of two in [1, 1024]");
     int count = 0;
@@ -141,14 +146,16 @@ int32_t dapol_ctx_create(int32_t device, int32_t max_parties, int32_t digest_id,
     hipLaunchKernelGGL(k_ctx_compress, dim3(nblk(rows, 64)), dim3(64), 0, c->stream, c->gens_comp.p, base_pts.p, rows);
     LAUNCH_CHECK();
     HIPCHK(hipStreamSynchronize(c->stream));
-    c->tv = TableView{c->table.p, P, wbits};
+    c->tv = TableView{c->table.p, P, wbits, digest_id};
     guard.c = nullptr;
     *out = c;
     return DAPOL_OK;
 }
 
+static void ctx_retain(dapol_ctx* ctx) { ctx->refs.fetch_add(1); }
 int32_t dapol_ctx_destroy(dapol_ctx* ctx) {
     if (!ctx) return DAPOL_OK;
+    if (ctx->refs.fetch_sub(1) > 1) return DAPOL_OK;          // trees / workloads still use it: the last of them frees it
     (void)hipSetDevice(ctx->device);
     ctx->scratch.release();
     ctx->table.release();
@@ -306,6 +313,7 @@ struct OwnedLeaves {
 };
 struct dapol_tree_owned : dapol_tree {
     OwnedLeaves leaves;          // empty when level 0 borrows the caller's device arrays (workload trees)
+    bool holds_ctx = false;      // API-created trees keep their context alive (workload trees live inside a workload that does)
 };
 
 int32_t dapol_tree_build(dapol_ctx* ctx, int32_t height, size_t n, const uint64_t* leaf_idx, const uint64_t* v, const uint8_t* r32,
@@ -327,6 +335,8 @@ int32_t dapol_tree_build(dapol_ctx* ctx, int32_t height, size_t n, const uint64_
     int32_t rc = tree_build_device(ctx, height, 0, n, t->leaves.idx.p, t->leaves.v.p, t->leaves.r.p, pad_seed32, t);
     if (rc != DAPOL_OK) return rc;
     guard.t = nullptr;
+    t->holds_ctx = true;
+    ctx_retain(ctx);
     *out = t;
     return DAPOL_OK;
 }
@@ -348,6 +358,8 @@ int32_t dapol_tree_build_shard(dapol_ctx* ctx, int32_t total_height, int32_t sha
     int32_t rc = tree_build_device(ctx, total_height, shard_bits, n, t->leaves.idx.p, t->leaves.v.p, t->leaves.r.p, pad_seed32, t);
     if (rc != DAPOL_OK) return rc;
     guard.t = nullptr;
+    t->holds_ctx = true;
+    ctx_retain(ctx);
     *out = t;
     return DAPOL_OK;
 }
@@ -406,12 +418,13 @@ int32_t dapol_tree_update(dapol_tree* tree, size_t k, const uint64_t* leaf_idx, 
     memcpy(seed, tree->pad_seed, 32);
     int32_t rc = tree_build_device(ctx, tree->index_bits, tree->shard_bits, n, fresh.leaves.idx.p, fresh.leaves.v.p, fresh.leaves.r.p, seed, &fresh);
     if (rc != DAPOL_OK) return rc;                          // the old tree stays as it was
+    fresh.holds_ctx = own->holds_ctx;
     *own = std::move(fresh);
     return DAPOL_OK;
 }
 
 // Mergeable::merge on compressed records
-__global__ void k_merge_records(size_t n, const uint32_t* CL, const uint32_t* HL, const uint64_t* vL, const uint32_t* rL,
+__global__ void k_merge_records(int dg, size_t n, const uint32_t* CL, const uint32_t* HL, const uint64_t* vL, const uint32_t* rL,
                                 const uint32_t* CR, const uint32_t* HR, const uint64_t* vR, const uint32_t* rR, uint32_t* C, uint32_t* H,
                                 uint64_t* v, uint32_t* r, uint32_t* bad) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -423,7 +436,7 @@ __global__ void k_merge_records(size_t n, const uint32_t* CL, const uint32_t* HL
     if (!ok) { atomicOr(bad, 1u); return; }
     ge_add(p, a, b);
     ge_compress(cp, p);
-    blake3_hash128(hp, cl, cr, hl, hr);
+    node_hash128(dg, hp, cl, cr, hl, hr);
     st8(C + i * 8, cp);
     st8(H + i * 8, hp);
     if (v) {
@@ -463,7 +476,7 @@ int32_t dapol_merge_batch(dapol_ctx* ctx, size_t n, const uint8_t* CL32, const u
     }
     DevBuf<uint32_t> oC, oH;
     HIPCHK(oC.alloc(n * 8)); HIPCHK(oH.alloc(n * 8));
-    hipLaunchKernelGGL(k_merge_records, dim3(nblk(n, 64)), dim3(64), 0, st, n, d[0].p, d[1].p, with_secrets ? dv[0].p : nullptr, d[4].p,
+    hipLaunchKernelGGL(k_merge_records, dim3(nblk(n, 64)), dim3(64), 0, st, ctx->tv.digest, n, d[0].p, d[1].p, with_secrets ? dv[0].p : nullptr, d[4].p,
                        d[2].p, d[3].p, with_secrets ? dv[1].p : nullptr, d[5].p, oC.p, oH.p, with_secrets ? dv[2].p : nullptr, d[6].p, bad.p);
     LAUNCH_CHECK();
     uint32_t h_bad = 0;
@@ -481,8 +494,11 @@ int32_t dapol_merge_batch(dapol_ctx* ctx, size_t n, const uint8_t* CL32, const u
 
 int32_t dapol_tree_destroy(dapol_tree* tree) {
     if (!tree) return DAPOL_OK;
+    dapol_tree_owned* own = static_cast<dapol_tree_owned*>(tree);
+    dapol_ctx* ctx = own->holds_ctx ? tree->ctx : nullptr;
     if (tree->ctx) (void)hipSetDevice(tree->ctx->device);
-    delete static_cast<dapol_tree_owned*>(tree);
+    delete own;
+    if (ctx) (void)dapol_ctx_destroy(ctx);
     return DAPOL_OK;
 }
 

@@ -126,6 +126,38 @@ DAPOL_HD void blake2s_compress(uint32_t* h, const uint32_t* m, uint32_t t, bool 
 #undef B2G
     for (int i = 0; i < 8; i++) h[i] ^= v[i] ^ v[8 + i];
 }
+// Node hashes for D = Blake2s-256 (Dapol<blake2::Blake2s, _>, src/dapol/tests.rs:21,33): the same byte strings as
+// the BLAKE3 ones above, 32 bytes = one block, 128 bytes = two.
+DAPOL_HD void blake2s_hash32(uint32_t* out8, const uint32_t* c8) {
+    uint32_t h[8], m[16];
+    blake3_iv(h);
+    h[0] ^= 0x01010020u;
+    for (int i = 0; i < 8; i++) m[i] = c8[i];
+    for (int i = 8; i < 16; i++) m[i] = 0;
+    blake2s_compress(h, m, 32, true);
+    for (int i = 0; i < 8; i++) out8[i] = h[i];
+}
+DAPOL_HD void blake2s_hash128(uint32_t* out8, const uint32_t* cl, const uint32_t* cr, const uint32_t* hl, const uint32_t* hr) {
+    uint32_t h[8], m[16];
+    blake3_iv(h);
+    h[0] ^= 0x01010020u;
+    for (int i = 0; i < 8; i++) { m[i] = cl[i]; m[8 + i] = cr[i]; }
+    blake2s_compress(h, m, 64, false);
+    for (int i = 0; i < 8; i++) { m[i] = hl[i]; m[8 + i] = hr[i]; }
+    blake2s_compress(h, m, 128, true);
+    for (int i = 0; i < 8; i++) out8[i] = h[i];
+}
+// The node hash of the context's digest D (DG_BLAKE3 / DG_BLAKE2S): leaf = D(C) (src/dapol/node.rs:34-36),
+// parent = D(C_L || C_R || H_L || H_R) (node.rs:66-77, src/proof/node.rs:58-64).
+DAPOL_HD void node_hash32(int kind, uint32_t* out8, const uint32_t* c8) {
+    if (kind == DG_BLAKE2S) blake2s_hash32(out8, c8);
+    else blake3_hash32(out8, c8);
+}
+DAPOL_HD void node_hash128(int kind, uint32_t* out8, const uint32_t* cl, const uint32_t* cr, const uint32_t* hl, const uint32_t* hr) {
+    if (kind == DG_BLAKE2S) blake2s_hash128(out8, cl, cr, hl, hr);
+    else blake3_hash128(out8, cl, cr, hl, hr);
+}
+
 DAPOL_HD void dg_init(Digest& d, int kind) {
     blake3_iv(d.h);                        // both digests start from the SHA-256 IV ...
     if (kind == DG_BLAKE2S) d.h[0] ^= 0x01010020u;   // ... Blake2s xors the parameter block (digest 32, fanout 1, depth 1)

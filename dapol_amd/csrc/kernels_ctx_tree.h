@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void k_commit_hash(TableView tbl, size_t n, co
     tbl_fixed_mul_add(acc, tbl, tbl.row_Bb(0), rw);
     uint32_t c[8], h[8];
     ge_compress(c, acc);
-    blake3_hash32(h, c);
+    node_hash32(tbl.digest, h, c);
     st8(C + i * 8, c);
     st8(H + i * 8, h);
     if (ext) st_p3(ext + i * 40, acc);
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void k_tree_merge(TableView tbl, LevelView cur
         ge_identity(pB);
         tbl_fixed_mul_add(pB, tbl, tbl.row_Bb(0), rB);
         ge_compress(cB, pB);
-        blake3_hash32(hB, cB);
+        node_hash32(tbl.digest, hB, cB);
         st8(cur.padC + i * 8, cB);
         st8(cur.padH + i * 8, hB);
         st8(cur.padr + i * 8, rB);
@@ -266,8 +266,8 @@ __global__ __launch_bounds__(256) void k_tree_merge(TableView tbl, LevelView cur
     ge_p3 pp;
     ge_add(pp, pA, pB);
     ge_compress(cp, pp);
-    if (a_is_left) blake3_hash128(hp, cA, cB, hA, hB);
-    else blake3_hash128(hp, cB, cA, hB, hA);
+    if (a_is_left) node_hash128(tbl.digest, hp, cA, cB, hA, hB);
+    else node_hash128(tbl.digest, hp, cB, cA, hB, hA);
     nxt.idx[q] = my_idx >> 1;
     nxt.v[q] = vA + vB;           // u64 wrap == release-mode Rust (node.rs:72)
     st8(nxt.r + q * 8, rp);

@@ -237,7 +237,7 @@ __global__ __launch_bounds__(64) void k_rv_finish(VerifyArgs V, TableView tbl) {
 
 // MerkleProof::verify for single leaves with DapolProofNode::merge (src/proof/node.rs:56-69, src/proof/mod.rs:41-47):
 // re-merge the leaf with its siblings (root side first in `pC/pH`) and compare with the root.  One lane per entity.
-__global__ __launch_bounds__(64) void k_verify_paths(size_t b, int height, const uint64_t* leaf_idx, const uint32_t* leafC, const uint32_t* leafH,
+__global__ __launch_bounds__(64) void k_verify_paths(int dg, size_t b, int height, const uint64_t* leaf_idx, const uint32_t* leafC, const uint32_t* leafH,
                                                     const uint32_t* pC, const uint32_t* pH, const uint32_t* rootC, const uint32_t* rootH,
                                                     uint8_t* ok) {
     size_t e = (size_t)blockIdx.x * 64 + threadIdx.x;
@@ -253,8 +253,8 @@ __global__ __launch_bounds__(64) void k_verify_paths(size_t b, int height, const
         ld8(sc_, pC + slot * 8);
         ld8(sh, pH + slot * 8);
         good &= ge_decompress(sp, sc_);                      // deserialisation rejects non-canonical points (proof/node.rs:88-94)
-        if ((idx >> k) & 1) blake3_hash128(hn, sc_, c, sh, h);
-        else blake3_hash128(hn, c, sc_, h, sh);
+        if ((idx >> k) & 1) node_hash128(dg, hn, sc_, c, sh, h);
+        else node_hash128(dg, hn, c, sc_, h, sh);
         ge_p3 t;
         ge_add(t, acc, sp);
         acc = t;

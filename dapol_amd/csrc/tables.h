@@ -28,6 +28,7 @@ struct TableView {
     const int32_t* base;   // device pointer
     int32_t max_parties;
     int32_t wbits;         // W
+    int32_t digest;        // node hash D of the context: DG_BLAKE3 (0) or DG_BLAKE2S (1)
     // Windows of an UNREDUCED 255-bit integer (Scalar::from_bits leaf blindings): the top window must hold its value
     // plus the recoding carry within 2^(W-1), i.e. be at most W-1 bits wide -> 255/W + 1 windows.  Canonical scalars
     // (< 2^253, everything in the digit matrices) need 253/W + 1.

@@ -44,7 +44,8 @@ struct DapolNode {
 
 class Context {                                // PedersenGens::default() + BulletproofGens::new(64, m), once
   public:
-    explicit Context(int device = 0, int max_parties = 32) { check(dapol_ctx_create(device, max_parties, DAPOL_DIGEST_BLAKE3, &h_)); }
+    // digest = the node hash D of Dapol<D, R>: DAPOL_DIGEST_BLAKE3 or DAPOL_DIGEST_BLAKE2S
+    explicit Context(int device = 0, int max_parties = 32, int digest = DAPOL_DIGEST_BLAKE3) { check(dapol_ctx_create(device, max_parties, digest, &h_)); }
     ~Context() { dapol_ctx_destroy(h_); }
     Context(const Context&) = delete;
     Context& operator=(const Context&) = delete;

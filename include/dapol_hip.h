@@ -56,12 +56,16 @@ typedef struct dapol_ctx dapol_ctx;
 typedef struct dapol_tree dapol_tree;
 
 enum { DAPOL_POLICY_PADDING = 0, DAPOL_POLICY_SPLITTING = 1 };  /* RangeProofPadding / RangeProofSplitting */
-enum { DAPOL_DIGEST_BLAKE3 = 0, DAPOL_DIGEST_BLAKE2S = 1 };     /* D = blake3::Hasher (benches/dapol.rs:38); Blake2s only for leaf derivation */
+enum { DAPOL_DIGEST_BLAKE3 = 0, DAPOL_DIGEST_BLAKE2S = 1 };     /* D = blake3::Hasher (benches/dapol.rs:38) or blake2::Blake2s (src/dapol/tests.rs:21) */
 
 /* Replaces the per-call PedersenGens::default() (src/dapol/node.rs:31, src/range/mod.rs:49,65,84,103) and
  * BulletproofGens::new(64, m) (src/range/mod.rs:50,66,85,104): generators and their window tables are derived
- * ONCE, on the GPU, for up to max_parties parties of 64 bits.  max_parties must be a power of two <= 1024. */
+ * ONCE, on the GPU, for up to max_parties parties of 64 bits.  max_parties must be a power of two <= 1024.
+ * digest_id: the node hash D of Dapol<D, R> used by every tree / merge / verify call of this context; anything but the
+ * two 32-byte digests above -> DAPOL_ERR_INVALID_DIGEST_SIZE (DapolError::InvalidDigestSize, src/dapol/mod.rs:101-103). */
 int32_t dapol_ctx_create(int32_t device, int32_t max_parties, int32_t digest_id, dapol_ctx** out);
+/* Trees and workloads built on a context keep it alive: dapol_ctx_destroy releases the caller's handle, the storage goes
+ * when the last tree / workload of the context is destroyed too -- handles may be destroyed in any order. */
 int32_t dapol_ctx_destroy(dapol_ctx* ctx);
 /* Compressed generators (for cross-checks): which = 0 B, 1 B_blinding, 2 G[party][bit], 3 H[party][bit]. */
 int32_t dapol_ctx_generator(dapol_ctx* ctx, int32_t which, int32_t party, int32_t bit, uint8_t out32[32]);

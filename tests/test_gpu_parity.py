@@ -214,6 +214,22 @@ def test_error_behaviour(gpu_ctx, hip_lib):
     assert C.shape == (0, 32)
 
 
+def test_handles_may_be_destroyed_in_any_order(hip_lib):
+    """A tree keeps its context alive (garbage-collected bindings finalise in arbitrary order)."""
+    ctx = hip_lib.Context(0, 1)
+    r = np.ones((2, 32), np.uint8)
+    r[:, 31] = 0
+    tr = hip_lib.Tree(ctx, 3, [1, 6], [4, 5], r, SEED)
+    before = tr.root()
+    ctx.close()                                            # the caller's handle goes first
+    assert tr.root() == before and tr.paths([6])[0].shape == (1, 3, 32)
+    tr.update([2], [9], r[:1])
+    assert tr.root()[2] == 18
+    tr.close()
+    ctx2 = hip_lib.Context(0, 1)                           # no stale HIP error is left behind
+    assert ctx2.commit_hash_batch([1], r[:1])[0].shape == (1, 32)
+
+
 def test_single_leaf_and_full_level(gpu_ctx, hip_lib, ref):
     for height, idx in ((1, [1]), (3, list(range(8))), (10, [1023])):
         idx = np.array(idx, np.uint64)
@@ -448,6 +464,48 @@ def test_leaf_derivation_reference_kats(gpu_ctx, hip_lib):
     tr = hip_lib.Tree(gpu_ctx, 4, out3["leaf_idx"], out3["v"], out3["r"], bytes(range(32)), enforce_sparsity=True)
     C, H, v, r = tr.root()
     assert (C.hex(), H.hex(), v) == (kat["blake3"]["root"]["C"], kat["blake3"]["root"]["H"], 26)
+
+
+def test_blake2s_dapol_like_the_reference_tests(hip_lib, pyref):
+    """src/dapol/tests.rs:18-107 builds Dapol::<blake2::Blake2s, RangeProofPadding>: Blake2s is the NODE hash too.
+    A Blake2s context: every node of the tree, the proofs for ids a..d (leaves 7, 12, 2, 4), the batch proof for
+    [a, b] and both verifiers, against the Python restatement with dg = blake2s."""
+    ctx = hip_lib.Context(0, 8, digest=hip_lib.DIGEST_BLAKE2S)
+    kat = load_golden("kat.json")
+    liab = [(i.encode(), e.encode(), v) for i, e, v in kat["liabilities"]]
+    out = ctx.build_leaf_nodes(liab, b"test", 4, hip_lib.DIGEST_BLAKE2S)
+    tr = hip_lib.Tree(ctx, 4, out["leaf_idx"], out["v"], out["r"], SEED, enforce_sparsity=True)
+    pt, id_map = pyref.dapol_new(liab, b"test", 4, SEED, dg="blake2s")
+    assert id_map == {b"a": 7, b"b": 12, b"c": 2, b"d": 4}
+    C, H, v, r = tr.root()
+    assert (C, H, v) == (pt.root.C, pt.root.H, 26)                        # tests.rs:24
+    for level in range(5):
+        idx, vv, rr, CC, HH, pad = tr.level_nodes(level)
+        got = {int(i): (c.tobytes(), h.tobytes()) for i, c, h in zip(idx, CC, HH)}
+        assert got == {i: (n.C, n.H) for i, n in pt.levels[level].items()}
+    leaf_idx = np.array([2, 4, 7, 12], np.uint64)
+    pC, pH, proofs = tr.prove_entities(leaf_idx, 0, 2, 8, SEED)           # build_test_options(4, 2)
+    for k, li in enumerate(leaf_idx):
+        sibs, aggregated, individual = pyref.dapol_prove(pt, int(li), "padding", 2, SEED, n=8)
+        assert [pH[k, s].tobytes() for s in range(4)] == [x.H for x in sibs]
+        assert proofs[k].tobytes() == b"".join(aggregated) + b"".join(individual)
+    lC, lH = ctx.commit_hash_batch(out["v"], out["r"])
+    assert [h.tobytes() for h in lH] == [pt.levels[0][int(i)].H for i in leaf_idx]
+    assert ctx.verify_entities(4, leaf_idx, lC, lH, pC, pH, C, H, 0, 2, 8, proofs, verify_seed=SEED).all()
+    level, index, sC, sH, blob = tr.prove_batch([7, 12], 0, 2, 8, SEED)   # generate_proof_batch_for_ids([a, b])
+    _, sibs, aggregated, individual = pyref.dapol_prove_batch(pt, [7, 12], "padding", 2, SEED, n=8)
+    assert [h.tobytes() for h in sH] == [x.H for x in sibs] and blob == b"".join(aggregated) + b"".join(individual)
+    assert ctx.verify_batch(4, [7, 12], lC[2:], lH[2:], sC, sH, C, H, 0, 2, 8, blob, verify_seed=SEED)
+    # the same proof does not verify under a BLAKE3 context (different node hashes)
+    ctx3 = hip_lib.Context(0, 8)
+    assert not ctx3.verify_batch(4, [7, 12], lC[2:], lH[2:], sC, sH, C, H, 0, 2, 8, blob, verify_seed=SEED)
+    assert not ctx3.verify_entities(4, leaf_idx, lC, lH, pC, pH, C, H, 0, 2, 8, proofs, verify_seed=SEED).any()
+    mC, mH, mv, mr = ctx.merge_batch(lC[:1], lH[:1], lC[1:2], lH[1:2], out["v"][:1], out["r"][:1], out["v"][1:2], out["r"][1:2])
+    n = pyref.node_merge(pt.levels[0][2], pt.levels[0][4], "blake2s")
+    assert (mC[0].tobytes(), mH[0].tobytes(), int(mv[0])) == (n.C, n.H, 18)
+    with pytest.raises(hip_lib.DapolError) as e:
+        hip_lib.Context(0, 8, digest=2)                                   # e.g. Blake2b: 64-byte output
+    assert e.value.code == 3                                              # DapolError::InvalidDigestSize
 
 
 @pytest.mark.parametrize("height,n,digest", [(6, 30, "blake3"), (8, 100, "blake2s"), (5, 16, "blake3"), (20, 3000, "blake3"), (7, 64, "blake2s")])
