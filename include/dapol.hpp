@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <cstring>
 #include <memory>
+#include <map>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -139,9 +140,67 @@ struct DapolBatchProof {
     }
 };
 
+// LiabilityId / Liability / DapolOptions (src/dapol/mod.rs:36-56)
+using LiabilityId = std::vector<uint8_t>;
+inline LiabilityId liability_id_from_str(const std::string& s) { return LiabilityId(s.begin(), s.end()); }
+struct Liability {
+    LiabilityId internal_id, external_id;
+    uint64_t value = 0;
+};
+struct DapolOptions {
+    std::vector<uint8_t> audit_seed;
+    int tree_height = 0;
+    size_t aggregation_factor = 0;
+    Bytes32 secret{};                 // smtree Secret: here the seed of the positional padding draws
+};
+
 // Dapol<D, R> (src/dapol/mod.rs:78-83)
 class Dapol {
   public:
+    // Dapol::new (mod.rs:100-128): validation, leaf derivation (build_leaf_nodes, on the GPU), tree build.  D = the
+    // context's digest for node hashes AND leaf derivation, as in the reference.  Throws DapolError with the code of
+    // TreeHeightTooBig / SparsityTooSmall / DuplicatedInternalId / FailedToMapIndex.
+    static Dapol create(std::shared_ptr<Context> ctx, int digest, const std::vector<Liability>& liabilities, const DapolOptions& options,
+                        Policy policy = Policy::Padding) {
+        Dapol d = new_blank(std::move(ctx), options.tree_height, options.aggregation_factor, policy);
+        size_t n = liabilities.size();
+        std::vector<uint8_t> iid, eid;
+        std::vector<uint32_t> ioff(n + 1, 0), eoff(n + 1, 0);
+        std::vector<uint64_t> vals(n);
+        for (size_t i = 0; i < n; i++) {
+            iid.insert(iid.end(), liabilities[i].internal_id.begin(), liabilities[i].internal_id.end());
+            eid.insert(eid.end(), liabilities[i].external_id.begin(), liabilities[i].external_id.end());
+            ioff[i + 1] = (uint32_t)iid.size();
+            eoff[i + 1] = (uint32_t)eid.size();
+            vals[i] = liabilities[i].value;
+        }
+        iid.push_back(0); eid.push_back(0);                                 // never pass a null data pointer
+        std::vector<uint64_t> idx(n), v(n), by_entity(n);
+        std::vector<uint32_t> order(n);
+        std::vector<Bytes32> r(n);
+        check(dapol_build_leaf_nodes(d.ctx_->get(), digest, options.audit_seed.data(), options.audit_seed.size(), options.tree_height, n, iid.data(),
+                                     ioff.data(), eid.data(), eoff.data(), vals.data(), idx.data(), v.data(), n ? r[0].data() : nullptr,
+                                     order.data(), by_entity.data()));
+        for (size_t i = 0; i < n; i++) d.id_to_idx_map_[liabilities[i].internal_id] = by_entity[i];
+        d.build(idx, v, r, options.secret, true);
+        return d;
+    }
+    // Dapol::generate_proof_for_id / generate_proof_batch_for_ids (mod.rs:148-164): None for an unknown id.
+    std::optional<DapolProof> generate_proof_for_id(const LiabilityId& id, const Bytes32& nonce_seed, int n_bits = 64) const {
+        auto it = id_to_idx_map_.find(id);
+        if (it == id_to_idx_map_.end()) return std::nullopt;
+        return generate_proof(it->second, nonce_seed, n_bits);
+    }
+    std::optional<DapolBatchProof> generate_proof_batch_for_ids(const std::vector<LiabilityId>& ids, const Bytes32& nonce_seed, int n_bits = 64) const {
+        std::vector<uint64_t> idx;
+        for (auto& id : ids) {
+            auto it = id_to_idx_map_.find(id);
+            if (it == id_to_idx_map_.end()) return std::nullopt;
+            idx.push_back(it->second);
+        }
+        return generate_proof_batch(idx, nonce_seed, n_bits);
+    }
+    const std::map<LiabilityId, uint64_t>& id_to_idx_map() const { return id_to_idx_map_; }
     // Dapol::new_blank (mod.rs:196-204)
     static Dapol new_blank(std::shared_ptr<Context> ctx, int height, size_t aggregation_factor, Policy policy = Policy::Padding) {
         Dapol d;
@@ -237,6 +296,7 @@ class Dapol {
         return out;
     }
   private:
+    std::map<LiabilityId, uint64_t> id_to_idx_map_;
     std::shared_ptr<Context> ctx_;
     std::shared_ptr<dapol_tree> tree_;
     int height_ = 0;

@@ -68,6 +68,41 @@ int main(int argc, char** argv) {
         if (bp->verify_batch(*ctx, bd.root(), lv, seed)) { std::printf("FAIL batch verify accepted swapped leaves\n"); return 1; }
         if (bd.generate_proof_batch({3, 41}, seed, 8)) { std::printf("FAIL batch none\n"); return 1; }
     }
+    {   // src/dapol/tests.rs:18-107 with Dapol::<blake2::Blake2s, RangeProofPadding>::new
+        auto c2 = std::make_shared<Context>(0, 8, DAPOL_DIGEST_BLAKE2S);
+        std::vector<Liability> liab;
+        const char* iids[4] = {"a", "b", "c", "d"};
+        const char* eids[4] = {"w", "x", "y", "z"};
+        const uint64_t lv[4] = {3, 5, 7, 11};
+        for (int i = 0; i < 4; i++) liab.push_back({liability_id_from_str(iids[i]), liability_id_from_str(eids[i]), lv[i]});
+        DapolOptions opt;
+        opt.audit_seed = {'t', 'e', 's', 't'};
+        opt.tree_height = 4;
+        opt.aggregation_factor = 2;
+        opt.secret = seed;
+        Dapol t = Dapol::create(c2, DAPOL_DIGEST_BLAKE2S, liab, opt, Policy::Padding);
+        if (t.root_raw().get_value() != 26) { std::printf("FAIL root value\n"); return 1; }                   // tests.rs:24
+        const uint64_t want[4] = {7, 12, 2, 4};                                                                // tests.rs:30-85
+        for (int i = 0; i < 4; i++) {
+            auto by_id = t.generate_proof_for_id(liability_id_from_str(iids[i]), seed, 8);
+            auto by_ix = t.generate_proof(want[i], seed, 8);
+            if (!by_id || !by_ix || by_id->leaf_index != want[i] || by_id->range_proofs != by_ix->range_proofs) { std::printf("FAIL for_id %d\n", i); return 1; }
+            for (size_t s2 = 0; s2 < by_id->merkle_siblings.size(); s2++)
+                if (by_id->merkle_siblings[s2].com != by_ix->merkle_siblings[s2].com || by_id->merkle_siblings[s2].hash != by_ix->merkle_siblings[s2].hash) { std::printf("FAIL path %d\n", i); return 1; }
+        }
+        auto ba = t.generate_proof_batch_for_ids({liability_id_from_str("a"), liability_id_from_str("b")}, seed, 8);   // tests.rs:88-107
+        auto bi = t.generate_proof_batch({7, 12}, seed, 8);
+        if (!ba || !bi || ba->range_proofs != bi->range_proofs || ba->merkle_siblings.size() != bi->merkle_siblings.size()) { std::printf("FAIL batch_for_ids\n"); return 1; }
+        if (t.generate_proof_for_id(liability_id_from_str("zz"), seed, 8)) { std::printf("FAIL unknown id\n"); return 1; }
+        try {
+            liab.push_back({liability_id_from_str("a"), liability_id_from_str("q"), 1});
+            Dapol::create(c2, DAPOL_DIGEST_BLAKE2S, liab, opt);
+            std::printf("FAIL duplicate accepted\n");
+            return 1;
+        } catch (const DapolError& e) {
+            if (e.code != DAPOL_ERR_DUPLICATED_INTERNAL_ID) { std::printf("FAIL dup code %d\n", e.code); return 1; }
+        }
+    }
     std::printf("OK proof_bytes=%zu\n", proof->range_proofs.size());
     return 0;
 }
