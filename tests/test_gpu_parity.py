@@ -665,3 +665,103 @@ def test_full_size_roundtrip_config1(gpu_ctx, hip_lib):
     assert proofs.shape[1] == 32 * (9 + 2 * 10)                            # 928 bytes: m = 16 parties of 64 bits
     lC, lH = gpu_ctx.commit_hash_batch(v, r)
     assert gpu_ctx.verify_entities(height, idx, lC, lH, pC, pH, rC, rH, hip_lib.POLICY_PADDING, height, 64, proofs, verify_seed=SEED).all()
+
+
+def _oracle_padding_proof(ref, n_bits, height, sv, sr, leaf, seed=SEED):
+    """The C oracle's padding-policy proof over one entity's siblings (root side first), padded with (0, 1)."""
+    m = 1
+    while m < height:
+        m <<= 1
+    pv, pr = np.zeros(m, np.uint64), np.zeros((m, 32), np.uint8)
+    pv[:height], pr[:height] = sv, sr
+    pr[height:, 0] = 1
+    ref.ref_range_proof_size.restype = ctypes.c_size_t
+    ps = ref.ref_range_proof_size(n_bits, m)
+    out = ctypes.create_string_buffer(ps)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    assert ref.ref_range_prove(n_bits, m, p(pv), p(pr), seed, ctypes.c_uint64(int(leaf)), ctypes.c_uint64(0), None, 0, out) == 0
+    return out.raw
+
+
+def test_full_size_config0_32bit(gpu_ctx, hip_lib, ref):
+    """BASELINE configs[0] as written: 2^10 entities, height 16, 32-BIT range proofs -- the whole tree against the C oracle,
+    sampled proofs byte for byte, and every inclusion proof through DapolProof::verify."""
+    height, n, nb = 16, 1 << 10, 32
+    idx = (np.arange(n, dtype=np.uint64) * np.uint64((1 << height) // n))
+    rng = np.random.default_rng(1016)
+    v = rng.integers(0, 2**20, size=n, dtype=np.uint64)                    # sums stay below 2^32
+    r = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    r[:, 31] &= 0x0F
+    w = hip_lib.Workload(gpu_ctx, height, idx, v, r)
+    st = w.run(SEED, SEED, n_bits=nb)
+    ps = st.proof_bytes // n
+    assert ps == 32 * (9 + 2 * 9)                                          # m = 16 parties of 32 bits: 864 bytes
+    t = _ref_tree(ref, height, idx, v, r)
+    rC, rH, rv, _ = _ref_root(ref, t)
+    ref.ref_tree_free(t)
+    assert bytes(st.root_C) == rC and bytes(st.root_H) == rH and rv == int(v.sum())
+    sample = np.ascontiguousarray(idx[::64])
+    sv, sr, sC, sH = w.paths(sample, with_nodes=True)
+    for k, leaf in enumerate(sample):
+        assert w.proofs(k * 64, 1, ps).tobytes() == _oracle_padding_proof(ref, nb, height, sv[k], sr[k], leaf)
+    aC, aH = w.paths(idx, with_nodes=True)[2:]
+    lC, lH = gpu_ctx.commit_hash_batch(v, r)
+    ok = gpu_ctx.verify_entities(height, idx, lC, lH, aC, aH, bytes(st.root_C), bytes(st.root_H), hip_lib.POLICY_PADDING, height, nb,
+                                 w.proofs(0, n, ps), verify_seed=SEED)
+    assert ok.all()
+
+
+def test_full_size_config1_properties(gpu_ctx, hip_lib, ref):
+    """BASELINE configs[1] at FULL size: 2^16 entities, height 24, 64-bit proofs.  Size-independent properties: root value =
+    sum of liabilities, two runs give the same checksum, another nonce seed changes it, sampled proofs equal the C oracle's
+    over the same siblings, and 4,096 sampled inclusion proofs pass DapolProof::verify while a tampered one fails."""
+    height, n = 24, 1 << 16
+    idx = (np.arange(n, dtype=np.uint64) * np.uint64((1 << height) // n))
+    rng = np.random.default_rng(2416)
+    v = rng.integers(0, 2**32, size=n, dtype=np.uint64)
+    r = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    r[:, 31] &= 0x0F
+    w = hip_lib.Workload(gpu_ctx, height, idx, v, r)
+    (rC, rH, rv, _), _ = w.build(SEED)
+    assert rv == int(v.sum())
+    st = w.prove(SEED, 64)
+    ps = st.proof_bytes // n
+    assert ps == 992 and st.proofs == n
+    c1 = st.checksum
+    pos = np.arange(0, n, 16)
+    sample = np.ascontiguousarray(idx[pos])
+    sv, sr, sC, sH = w.paths(sample, with_nodes=True)
+    proofs = np.concatenate([w.proofs(int(q), 1, ps) for q in pos])
+    for k in (0, 1000, 4095):
+        assert proofs[k].tobytes() == _oracle_padding_proof(ref, 64, height, sv[k], sr[k], sample[k])
+    lC, lH = gpu_ctx.commit_hash_batch(v[pos], r[pos])
+    args = (rC, rH, hip_lib.POLICY_PADDING, height, 64)
+    assert gpu_ctx.verify_entities(height, sample, lC, lH, sC, sH, *args, proofs, verify_seed=SEED).all()
+    bad = proofs.copy()
+    bad[7, 500] ^= 0x10
+    okb = gpu_ctx.verify_entities(height, sample, lC, lH, sC, sH, *args, bad, verify_seed=SEED)
+    assert okb[7] == 0 and okb.sum() == len(pos) - 1
+    assert w.prove(SEED, 64).checksum == c1                                  # deterministic
+    assert w.prove(bytes(32), 64).checksum != c1                             # fresh nonces, different bytes
+
+
+def test_config4_shape_1024_party_verification(hip_lib):
+    """BASELINE configs[4] shape: aggregated proofs over 1,024 commitments (m = 1024, n = 64) verify; one flipped bit or one
+    swapped commitment is rejected, and only in the proof it belongs to."""
+    ctx = hip_lib.Context(0, 1024)
+    b, m = 3, 1024
+    rng = np.random.default_rng(1024)
+    v = rng.integers(0, 2**63, size=(b, m), dtype=np.uint64)
+    r = rng.integers(0, 256, size=(b, m, 32), dtype=np.uint8)
+    r[:, :, 31] &= 0x0F
+    proofs = ctx.range_prove_batch(64, m, v, r, nonce_seed=SEED, stream_id=np.arange(b, dtype=np.uint64))
+    assert proofs.shape[1] == 32 * (9 + 2 * 16)                              # 1,312 bytes
+    C, _ = ctx.commit_hash_batch(v.reshape(-1), r.reshape(-1, 32))
+    V = C.reshape(b, m, 32)
+    assert ctx.range_verify_batch(64, m, proofs, V, verify_seed=SEED).all()
+    bad = proofs.copy()
+    bad[1, 1000] ^= 1
+    assert list(ctx.range_verify_batch(64, m, bad, V, verify_seed=SEED)) == [1, 0, 1]
+    V2 = V.copy()
+    V2[2, [5, 900]] = V2[2, [900, 5]]
+    assert list(ctx.range_verify_batch(64, m, proofs, V2, verify_seed=SEED)) == [1, 1, 0]
