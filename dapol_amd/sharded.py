@@ -58,9 +58,10 @@ def top_levels(ctx, records, rank, merge=None):
 class ShardedProver:
     """bench.py's step: build this rank's subtree, exchange roots, prove this rank's entities."""
 
-    def __init__(self, ctx, height, leaf_idx, v, r32, rank=0, world=1, dist=None, torch=None):
+    def __init__(self, ctx, height, leaf_idx, v, r32, rank=0, world=1, dist=None, torch=None, comm_device="cuda"):
         assert world & (world - 1) == 0, "number of GPUs must be a power of two"
         self.ctx, self.height, self.rank, self.world, self.dist, self.torch = ctx, height, rank, world, dist, torch
+        self.comm_device = comm_device            # "cuda": RCCL over xGMI; "cpu": gloo (tests)
         self.shard_bits = world.bit_length() - 1
         self.idx = np.ascontiguousarray(leaf_idx, np.uint64)
         self.w = capi.Workload(ctx, height, leaf_idx, v, r32, shard_bits=self.shard_bits)
@@ -71,7 +72,7 @@ class ShardedProver:
         if self.world == 1:
             self.root, self.upper = root, None
             return
-        buf = exchange_records(self.dist, self.torch, pack_record(root), self.world, "cuda")   # RCCL over xGMI
+        buf = exchange_records(self.dist, self.torch, pack_record(root), self.world, self.comm_device)   # RCCL over xGMI
         recs = unpack_records(buf, self.world)
         self.root, self.upper = top_levels(self.ctx, recs, self.rank)
 
@@ -82,7 +83,7 @@ class ShardedProver:
         if self.world > 1:
             t = self.torch
             # final reduce of the aggregated proof transcript checksum (wrapping 64-bit sum, carried as two 32-bit halves)
-            cs = t.tensor([st.checksum & 0xFFFFFFFF, st.checksum >> 32], dtype=t.int64, device="cuda")
+            cs = t.tensor([st.checksum & 0xFFFFFFFF, st.checksum >> 32], dtype=t.int64, device=self.comm_device)
             self.dist.all_reduce(cs)
             st.checksum = (int(cs[0].item()) + (int(cs[1].item()) << 32)) & 0xFFFFFFFFFFFFFFFF
         return st
