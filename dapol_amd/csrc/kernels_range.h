@@ -224,7 +224,7 @@ __global__ __launch_bounds__(64, 3) void k_rp_msm(RangeArgs A, TableView tbl, in
     }
     bool valid = b < A.B;
     if (!valid) b = A.B - 1;
-    if constexpr (MODE == MSM_TAIL) tbl.base += b * (size_t)(2 * A.N) * TAIL_ROW_WORDS;
+    if constexpr (MODE == MSM_TAIL) tbl.base += b * (size_t)(2 * A.N) * tbl.row_words();
     const dig_t* dig = A.dig + b * A.nwin * (size_t)A.TP + 32 * side;
     const int NW = A.nwin, W = A.wbits;
     ge_p3 acc;
@@ -264,20 +264,17 @@ __global__ __launch_bounds__(64, 3) void k_rp_msm(RangeArgs A, TableView tbl, in
     }
 }
 
-// One lane per materialised generator P: its table row 0*P .. 8*P in affine niels form (one inversion per row by
-// Montgomery's trick; the projective multiples wait in the row's own entry slots), and the tail argument's vectors:
-// a, b = the first T entries of the folded vectors, coefficients s = 1.
-__global__ __launch_bounds__(64) void k_rp_tail_table(RangeArgs A) {
-    const int T = A.tail_n, bpp = (2 * T) >> 6;                  // blocks per proof
-    size_t b = blockIdx.x / bpp;
-    int g = (int)(blockIdx.x % bpp) * 64 + threadIdx.x;          // row: G'_g (g < T) or H'_(g-T)
-    int32_t* row = A.tailT + (b * (size_t)(2 * T) + g) * TAIL_ROW_WORDS;
+// Table row of one point P: the multiples 0*P .. (ENTRIES-1)*P in affine niels form (the 128-byte entry format of the
+// context tables).  P waits in extended coordinates at the head of the row; the projective multiples are parked in the
+// row's own entry slots and normalised with ONE inversion (Montgomery's trick).
+template <int ENTRIES>
+__device__ __forceinline__ void build_niels_row(int32_t* row) {
     ge_p3 base, mul;
     ld_p3(base, row);
     mul = base;
-    fe pre[TAIL_ENTRIES - 1];
+    fe pre[ENTRIES - 1];
 #pragma unroll
-    for (int e = 1; e < TAIL_ENTRIES; e++) {
+    for (int e = 1; e < ENTRIES; e++) {
         if (e > 1) { ge_p3 t; ge_add(t, mul, base); mul = t; }
         int32_t* slot = row + e * 32;
         for (int i = 0; i < 10; i++) { slot[i] = mul.X.v[i]; slot[10 + i] = mul.Y.v[i]; slot[20 + i] = mul.Z.v[i]; }
@@ -285,9 +282,9 @@ __global__ __launch_bounds__(64) void k_rp_tail_table(RangeArgs A) {
         else fe_mul(pre[e - 1], pre[e - 2], mul.Z);
     }
     fe inv;
-    fe_invert(inv, pre[TAIL_ENTRIES - 2]);
+    fe_invert(inv, pre[ENTRIES - 2]);
 #pragma unroll
-    for (int e = TAIL_ENTRIES - 1; e >= 1; e--) {
+    for (int e = ENTRIES - 1; e >= 1; e--) {
         int32_t* slot = row + e * 32;
         fe X, Y, Z, zi, x, y;
         for (int i = 0; i < 10; i++) { X.v[i] = slot[i]; Y.v[i] = slot[10 + i]; Z.v[i] = slot[20 + i]; }
@@ -304,6 +301,15 @@ __global__ __launch_bounds__(64) void k_rp_tail_table(RangeArgs A) {
     ge_niels_identity(id);
     for (int i = 0; i < 10; i++) { row[i] = id.ypx.v[i]; row[10 + i] = id.ymx.v[i]; row[20 + i] = id.xy2d.v[i]; }
     row[30] = 0; row[31] = 0;
+}
+
+// One lane per materialised generator: its table row, and the tail argument's vectors: a, b = the first T entries of the
+// folded vectors, coefficients s = 1.
+__global__ __launch_bounds__(64) void k_rp_tail_table(RangeArgs A) {
+    const int T = A.tail_n, bpp = (2 * T) >> 6;                  // blocks per proof
+    size_t b = blockIdx.x / bpp;
+    int g = (int)(blockIdx.x % bpp) * 64 + threadIdx.x;          // row: G'_g (g < T) or H'_(g-T)
+    build_niels_row<TAIL_ENTRIES>(A.tailT + (b * (size_t)(2 * T) + g) * TAIL_ROW_WORDS);
     sc one, v;
     sc_one_mont(one);
     int i = g < T ? g : g - T;

@@ -10,6 +10,7 @@ namespace dapol {
 enum { RV_MAX_ROUNDS = 20 };
 struct VerifyState {                 // per proof
     sc y, z, y_inv, x, w, c, a, b, t_x, tau, mu;
+    sc rho;                          // weight of this proof in a cross-proof batch (random linear combination)
     sc u[RV_MAX_ROUNDS], u_inv[RV_MAX_ROUNDS];
     uint32_t ok, pad_[3];
 };
@@ -17,7 +18,17 @@ struct VerifyArgs {
     RangeArgs R;                     // reuses n, m, N, lgN, TP, B, Vc, dig, P0, P1, PA(=P2), out(=proof words), out_words, seed
     VerifyState* vs;
     uint8_t* verdict;                // [B]
+    // Per-proof power tables (k_rv_tables), tab_stride scalars per proof:
+    //   SH[2^hb] | SL[2^lb] : s_i = SH[i >> lb] * SL[i & (2^lb - 1)]        (lgN = hb + lb)
+    //   YH[2^hb] | YL[2^lb] : y^-q = YH[q >> lb] * YL[q & (2^lb - 1)]
+    //   ZZ[m]               : z^2 z^j
+    sc* tabs;
+    int hb, lb, tab_stride;
 };
+__host__ __device__ inline int rv_tab_entries(int lgN, int m) {
+    int lb = lgN / 2, hb = lgN - lb;
+    return 2 * (1 << hb) + 2 * (1 << lb) + m;
+}
 
 __device__ __forceinline__ bool words_canonical_scalar(const uint32_t* w) {   // w < l
     uint64_t borrow = 0;
@@ -83,18 +94,70 @@ __global__ __launch_bounds__(64) void k_rv_transcript(VerifyArgs V) {
     seed_wide(wide, seed, 3u, (uint64_t)b, 0);
     sc_from_wide(vs.c, wide);
     if (sc_is_zero(vs.c)) sc_one_mont(vs.c);
+    seed_wide(wide, seed, 5u, (uint64_t)b, 0);
+    sc_from_wide(vs.rho, wide);
+    if (sc_is_zero(vs.rho)) sc_one_mont(vs.rho);
     vs.ok = ok ? 1u : 0u;
 }
 
-// V2: g_i = -z - a s_i  (list 0, over G_i);  h_i = z + y^-i (z^2 z^j 2^i' - b s_(N-1-i))  (list 1, over H_i)  -> digits.
-__device__ __forceinline__ void rv_s(sc& r, const VerifyState& vs, int lgN, int i) {
-    sc acc;
-    sc_one_mont(acc);
-    for (int k = 0; k < lgN; k++) {
-        bool bit = (i >> (lgN - 1 - k)) & 1;           // MSB of i <-> first round
-        sc_montmul(acc, acc, bit ? vs.u[k] : vs.u_inv[k]);
+// V2a: the power tables of every proof (lane per entry).  grid = B * ceil(tab_stride / 64) blocks.
+__global__ __launch_bounds__(64) void k_rv_tables(VerifyArgs V) {
+    const RangeArgs& A = V.R;
+    const int bpp = (V.tab_stride + 63) >> 6;
+    size_t b = blockIdx.x / bpp;
+    int e = (int)(blockIdx.x % bpp) * 64 + threadIdx.x;
+    if (e >= V.tab_stride) return;
+    const VerifyState& vs = V.vs[b];
+    const int nh = 1 << V.hb, nl = 1 << V.lb;
+    sc r;
+    if (e < nh + nl) {                                  // products of u_k^{+-1}: MSB of i <-> first round
+        bool hi = e < nh;
+        int x = hi ? e : e - nh, k0 = hi ? 0 : V.hb, nbits = hi ? V.hb : V.lb;
+        sc_one_mont(r);
+        for (int k = 0; k < nbits; k++) {
+            bool bit = (x >> (nbits - 1 - k)) & 1;
+            sc_montmul(r, r, bit ? vs.u[k0 + k] : vs.u_inv[k0 + k]);
+        }
+    } else if (e < 2 * (nh + nl)) {
+        int x = e - nh - nl;
+        sc_pow_mont(r, vs.y_inv, x < nh ? (uint32_t)x << V.lb : (uint32_t)(x - nh));
+    } else {
+        sc zz;
+        sc_montmul(zz, vs.z, vs.z);
+        sc_pow_mont(r, vs.z, (uint32_t)(e - 2 * (nh + nl)));
+        sc_montmul(r, r, zz);
     }
-    r = acc;
+    st_sc(V.tabs + b * (size_t)V.tab_stride + e, r);
+}
+// V2: g_i = -z - a s_i  (list 0, over G_i);  h_i = z + y^-i (z^2 z^j 2^i' - b s_(N-1-i))  (list 1, over H_i)  -> digits.
+__device__ __forceinline__ void rv_gh_scalar(sc& r, const VerifyArgs& V, size_t b, int side, int q) {
+    const RangeArgs& A = V.R;
+    const VerifyState& vs = V.vs[b];
+    const sc* T = V.tabs + b * (size_t)V.tab_stride;
+    const int nh = 1 << V.hb, nl = 1 << V.lb;
+    int i = side == 0 ? q : A.N - 1 - q;
+    sc sh, sl, s, t;
+    ld_sc(sh, T + (i >> V.lb));
+    ld_sc(sl, T + nh + (i & (nl - 1)));
+    sc_montmul(s, sh, sl);
+    if (side == 0) {
+        sc_montmul(t, vs.a, s);
+        sc_add(t, t, vs.z);
+        sc_neg(r, t);                                  // -z - a s_i
+    } else {
+        int j = q / A.n, ii = q - j * A.n;
+        sc yh, yl, yi, zzj, two;
+        ld_sc(yh, T + nh + nl + (q >> V.lb));
+        ld_sc(yl, T + 2 * nh + nl + (q & (nl - 1)));
+        sc_montmul(yi, yh, yl);
+        ld_sc(zzj, T + 2 * (nh + nl) + j);
+        sc_from_u64_mont(two, 1ull << ii);
+        sc_montmul(t, zzj, two);                       // z^2 z^j 2^i'
+        sc_montmul(s, vs.b, s);
+        sc_sub(t, t, s);
+        sc_montmul(t, yi, t);
+        sc_add(r, vs.z, t);
+    }
 }
 __global__ __launch_bounds__(64) void k_rv_scalars(VerifyArgs V) {
     const RangeArgs& A = V.R;
@@ -102,29 +165,37 @@ __global__ __launch_bounds__(64) void k_rv_scalars(VerifyArgs V) {
     size_t b = blockIdx.x / nch;
     int ch = blockIdx.x % nch, l = threadIdx.x, side = l >> 5, q = 32 * ch + (l & 31), pos = 64 * ch + l;
     if (q >= A.N) { zero_digits(A, b, pos); return; }
-    const VerifyState& vs = V.vs[b];
-    sc s, t, r;
-    if (side == 0) {
-        rv_s(s, vs, A.lgN, q);
-        sc_montmul(t, vs.a, s);
-        sc_add(t, t, vs.z);
-        sc_neg(r, t);                                  // -z - a s_i
-    } else {
-        int j = q / A.n, ii = q - j * A.n;
-        rv_s(s, vs, A.lgN, A.N - 1 - q);
-        sc zj, two, yi, zz;
-        sc_montmul(zz, vs.z, vs.z);
-        sc_pow_mont(zj, vs.z, (uint32_t)j);
-        sc_from_u64_mont(two, 1ull << ii);
-        sc_pow_mont(yi, vs.y_inv, (uint32_t)q);
-        sc_montmul(t, zz, zj);
-        sc_montmul(t, t, two);                         // z^2 z^j 2^i'
-        sc_montmul(s, vs.b, s);
-        sc_sub(t, t, s);
-        sc_montmul(t, yi, t);
-        sc_add(r, vs.z, t);
-    }
+    sc r;
+    rv_gh_scalar(r, V, b, side, q);
     write_digits(A, b, pos, r);
+}
+
+// The t-th of a proof's own K = 4 + 2 lgN + m points and its scalar:  A, x S, c x T1, c x^2 T2, u_k^2 L_k, u_k^-2 R_k,
+// c z^(2+j) V_j.
+__device__ __forceinline__ void rv_own_point(uint32_t* w8, sc& sm, const VerifyArgs& V, size_t b, int t) {
+    const RangeArgs& A = V.R;
+    const VerifyState& vs = V.vs[b];
+    const uint32_t* pr = A.out + b * A.out_words;
+    if (t < 4) {
+        ld8(w8, pr + 8 * t);
+        if (t == 0) sc_one_mont(sm);
+        else if (t == 1) sm = vs.x;
+        else { sc_montmul(sm, vs.c, vs.x); if (t == 3) sc_montmul(sm, sm, vs.x); }
+    } else if (t < 4 + A.lgN) {
+        int k = t - 4;
+        ld8(w8, pr + 56 + 16 * k);
+        sc_montmul(sm, vs.u[k], vs.u[k]);
+    } else if (t < 4 + 2 * A.lgN) {
+        int k = t - 4 - A.lgN;
+        ld8(w8, pr + 56 + 16 * k + 8);
+        sc_montmul(sm, vs.u_inv[k], vs.u_inv[k]);
+    } else {
+        int j = t - 4 - 2 * A.lgN;
+        ld8(w8, A.Vc + (b * A.m + j) * 8);
+        sc zzj;
+        ld_sc(zzj, V.tabs + b * (size_t)V.tab_stride + 2 * ((1 << V.hb) + (1 << V.lb)) + j);
+        sc_montmul(sm, vs.c, zzj);
+    }
 }
 
 // V4: the proof's own points (wave per proof): decompress, multiply (binary double-and-add), reduce.
@@ -147,38 +218,14 @@ __global__ __launch_bounds__(64) void k_rv_varpoints(VerifyArgs V) {
     const RangeArgs& A = V.R;
     size_t b = blockIdx.x;
     int l = threadIdx.x;
-    const VerifyState& vs = V.vs[b];
-    const uint32_t* pr = A.out + b * A.out_words;
     const int K = 4 + 2 * A.lgN + A.m;
     ge_p3 acc;
     ge_identity(acc);
     bool ok = true;
-    sc cx, cxx, czz;
-    sc_montmul(cx, vs.c, vs.x);
-    sc_montmul(cxx, cx, vs.x);
-    sc_montmul(czz, vs.z, vs.z);
-    sc_montmul(czz, czz, vs.c);
     for (int t = l; t < K; t += 64) {
         uint32_t w8[8], k8[8];
         sc sm;
-        if (t < 4) {
-            ld8(w8, pr + 8 * t);
-            if (t == 0) sc_one_mont(sm); else if (t == 1) sm = vs.x; else if (t == 2) sm = cx; else sm = cxx;
-        } else if (t < 4 + A.lgN) {
-            int k = t - 4;
-            ld8(w8, pr + 56 + 16 * k);
-            sc_montmul(sm, vs.u[k], vs.u[k]);
-        } else if (t < 4 + 2 * A.lgN) {
-            int k = t - 4 - A.lgN;
-            ld8(w8, pr + 56 + 16 * k + 8);
-            sc_montmul(sm, vs.u_inv[k], vs.u_inv[k]);
-        } else {
-            int j = t - 4 - 2 * A.lgN;
-            ld8(w8, A.Vc + (b * A.m + j) * 8);
-            sc zj;
-            sc_pow_mont(zj, vs.z, (uint32_t)j);
-            sc_montmul(sm, czz, zj);
-        }
+        rv_own_point(w8, sm, V, b, t);
         ge_p3 p, q;
         ok &= ge_decompress(p, w8);
         sc_from_mont(k8, sm);
@@ -192,22 +239,9 @@ __global__ __launch_bounds__(64) void k_rv_varpoints(VerifyArgs V) {
     if (!ok) atomicAnd(&V.vs[b].ok, 0u);
 }
 
-// V5: assemble and test for the identity (lane per proof).
-__global__ __launch_bounds__(64) void k_rv_finish(VerifyArgs V, TableView tbl) {
-    const RangeArgs& A = V.R;
-    size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
-    if (b >= A.B) return;
-    const VerifyState& vs = V.vs[b];
-    ge_p3 p0, p1, t;
-    const int nsplit = A.nsplit > 1 ? A.nsplit : 1;
-    ld_p3(p0, A.PA + b * 40);
-    for (int sidx = 0; sidx < nsplit; sidx++) {            // partial sums of the (possibly split) fixed-base MSM
-        ld_p3(p1, A.P0 + (b * nsplit + sidx) * 40);
-        ge_add(t, p0, p1);
-        ld_p3(p1, A.P1 + (b * nsplit + sidx) * 40);
-        ge_add(p0, t, p1);
-    }
-    sc one, zz, sumy, py, sumz, pz, sum2, delta, s1, s2, bb, bs;
+// The scalars of B_blinding and B in one proof's check:  -mu - c tau   and   w (t_x - a b) + c (delta(y, z) - t_x).
+__device__ __forceinline__ void rv_base_scalars(sc& bb, sc& bs, const VerifyState& vs, const RangeArgs& A) {
+    sc one, zz, sumy, py, sumz, pz, sum2, delta, s1, s2;
     sc_one_mont(one);
     sc_montmul(zz, vs.z, vs.z);
     // sum_{i<N} y^i = (y^N - 1) / (y - 1)   (N a power of two: lgN squarings; y = 1 has probability 2^-252)
@@ -226,6 +260,25 @@ __global__ __launch_bounds__(64) void k_rv_finish(VerifyArgs V, TableView tbl) {
     sc_montmul(s1, vs.c, vs.tau); sc_add(s1, s1, vs.mu); sc_neg(bb, s1);               // -mu - c tau
     sc_montmul(s1, vs.a, vs.b); sc_sub(s1, vs.t_x, s1); sc_montmul(bs, vs.w, s1);
     sc_sub(s2, delta, vs.t_x); sc_montmul(s2, vs.c, s2); sc_add(bs, bs, s2);            // w (t_x - ab) + c (delta - t_x)
+}
+
+// V5: assemble and test for the identity (lane per proof).
+__global__ __launch_bounds__(64) void k_rv_finish(VerifyArgs V, TableView tbl) {
+    const RangeArgs& A = V.R;
+    size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (b >= A.B) return;
+    const VerifyState& vs = V.vs[b];
+    ge_p3 p0, p1, t;
+    const int nsplit = A.nsplit > 1 ? A.nsplit : 1;
+    ld_p3(p0, A.PA + b * 40);
+    for (int sidx = 0; sidx < nsplit; sidx++) {            // partial sums of the (possibly split) fixed-base MSM
+        ld_p3(p1, A.P0 + (b * nsplit + sidx) * 40);
+        ge_add(t, p0, p1);
+        ld_p3(p1, A.P1 + (b * nsplit + sidx) * 40);
+        ge_add(p0, t, p1);
+    }
+    sc bb, bs;
+    rv_base_scalars(bb, bs, vs, A);
     uint32_t k8[8], c8[8];
     sc_from_mont(k8, bb);
     tbl_fixed_mul_add(p0, tbl, tbl.row_Bb(0), k8);
@@ -233,6 +286,142 @@ __global__ __launch_bounds__(64) void k_rv_finish(VerifyArgs V, TableView tbl) {
     tbl_fixed_mul_add(p0, tbl, tbl.row_B(0), k8);
     ge_compress(c8, p0);
     V.verdict[b] = (vs.ok && words_zero(c8)) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Cross-proof batching (not in the reference, which checks every proof on its own): with
+// random weights rho_p the sum over the batch of rho_p * (proof p's check) is one multiscalar test in which the shared
+// bases G_i, H_i, B, B_blinding appear ONCE (their scalars summed over the proofs), so the 2nm-term fixed-base part is
+// paid per batch instead of per proof.  What stays per proof is its own K points; they go through ONE Straus MSM over
+// per-point 4-bit tables (the prover's tail kernel) instead of K separate double-and-add ladders.  A batch that passes
+// means every proof passes (error 2^-250); a batch that fails is re-checked proof by proof by the path above, so the
+// verdicts are always the per-proof ones.
+enum { PT_WBITS = 4, PT_NWIN = 253 / PT_WBITS + 1, PT_ENTRIES = (1 << (PT_WBITS - 1)) + 1, PT_ROW_WORDS = PT_ENTRIES * 32 };
+struct RlcArgs {
+    VerifyArgs V;              // the batch: V.R.B proofs; V.R.dig / P0 / P1 / nsplit serve the ONE generator MSM
+    int G;                     // proof groups of the generator-scalar accumulation
+    sc* partial;               // [G][TP]  partial sums of rho_p * (g_i | h_i), digit-position order
+    sc* bsum;                  // [B][2]   rho_p * (B_blinding scalar, B scalar)
+    int K;                     // own points per proof
+    size_t npts, Np;           // B * K points, as two lists of Np
+    int TP2, ns2;              // digit-row length and wavefront splits of the point MSM
+    int32_t* ptT;              // [2 Np][PT_ENTRIES][32]  per-point tables
+    dig_t* dig2;               // [PT_NWIN][TP2]
+    int32_t* Q0; int32_t* Q1;  // [ns2][40] partial sums of the point MSM
+    uint32_t* flag;            // [0] = 1: the combined check is the identity; [1] = 1: some point failed to decode
+};
+
+// rho_p-weighted generator scalars, summed over the proofs p = g (mod G) of one group.  grid = (TP/64) * G blocks.
+__global__ __launch_bounds__(64) void k_rvb_gh_partial(RlcArgs R) {
+    const RangeArgs& A = R.V.R;
+    int nch = A.TP >> 6;
+    int g = blockIdx.x / nch, ch = blockIdx.x % nch, l = threadIdx.x, side = l >> 5, q = 32 * ch + (l & 31), pos = 64 * ch + l;
+    sc acc;
+    sc_zero(acc);
+    if (q < A.N) {
+        for (size_t p = g; p < A.B; p += R.G) {
+            const VerifyState& vs = R.V.vs[p];
+            if (!vs.ok) continue;
+            sc r;
+            rv_gh_scalar(r, R.V, p, side, q);
+            sc_montmul(r, r, vs.rho);
+            sc_add(acc, acc, r);
+        }
+    }
+    st_sc(R.partial + (size_t)g * A.TP + pos, acc);
+}
+// ... summed over the groups -> the digits of the one generator MSM.  grid = TP/64 blocks.
+__global__ __launch_bounds__(64) void k_rvb_gh_reduce(RlcArgs R) {
+    const RangeArgs& A = R.V.R;
+    int ch = blockIdx.x, l = threadIdx.x, q = 32 * ch + (l & 31), pos = 64 * ch + l;
+    if (q >= A.N) { zero_digits(A, 0, pos); return; }
+    sc acc, t;
+    sc_zero(acc);
+    for (int g = 0; g < R.G; g++) { ld_sc(t, R.partial + (size_t)g * A.TP + pos); sc_add(acc, acc, t); }
+    write_digits(A, 0, pos, acc);
+}
+// rho_p-weighted scalars of B_blinding and B (lane per proof).
+__global__ __launch_bounds__(64) void k_rvb_base_scalars(RlcArgs R) {
+    const RangeArgs& A = R.V.R;
+    size_t p = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (p >= A.B) return;
+    const VerifyState& vs = R.V.vs[p];
+    sc bb, bs;
+    sc_zero(bb); sc_zero(bs);
+    if (vs.ok) {
+        rv_base_scalars(bb, bs, vs, A);
+        sc_montmul(bb, bb, vs.rho);
+        sc_montmul(bs, bs, vs.rho);
+    }
+    st_sc(R.bsum + 2 * p, bb);
+    st_sc(R.bsum + 2 * p + 1, bs);
+}
+// One lane per own point of the batch: decode, rho-weighted scalar -> digits, table row.  Slot t = list * Np + q.
+__global__ __launch_bounds__(64) void k_rvb_points(RlcArgs R) {
+    const RangeArgs& A = R.V.R;
+    size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (t >= 2 * R.Np) return;
+    size_t list = t / R.Np, q = t - list * R.Np;
+    dig_t* d = R.dig2 + 64 * (q >> 5) + (q & 31) + 32 * list;
+    int32_t* row = R.ptT + t * (size_t)PT_ROW_WORDS;
+    bool live = t < R.npts;
+    size_t p = live ? t / R.K : 0;
+    ge_p3 pt;
+    ge_identity(pt);
+    sc sm;
+    sc_zero(sm);
+    if (live && R.V.vs[p].ok) {
+        uint32_t w8[8];
+        rv_own_point(w8, sm, R.V, p, (int)(t - p * R.K));
+        if (ge_decompress(pt, w8)) sc_montmul(sm, sm, R.V.vs[p].rho);
+        else { atomicOr(&R.flag[1], 1u); ge_identity(pt); sc_zero(sm); }
+    }
+    uint32_t c[8];
+    sc_from_mont(c, sm);
+    const size_t TP2 = (size_t)R.TP2;
+    sc_recode_w(PT_WBITS, PT_NWIN, c, [&](int i, int digit) { d[(size_t)i * TP2] = (dig_t)digit; });
+    st_p3(row, pt);
+    build_niels_row<PT_ENTRIES>(row);
+}
+// Sums everything and tests for the identity (one wavefront).
+__global__ __launch_bounds__(64) void k_rvb_finish(RlcArgs R, TableView tbl) {
+    __shared__ int32_t lds[40 * 64];
+    const RangeArgs& A = R.V.R;
+    int l = threadIdx.x;
+    const int ns1 = A.nsplit > 1 ? A.nsplit : 1;
+    ge_p3 acc, p, t;
+    ge_identity(acc);
+    for (int i = l; i < 2 * ns1 + 2 * R.ns2; i += 64) {
+        const int32_t* src = i < ns1 ? A.P0 + (size_t)i * 40 : i < 2 * ns1 ? A.P1 + (size_t)(i - ns1) * 40
+                           : i < 2 * ns1 + R.ns2 ? R.Q0 + (size_t)(i - 2 * ns1) * 40 : R.Q1 + (size_t)(i - 2 * ns1 - R.ns2) * 40;
+        ld_p3(p, src);
+        ge_add(t, acc, p);
+        acc = t;
+    }
+    wave_reduce_point(acc, lds, l, 64);
+    sc bb, bs, x;
+    sc_zero(bb); sc_zero(bs);
+    for (size_t i = l; i < A.B; i += 64) {
+        ld_sc(x, R.bsum + 2 * i); sc_add(bb, bb, x);
+        ld_sc(x, R.bsum + 2 * i + 1); sc_add(bs, bs, x);
+    }
+    uint32_t* lw = reinterpret_cast<uint32_t*>(lds);
+    wave_reduce_sc(bb, lw, l);
+    wave_reduce_sc(bs, lw, l);
+    if (l == 0) {
+        uint32_t k8[8], c8[8];
+        sc_from_mont(k8, bb);
+        tbl_fixed_mul_add(acc, tbl, tbl.row_Bb(0), k8);
+        sc_from_mont(k8, bs);
+        tbl_fixed_mul_add(acc, tbl, tbl.row_B(0), k8);
+        ge_compress(c8, acc);
+        R.flag[0] = words_zero(c8) ? 1u : 0u;
+    }
+}
+// verdict[p] = the proof parsed (the batch check vouches for the rest)
+__global__ void k_rvb_verdicts(VerifyArgs V) {
+    size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < V.R.B) V.verdict[p] = V.vs[p].ok ? 1 : 0;
 }
 
 // MerkleProof::verify for single leaves with DapolProofNode::merge (src/proof/node.rs:56-69, src/proof/mod.rs:41-47):

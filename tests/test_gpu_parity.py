@@ -765,3 +765,48 @@ def test_config4_shape_1024_party_verification(hip_lib):
     V2 = V.copy()
     V2[2, [5, 900]] = V2[2, [900, 5]]
     assert list(ctx.range_verify_batch(64, m, proofs, V2, verify_seed=SEED)) == [1, 1, 0]
+
+
+@pytest.mark.parametrize("n_bits,m,b", [(64, 32, 50), (64, 1, 200), (16, 4, 70), (8, 2, 3)])
+def test_cross_proof_batching_gives_the_per_proof_verdicts(gpu_ctx, n_bits, m, b):
+    """The verifier checks a batch through one random linear combination and falls back to the per-proof check when
+    it fails: the verdict vector must be the per-proof one in every case (all good, some tampered, tampered
+    commitments, malformed encodings), and DAPOL_VERIFY_NO_RLC=1 -- the reference's proof-by-proof check -- must agree."""
+    import os
+    rng = np.random.default_rng(n_bits * 100 + m)
+    v = rng.integers(0, 2**n_bits if n_bits < 64 else 2**63, size=(b, m), dtype=np.uint64)
+    r = rng.integers(0, 256, size=(b, m, 32), dtype=np.uint8)
+    r[:, :, 31] &= 0x0F
+    proofs = gpu_ctx.range_prove_batch(n_bits, m, v, r, nonce_seed=SEED, stream_id=np.arange(b, dtype=np.uint64))
+    C, _ = gpu_ctx.commit_hash_batch(v.reshape(-1), r.reshape(-1, 32))
+    V = C.reshape(b, m, 32)
+
+    def both(p, vv):
+        os.environ.pop("DAPOL_VERIFY_NO_RLC", None)
+        a = gpu_ctx.range_verify_batch(n_bits, m, p, vv, verify_seed=SEED)
+        os.environ["DAPOL_VERIFY_NO_RLC"] = "1"
+        try:
+            c = gpu_ctx.range_verify_batch(n_bits, m, p, vv, verify_seed=SEED)
+        finally:
+            os.environ.pop("DAPOL_VERIFY_NO_RLC", None)
+        assert list(a) == list(c)
+        return list(a)
+
+    assert both(proofs, V) == [1] * b
+    bad = proofs.copy()
+    want = [1] * b
+    for k, off in ((0, 5), (b // 2, 40), (b - 1, proofs.shape[1] - 3)):       # A, a scalar, the final b
+        bad[k, off] ^= 4
+        want[k] = 0
+    assert both(bad, V) == want
+    V2 = V.copy()
+    V2[1, 0] = V[2, 0]                                                          # a commitment that belongs to another proof
+    want = [1] * b
+    want[1] = 0
+    assert both(proofs, V2) == want
+    mal = proofs.copy()
+    mal[2, 64:96] = 0xFF                                                        # T_1 is not a canonical point encoding
+    mal[0, 32 * 7:32 * 8] = 0xFF                                                # t_x >= l
+    want = [1] * b
+    want[0] = want[2] = 0
+    assert both(mal, V) == want
