@@ -120,7 +120,8 @@ def test_tree_vs_oracle_random(gpu_ctx, hip_lib, ref, height, n):
     ref.ref_tree_free(t)
 
 
-@pytest.mark.parametrize("n_bits,m,b", [(64, 32, 48), (64, 1, 64), (32, 16, 32), (8, 1, 130), (16, 8, 33)])
+@pytest.mark.parametrize("n_bits,m,b", [(64, 32, 48), (64, 1, 64), (32, 16, 32), (8, 1, 130), (16, 8, 33),
+                                        (64, 4, 20), (8, 32, 40), (64, 16, 10), (32, 32, 12), (16, 16, 21), (8, 16, 5), (32, 8, 9)])
 def test_range_prove_vs_oracle_random(gpu_ctx, ref, n_bits, m, b):
     rng = np.random.default_rng(n_bits * 100 + m)
     v = rng.integers(0, 2**n_bits if n_bits < 64 else 2**63, size=(b, m), dtype=np.uint64)
@@ -810,3 +811,26 @@ def test_cross_proof_batching_gives_the_per_proof_verdicts(gpu_ctx, n_bits, m, b
     want = [1] * b
     want[0] = want[2] = 0
     assert both(mal, V) == want
+
+
+@pytest.mark.parametrize("n_bits,m", [(64, 32), (64, 4), (32, 32)])
+def test_every_proving_strategy_gives_the_same_bytes(gpu_ctx, n_bits, m):
+    """The hybrid inner-product argument is a re-arrangement, not a different proof: no tail at all, tails of length 32 /
+    64 / 128, other lanes-per-list and chunk sizes all produce byte-identical proofs."""
+    import os
+    b = 37
+    rng = np.random.default_rng(n_bits + m)
+    v = rng.integers(0, 2**n_bits if n_bits < 64 else 2**63, size=(b, m), dtype=np.uint64)
+    r = rng.integers(0, 256, size=(b, m, 32), dtype=np.uint8)
+    r[:, :, 31] &= 0x0F
+    sid = np.arange(b, dtype=np.uint64)
+    base = gpu_ctx.range_prove_batch(n_bits, m, v, r, nonce_seed=SEED, stream_id=sid).tobytes()
+    for env in ({"DAPOL_NO_TAIL": "1"}, {"DAPOL_TAIL_N": "32"}, {"DAPOL_TAIL_N": "128"}, {"DAPOL_TAIL_LPL": "4"}, {"DAPOL_TAIL_LPL": "1"},
+                {"DAPOL_LPL": "32"}, {"DAPOL_LPL": "4"}, {"DAPOL_CHUNK": "64"}, {"DAPOL_TAIL_N": "256", "DAPOL_LPL": "16"}):
+        os.environ.update(env)
+        try:
+            got = gpu_ctx.range_prove_batch(n_bits, m, v, r, nonce_seed=SEED, stream_id=sid).tobytes()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        assert got == base, env
