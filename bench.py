@@ -181,6 +181,7 @@ def main():
         elapsed = float(tt.item())
     if rank != 0:
         if dist is not None:
+            dist.barrier()                     # leave together with rank 0 (which still runs its parity / verification legs)
             dist.destroy_process_group()
         return
 
@@ -249,6 +250,7 @@ def main():
     }
     print(json.dumps(line), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 
