@@ -119,7 +119,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
-    ap.add_argument("--warmup", type=int, default=0)
+    ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log2-entities", type=int, default=20, help="entities per GPU = 2^this (default: BASELINE configs[2])")
     ap.add_argument("--height", type=int, default=32)
     ap.add_argument("--n-bits", type=int, default=64)

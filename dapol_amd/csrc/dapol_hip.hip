@@ -67,6 +67,8 @@ struct dapol_ctx {
     int device = 0;
     int max_parties = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};   // further pipelines of the range prover (several chunks in flight)
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     DevBuf<int32_t> table;       // window tables
     DevBuf<uint32_t> gens_comp;  // compressed base points of every row (for dapol_ctx_generator)
     TableView tv{};
@@ -109,6 +111,11 @@ int32_t dapol_ctx_create(int32_t device, int32_t max_parties, int32_t digest_id,
     c->max_parties = max_parties;
     struct Guard { dapol_ctx* c; ~Guard() { if (c) dapol_ctx_destroy(c); } } guard{c};
     HIPCHK(hipStreamCreate(&c->stream));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    for (int i = 0; i < 3; i++) {
+        HIPCHK(hipStreamCreate(&c->side[i]));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+    }
     const int P = max_parties;
     // window width: the widest (<= 17 bits: wider measured slower, profiles/r01_wbits_ab4.txt) whose tables fit the budget
     // (DAPOL_TABLE_GB, default 40 GB), or DAPOL_WBITS (up to 20)
@@ -161,6 +168,11 @@ int32_t dapol_ctx_destroy(dapol_ctx* ctx) {
     ctx->table.release();
     ctx->gens_comp.release();
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    for (int i = 0; i < 3; i++) {
+        if (ctx->side[i]) (void)hipStreamDestroy(ctx->side[i]);
+        if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
+    }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     delete ctx;
     return DAPOL_OK;
 }
