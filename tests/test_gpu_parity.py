@@ -816,7 +816,8 @@ def test_cross_proof_batching_gives_the_per_proof_verdicts(gpu_ctx, n_bits, m, b
 @pytest.mark.parametrize("n_bits,m", [(64, 32), (64, 4), (32, 32)])
 def test_every_proving_strategy_gives_the_same_bytes(gpu_ctx, n_bits, m):
     """The hybrid inner-product argument is a re-arrangement, not a different proof: no tail at all, tails of length 32 /
-    64 / 128, other lanes-per-list and chunk sizes all produce byte-identical proofs."""
+    64 / 128, other lanes-per-list, chunk sizes and numbers of chunks in flight (DAPOL_CHUNK below the batch size puts several chunks on
+    several streams) all produce byte-identical proofs."""
     import os
     b = 37
     rng = np.random.default_rng(n_bits + m)
@@ -826,7 +827,9 @@ def test_every_proving_strategy_gives_the_same_bytes(gpu_ctx, n_bits, m):
     sid = np.arange(b, dtype=np.uint64)
     base = gpu_ctx.range_prove_batch(n_bits, m, v, r, nonce_seed=SEED, stream_id=sid).tobytes()
     for env in ({"DAPOL_NO_TAIL": "1"}, {"DAPOL_TAIL_N": "32"}, {"DAPOL_TAIL_N": "128"}, {"DAPOL_TAIL_LPL": "4"}, {"DAPOL_TAIL_LPL": "1"},
-                {"DAPOL_LPL": "32"}, {"DAPOL_LPL": "4"}, {"DAPOL_CHUNK": "64"}, {"DAPOL_TAIL_N": "256", "DAPOL_LPL": "16"}):
+                {"DAPOL_LPL": "32"}, {"DAPOL_LPL": "4"}, {"DAPOL_CHUNK": "64"}, {"DAPOL_TAIL_N": "256", "DAPOL_LPL": "16"},
+                {"DAPOL_CHUNK": "8"}, {"DAPOL_CHUNK": "5", "DAPOL_STREAMS": "4"}, {"DAPOL_CHUNK": "16", "DAPOL_STREAMS": "1"},
+                {"DAPOL_CHUNK": "36", "DAPOL_STREAMS": "3"}):
         os.environ.update(env)
         try:
             got = gpu_ctx.range_prove_batch(n_bits, m, v, r, nonce_seed=SEED, stream_id=sid).tobytes()
