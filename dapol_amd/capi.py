@@ -40,6 +40,7 @@ _SIG = {
     "dapol_tree_build": (ctypes.c_int32, [_P, ctypes.c_int32, ctypes.c_size_t, _P, _P, _P, _P, ctypes.c_int32, ctypes.POINTER(_P)]),
     "dapol_tree_build_shard": (ctypes.c_int32, [_P, ctypes.c_int32, ctypes.c_int32, ctypes.c_size_t, _P, _P, _P, _P, ctypes.POINTER(_P)]),
     "dapol_merge_batch": (ctypes.c_int32, [_P, ctypes.c_size_t] + [_P] * 12),
+    "dapol_padding_nodes": (ctypes.c_int32, [_P, _P, ctypes.c_size_t, _P, _P, _P, _P, _P]),
     "dapol_tree_destroy": (ctypes.c_int32, [_P]),
     "dapol_tree_root": (ctypes.c_int32, [_P, _P, _P, _P, _P]),
     "dapol_tree_node_count": (ctypes.c_int32, [_P, _P, _P]),
@@ -189,6 +190,15 @@ class Context:
         _chk(lib().dapol_build_leaf_nodes(self.h, digest, _ptr(sd), len(audit_seed), height, n, _ptr(ib), _ptr(ioff), _ptr(eb), _ptr(eoff),
                                           _ptr(vals), _ptr(idx), _ptr(v), _ptr(r), _ptr(order), _ptr(by_e)))
         return dict(leaf_idx=idx, v=v, r=r, order=order, idx_by_entity=by_e)
+
+    def padding_nodes(self, pad_seed, level, index):
+        """Paddable::padding at the given (level above the leaves, index) positions: (C, H, r); the value is 0."""
+        level, index = _u8(level), _u64(index)
+        n = index.shape[0]
+        C, H, r = (np.zeros((n, 32), np.uint8) for _ in range(3))
+        seed = _u8(np.frombuffer(pad_seed, np.uint8))
+        _chk(lib().dapol_padding_nodes(self.h, _ptr(seed), n, _ptr(level), _ptr(index), _ptr(C), _ptr(H), _ptr(r)))
+        return C, H, r
 
     def merge_batch(self, CL, HL, CR, HR, vL=None, rL=None, vR=None, rR=None):
         """Mergeable::merge on compressed records; returns (C, H) or (C, H, v, r) when the secrets are given."""

@@ -435,6 +435,50 @@ int32_t dapol_tree_update(dapol_tree* tree, size_t k, const uint64_t* leaf_idx, 
     return DAPOL_OK;
 }
 
+// Paddable::padding (src/dapol/node.rs:86-88): new(0, random blinding) with the draw keyed by the node's position.
+__global__ void k_padding_nodes(TableView tbl, size_t n, const uint32_t* pad_seed, const uint8_t* level, const uint64_t* index, uint32_t* C,
+                                uint32_t* H, uint32_t* r) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t seed[8], wide[16], rB[8], cB[8], hB[8];
+    for (int k = 0; k < 8; k++) seed[k] = pad_seed[k];
+    seed_wide(wide, seed, 1u, (uint64_t)level[i], index[i]);
+    sc rm;
+    sc_from_wide(rm, wide);
+    sc_from_mont(rB, rm);
+    ge_p3 p;
+    ge_identity(p);
+    tbl_fixed_mul_add(p, tbl, tbl.row_Bb(0), rB);
+    ge_compress(cB, p);
+    node_hash32(tbl.digest, hB, cB);
+    st8(C + i * 8, cB);
+    st8(H + i * 8, hB);
+    st8(r + i * 8, rB);
+}
+int32_t dapol_padding_nodes(dapol_ctx* ctx, const uint8_t pad_seed32[32], size_t n, const uint8_t* level, const uint64_t* index, uint8_t* C32,
+                            uint8_t* H32, uint8_t* r32) {
+    if (!ctx || !pad_seed32 || (n && (!level || !index || !C32 || !H32 || !r32))) return fail(DAPOL_ERR_INVALID_ARGUMENT, "null argument");
+    if (n == 0) return DAPOL_OK;
+    for (size_t i = 0; i < n; i++)
+        if (level[i] > 64) return fail(DAPOL_ERR_INVALID_ARGUMENT, "level must not exceed 64");
+    HIPCHK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    DevBuf<uint32_t> seed, dC, dH, dr;
+    DevBuf<uint8_t> dl;
+    DevBuf<uint64_t> di;
+    HIPCHK(seed.alloc(8)); HIPCHK(dC.alloc(n * 8)); HIPCHK(dH.alloc(n * 8)); HIPCHK(dr.alloc(n * 8)); HIPCHK(dl.alloc(n)); HIPCHK(di.alloc(n));
+    HIPCHK(hipMemcpyAsync(seed.p, pad_seed32, 32, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(dl.p, level, n, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(di.p, index, n * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_padding_nodes, dim3(nblk(n, 64)), dim3(64), 0, st, ctx->tv, n, seed.p, dl.p, di.p, dC.p, dH.p, dr.p);
+    LAUNCH_CHECK();
+    HIPCHK(hipMemcpyAsync(C32, dC.p, n * 32, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(H32, dH.p, n * 32, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(r32, dr.p, n * 32, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return DAPOL_OK;
+}
+
 // Mergeable::merge on compressed records
 __global__ void k_merge_records(int dg, size_t n, const uint32_t* CL, const uint32_t* HL, const uint64_t* vL, const uint32_t* rL,
                                 const uint32_t* CR, const uint32_t* HR, const uint64_t* vR, const uint32_t* rR, uint32_t* C, uint32_t* H,

@@ -64,7 +64,9 @@ class ShardedProver:
         self.comm_device = comm_device            # "cuda": RCCL over xGMI; "cpu": gloo (tests)
         self.shard_bits = world.bit_length() - 1
         self.idx = np.ascontiguousarray(leaf_idx, np.uint64)
-        self.w = capi.Workload(ctx, height, leaf_idx, v, r32, shard_bits=self.shard_bits)
+        # A rank without liabilities (possible with hash-derived indexes and few entities) contributes the padding node that
+        # stands at its subtree's root position, Paddable::padding at (height - shard_bits, rank), and proves nothing.
+        self.w = capi.Workload(ctx, height, leaf_idx, v, r32, shard_bits=self.shard_bits) if len(self.idx) else None
         self.upper = None
         self.root = None
 
@@ -77,9 +79,14 @@ class ShardedProver:
         self.root, self.upper = top_levels(self.ctx, recs, self.rank)
 
     def step(self, pad_seed, nonce_seed, n_bits=64):
-        root, st = self.w.build(pad_seed)
-        self._exchange(root)
-        st = self.w.prove(nonce_seed, n_bits, upper=self.upper, stats=st)
+        if self.w is None:
+            C, H, r = self.ctx.padding_nodes(pad_seed, [self.height - self.shard_bits], [self.rank])
+            root, st = (C[0].tobytes(), H[0].tobytes(), 0, r[0].tobytes()), capi.WorkloadStats()
+            self._exchange(root)
+        else:
+            root, st = self.w.build(pad_seed)
+            self._exchange(root)
+            st = self.w.prove(nonce_seed, n_bits, upper=self.upper, stats=st)
         if self.world > 1:
             t = self.torch
             # final reduce of the aggregated proof transcript checksum (wrapping 64-bit sum, carried as two 32-bit halves)

@@ -104,6 +104,11 @@ int32_t dapol_tree_build(dapol_ctx* ctx, int32_t height, size_t n, const uint64_
  * single-GPU build of the whole tree produces.  dapol_tree_root then returns the subtree root. */
 int32_t dapol_tree_build_shard(dapol_ctx* ctx, int32_t total_height, int32_t shard_bits, size_t n, const uint64_t* leaf_idx,
                                const uint64_t* v, const uint8_t* r32, const uint8_t pad_seed32[32], dapol_tree** out);
+/* Paddable::padding (src/dapol/node.rs:86-88), batched: the padding node new(0, blinding) at (level above the leaves,
+ * index within that level), its blinding drawn positionally from pad_seed (domain 1 of the randomness contract) -- the
+ * very node dapol_tree_build puts there.  Value is 0.  Used e.g. as the record of an empty shard in a multi-GPU build. */
+int32_t dapol_padding_nodes(dapol_ctx* ctx, const uint8_t pad_seed32[32], size_t n, const uint8_t* level, const uint64_t* index,
+                            uint8_t* C32, uint8_t* H32, uint8_t* r32);
 /* Mergeable::merge (src/dapol/node.rs:64-80; the (C,H) half is DapolProofNode::merge, src/proof/node.rs:56-69),
  * batched on compressed inputs: parent[i] = merge(left[i], right[i]).  Used for the replicated top levels above
  * the shard roots and by the Merkle-path re-merge of verification.  v/r pointers may all be NULL ((C,H) only).

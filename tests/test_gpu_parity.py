@@ -343,6 +343,34 @@ def test_sharded_equals_single_gpu(gpu_ctx, hip_lib, shard_bits):
 
 
 # ------------------------------------------------------------------------------------------------ workload (bench path)
+def test_padding_nodes_and_empty_shard(gpu_ctx, hip_lib, pyref):
+    """Paddable::padding as an entry point: equals the oracle's positional padding node and the node the tree builder
+    puts at that position; an empty shard's record is exactly that node (top_levels then gives the single-GPU root)."""
+    from dapol_amd.sharded import top_levels
+    pos = [(0, 5), (3, 1), (7, 0), (31, 1), (63, 1)]
+    C, H, r = gpu_ctx.padding_nodes(SEED, [l for l, _ in pos], [i for _, i in pos])
+    for k, (level, index) in enumerate(pos):
+        nd = pyref.node_padding(SEED, level, index)
+        assert (C[k].tobytes(), H[k].tobytes(), r[k].tobytes()) == (nd.C, nd.H, nd.r.to_bytes(32, "little"))
+    # all leaves in the left half of a height-6 tree: shard 1 of 2 is empty
+    height = 6
+    idx = np.array([1, 7, 20, 31], np.uint64)
+    v = np.array([4, 5, 6, 7], np.uint64)
+    rr = np.tile(np.arange(32, dtype=np.uint8), (4, 1))
+    rr[:, 31] = 1
+    whole = hip_lib.Tree(gpu_ctx, height, idx, v, rr, SEED)
+    left = hip_lib.Tree(gpu_ctx, height, idx, v, rr, SEED, shard_bits=1)
+    pC, pH, pr = gpu_ctx.padding_nodes(SEED, [height - 1], [1])
+    lC, lH, lv, lr = left.root()
+    recs = (np.stack([np.frombuffer(lC, np.uint8), pC[0]]), np.stack([np.frombuffer(lH, np.uint8), pH[0]]),
+            np.array([lv, 0], np.uint64), np.stack([np.frombuffer(lr, np.uint8), pr[0]]))
+    root, upper = top_levels(gpu_ctx, recs, 0)
+    assert root == whole.root()
+    wC, wH, out = whole.prove_entities(idx, 0, height, 8, SEED)
+    sC, sH, sout = left.prove_entities(idx, 0, height, 8, SEED, upper=upper)
+    assert out.tobytes() == sout.tobytes() and wC.tobytes() == sC.tobytes()
+
+
 def test_workload_matches_api_and_is_deterministic(gpu_ctx, hip_lib):
     height, n = 10, 64
     stride = (1 << height) // n
