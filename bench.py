@@ -197,7 +197,7 @@ def main():
                         "bound (255-bit modular multiply-adds) and deliberately spends HBM bandwidth on wide (17-bit) window tables: see "
                         "traffic (measured HBM bytes per launch) and DESIGN.md section 5"}
     # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; tools/pmc_summary.py),
-    # measured on full 61,440-proof launches of this kernel; only quoted when this run's launches have that size too.
+    # measured on full 73,728-proof launches of this kernel; only quoted when this run's launches have that size too.
     pmc = os.path.join(ROOT, "profiles", "msm_pmc.json")
     if os.path.exists(pmc) and n_per_gpu >= 60000 and height == 32 and n_bits == 64:
         try:
