@@ -264,6 +264,22 @@ __global__ __launch_bounds__(64, 3) void k_rp_msm(RangeArgs A, TableView tbl, in
     }
 }
 
+// Small calls split every proof's term range over several wavefronts (latency): P0 / P1 [b] = sum of the partials.
+__global__ __launch_bounds__(64) void k_rp_sum_splits(size_t B, int nsplit, const int32_t* PS0, const int32_t* PS1, int32_t* P0, int32_t* P1) {
+    size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (t >= 2 * B) return;
+    size_t b = t >> 1;
+    const int32_t* src = ((t & 1) ? PS1 : PS0) + b * (size_t)nsplit * 40;
+    ge_p3 acc, p, r;
+    ld_p3(acc, src);
+    for (int s = 1; s < nsplit; s++) {
+        ld_p3(p, src + (size_t)s * 40);
+        ge_add(r, acc, p);
+        acc = r;
+    }
+    st_p3(((t & 1) ? P1 : P0) + b * 40, acc);
+}
+
 // Table row of one point P: the multiples 0*P .. (ENTRIES-1)*P in affine niels form (the 128-byte entry format of the
 // context tables).  P waits in extended coordinates at the head of the row; the projective multiples are parked in the
 // row's own entry slots and normalised with ONE inversion (Montgomery's trick).
