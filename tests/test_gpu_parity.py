@@ -857,7 +857,7 @@ def test_every_proving_strategy_gives_the_same_bytes(gpu_ctx, n_bits, m):
     for env in ({"DAPOL_NO_TAIL": "1"}, {"DAPOL_TAIL_N": "32"}, {"DAPOL_TAIL_N": "128"}, {"DAPOL_TAIL_LPL": "4"}, {"DAPOL_TAIL_LPL": "1"},
                 {"DAPOL_LPL": "32"}, {"DAPOL_LPL": "4"}, {"DAPOL_CHUNK": "64"}, {"DAPOL_TAIL_N": "256", "DAPOL_LPL": "16"},
                 {"DAPOL_CHUNK": "8"}, {"DAPOL_CHUNK": "5", "DAPOL_STREAMS": "4"}, {"DAPOL_CHUNK": "16", "DAPOL_STREAMS": "1"},
-                {"DAPOL_CHUNK": "36", "DAPOL_STREAMS": "3"}):
+                {"DAPOL_CHUNK": "36", "DAPOL_STREAMS": "3"}, {"DAPOL_NO_SPLIT": "1"}, {"DAPOL_NO_SPLIT": "1", "DAPOL_TAIL_LPL": "32"}):
         os.environ.update(env)
         try:
             got = gpu_ctx.range_prove_batch(n_bits, m, v, r, nonce_seed=SEED, stream_id=sid).tobytes()
