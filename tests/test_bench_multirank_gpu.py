@@ -13,9 +13,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.gpu
 def test_bench_two_ranks_share_one_gpu(hip_lib):
+    import socket
+    with socket.socket() as sk:                       # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
     env = dict(os.environ, DAPOL_BENCH_BACKEND="gloo", DAPOL_TABLE_GB="3", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
-           "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log2-entities", "9", "--height", "16", "--steps", "2", "--warmup", "1"]
+           port, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log2-entities", "9", "--height", "16", "--steps", "2", "--warmup", "1"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
