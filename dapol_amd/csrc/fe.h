@@ -77,6 +77,96 @@ DAPOL_HD void fe_reduce_cols(fe& h, int64_t c0, int64_t c1, int64_t c2, int64_t 
     h.v[2] = h2; h.v[3] = h3; h.v[4] = h4; h.v[5] = h5; h.v[6] = h6; h.v[7] = h7; h.v[8] = h8; h.v[9] = h9;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(DAPOL_NO_MAD_CHAIN)
+// Device form of the column sums.  Every column is ONE chain of v_mad_i64_i32 whose first addend is the carry out of
+// the column below, so the 64-bit carry additions of fe_reduce_cols disappear into MADs that are issued anyway
+// (per product: 100 MAD + 10 shift + 10 mask, without the 9 v_lshl_add_u64; same values, same limbs).  Written as
+// inline assembly, one statement per column, because LLVM re-associates a C sum so that the carry is added last, as
+// a separate instruction; one statement per column (not per MAD) keeps the hazard recogniser from padding the
+// dependent MADs with s_nop.
+#define DAPOL_MAD_CHAIN 1
+__device__ __forceinline__ int64_t mad_col10z(int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2, int32_t a3, int32_t b3, int32_t a4, int32_t b4, int32_t a5, int32_t b5, int32_t a6, int32_t b6, int32_t a7, int32_t b7, int32_t a8, int32_t b8, int32_t a9, int32_t b9) {
+    int64_t d;
+    uint64_t sdst;               // VOP3b scalar destination (carry out), unused
+    asm("v_mad_i64_i32 %0, %1, %2, %3, 0\n\t"
+        "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %10, %11, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %12, %13, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %14, %15, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %16, %17, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %18, %19, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %20, %21, %0"
+        : "=&v"(d), "=s"(sdst)
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), "v"(a6), "v"(b6), "v"(a7), "v"(b7), "v"(a8), "v"(b8), "v"(a9), "v"(b9));
+    return d;
+}
+__device__ __forceinline__ int64_t mad_col10c(int64_t d, int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2, int32_t a3, int32_t b3, int32_t a4, int32_t b4, int32_t a5, int32_t b5, int32_t a6, int32_t b6, int32_t a7, int32_t b7, int32_t a8, int32_t b8, int32_t a9, int32_t b9) {
+    uint64_t sdst;               // VOP3b scalar destination (carry out), unused
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %10, %11, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %12, %13, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %14, %15, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %16, %17, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %18, %19, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %20, %21, %0"
+        : "+v"(d), "=s"(sdst)
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), "v"(a6), "v"(b6), "v"(a7), "v"(b7), "v"(a8), "v"(b8), "v"(a9), "v"(b9));
+    return d;
+}
+__device__ __forceinline__ int64_t mad_col6z(int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2, int32_t a3, int32_t b3, int32_t a4, int32_t b4, int32_t a5, int32_t b5) {
+    int64_t d;
+    uint64_t sdst;               // VOP3b scalar destination (carry out), unused
+    asm("v_mad_i64_i32 %0, %1, %2, %3, 0\n\t"
+        "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %10, %11, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %12, %13, %0"
+        : "=&v"(d), "=s"(sdst)
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5));
+    return d;
+}
+__device__ __forceinline__ int64_t mad_col6c(int64_t d, int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2, int32_t a3, int32_t b3, int32_t a4, int32_t b4, int32_t a5, int32_t b5) {
+    uint64_t sdst;               // VOP3b scalar destination (carry out), unused
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %10, %11, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %12, %13, %0"
+        : "+v"(d), "=s"(sdst)
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5));
+    return d;
+}
+__device__ __forceinline__ int64_t mad_col5c(int64_t d, int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2, int32_t a3, int32_t b3, int32_t a4, int32_t b4) {
+    uint64_t sdst;               // VOP3b scalar destination (carry out), unused
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %10, %11, %0"
+        : "+v"(d), "=s"(sdst)
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4));
+    return d;
+}
+// Limbs from columns whose carries are already chained (c_k includes c_{k-1} >> shift).
+__device__ __forceinline__ void fe_reduce_chained(fe& h, int64_t c0, int64_t c1, int64_t c2, int64_t c3, int64_t c4, int64_t c5,
+                                                  int64_t c6, int64_t c7, int64_t c8, int64_t c9) {
+    int32_t h0 = (int32_t)c0 & 0x3ffffff, h1 = (int32_t)c1 & 0x1ffffff;
+    int64_t t = (c9 >> 25) * 19 + h0;
+    h.v[0] = (int32_t)t & 0x3ffffff;
+    h.v[1] = h1 + (int32_t)(t >> 26);
+    h.v[2] = (int32_t)c2 & 0x3ffffff; h.v[3] = (int32_t)c3 & 0x1ffffff; h.v[4] = (int32_t)c4 & 0x3ffffff;
+    h.v[5] = (int32_t)c5 & 0x1ffffff; h.v[6] = (int32_t)c6 & 0x3ffffff; h.v[7] = (int32_t)c7 & 0x1ffffff;
+    h.v[8] = (int32_t)c8 & 0x3ffffff; h.v[9] = (int32_t)c9 & 0x1ffffff;
+}
+#endif
+
 #define M64(a, b) ((int64_t)(a) * (int64_t)(b))
 
 DAPOL_HD void fe_mul(fe& h, const fe& f, const fe& g) {
@@ -87,6 +177,28 @@ DAPOL_HD void fe_mul(fe& h, const fe& f, const fe& g) {
     const int32_t g1_19 = 19 * g1, g2_19 = 19 * g2, g3_19 = 19 * g3, g4_19 = 19 * g4, g5_19 = 19 * g5, g6_19 = 19 * g6,
                   g7_19 = 19 * g7, g8_19 = 19 * g8, g9_19 = 19 * g9;
     const int32_t f1_2 = 2 * f1, f3_2 = 2 * f3, f5_2 = 2 * f5, f7_2 = 2 * f7, f9_2 = 2 * f9;
+#if defined(DAPOL_MAD_CHAIN)
+    const int64_t c0 = mad_col10z(f0, g0, f1_2, g9_19, f2, g8_19, f3_2, g7_19, f4, g6_19, f5_2, g5_19, f6, g4_19, f7_2,
+        g3_19, f8, g2_19, f9_2, g1_19);
+    const int64_t c1 = mad_col10c(c0 >> 26, f0, g1, f1, g0, f2, g9_19, f3, g8_19, f4, g7_19, f5, g6_19, f6, g5_19, f7,
+        g4_19, f8, g3_19, f9, g2_19);
+    const int64_t c2 = mad_col10c(c1 >> 25, f0, g2, f1_2, g1, f2, g0, f3_2, g9_19, f4, g8_19, f5_2, g7_19, f6, g6_19, f7_2,
+        g5_19, f8, g4_19, f9_2, g3_19);
+    const int64_t c3 = mad_col10c(c2 >> 26, f0, g3, f1, g2, f2, g1, f3, g0, f4, g9_19, f5, g8_19, f6, g7_19, f7, g6_19, f8,
+        g5_19, f9, g4_19);
+    const int64_t c4 = mad_col10c(c3 >> 25, f0, g4, f1_2, g3, f2, g2, f3_2, g1, f4, g0, f5_2, g9_19, f6, g8_19, f7_2,
+        g7_19, f8, g6_19, f9_2, g5_19);
+    const int64_t c5 = mad_col10c(c4 >> 26, f0, g5, f1, g4, f2, g3, f3, g2, f4, g1, f5, g0, f6, g9_19, f7, g8_19, f8,
+        g7_19, f9, g6_19);
+    const int64_t c6 = mad_col10c(c5 >> 25, f0, g6, f1_2, g5, f2, g4, f3_2, g3, f4, g2, f5_2, g1, f6, g0, f7_2, g9_19, f8,
+        g8_19, f9_2, g7_19);
+    const int64_t c7 = mad_col10c(c6 >> 26, f0, g7, f1, g6, f2, g5, f3, g4, f4, g3, f5, g2, f6, g1, f7, g0, f8, g9_19, f9,
+        g8_19);
+    const int64_t c8 = mad_col10c(c7 >> 25, f0, g8, f1_2, g7, f2, g6, f3_2, g5, f4, g4, f5_2, g3, f6, g2, f7_2, g1, f8, g0,
+        f9_2, g9_19);
+    const int64_t c9 = mad_col10c(c8 >> 26, f0, g9, f1, g8, f2, g7, f3, g6, f4, g5, f5, g4, f6, g3, f7, g2, f8, g1, f9, g0);
+    fe_reduce_chained(h, c0, c1, c2, c3, c4, c5, c6, c7, c8, c9);
+#else
     int64_t c0 = M64(f0, g0) + M64(f1_2, g9_19) + M64(f2, g8_19) + M64(f3_2, g7_19) + M64(f4, g6_19) + M64(f5_2, g5_19) +
                  M64(f6, g4_19) + M64(f7_2, g3_19) + M64(f8, g2_19) + M64(f9_2, g1_19);
     int64_t c1 = M64(f0, g1) + M64(f1, g0) + M64(f2, g9_19) + M64(f3, g8_19) + M64(f4, g7_19) + M64(f5, g6_19) +
@@ -108,6 +220,7 @@ DAPOL_HD void fe_mul(fe& h, const fe& f, const fe& g) {
     int64_t c9 = M64(f0, g9) + M64(f1, g8) + M64(f2, g7) + M64(f3, g6) + M64(f4, g5) + M64(f5, g4) + M64(f6, g3) + M64(f7, g2) +
                  M64(f8, g1) + M64(f9, g0);
     fe_reduce_cols(h, c0, c1, c2, c3, c4, c5, c6, c7, c8, c9);
+#endif
 }
 
 DAPOL_HD void fe_sq(fe& h, const fe& f) {
@@ -116,6 +229,19 @@ DAPOL_HD void fe_sq(fe& h, const fe& f) {
     const int32_t f0_2 = 2 * f0, f1_2 = 2 * f1, f2_2 = 2 * f2, f3_2 = 2 * f3, f4_2 = 2 * f4, f5_2 = 2 * f5, f6_2 = 2 * f6,
                   f7_2 = 2 * f7;
     const int32_t f5_38 = 38 * f5, f6_19 = 19 * f6, f7_38 = 38 * f7, f8_19 = 19 * f8, f9_38 = 38 * f9;
+#if defined(DAPOL_MAD_CHAIN)
+    const int64_t c0 = mad_col6z(f0, f0, f1_2, f9_38, f2_2, f8_19, f3_2, f7_38, f4_2, f6_19, f5, f5_38);
+    const int64_t c1 = mad_col5c(c0 >> 26, f0_2, f1, f2, f9_38, f3_2, f8_19, f4, f7_38, f5_2, f6_19);
+    const int64_t c2 = mad_col6c(c1 >> 25, f0_2, f2, f1_2, f1, f3_2, f9_38, f4_2, f8_19, f5_2, f7_38, f6, f6_19);
+    const int64_t c3 = mad_col5c(c2 >> 26, f0_2, f3, f1_2, f2, f4, f9_38, f5_2, f8_19, f6, f7_38);
+    const int64_t c4 = mad_col6c(c3 >> 25, f0_2, f4, f1_2, f3_2, f2, f2, f5_2, f9_38, f6_2, f8_19, f7, f7_38);
+    const int64_t c5 = mad_col5c(c4 >> 26, f0_2, f5, f1_2, f4, f2_2, f3, f6, f9_38, f7_2, f8_19);
+    const int64_t c6 = mad_col6c(c5 >> 25, f0_2, f6, f1_2, f5_2, f2_2, f4, f3_2, f3, f7_2, f9_38, f8, f8_19);
+    const int64_t c7 = mad_col5c(c6 >> 26, f0_2, f7, f1_2, f6, f2_2, f5, f3_2, f4, f8, f9_38);
+    const int64_t c8 = mad_col6c(c7 >> 25, f0_2, f8, f1_2, f7_2, f2_2, f6, f3_2, f5_2, f4, f4, f9, f9_38);
+    const int64_t c9 = mad_col5c(c8 >> 26, f0_2, f9, f1_2, f8, f2_2, f7, f3_2, f6, f4_2, f5);
+    fe_reduce_chained(h, c0, c1, c2, c3, c4, c5, c6, c7, c8, c9);
+#else
     int64_t c0 = M64(f0, f0) + M64(f1_2, f9_38) + M64(f2_2, f8_19) + M64(f3_2, f7_38) + M64(f4_2, f6_19) + M64(f5, f5_38);
     int64_t c1 = M64(f0_2, f1) + M64(f2, f9_38) + M64(f3_2, f8_19) + M64(f4, f7_38) + M64(f5_2, f6_19);
     int64_t c2 = M64(f0_2, f2) + M64(f1_2, f1) + M64(f3_2, f9_38) + M64(f4_2, f8_19) + M64(f5_2, f7_38) + M64(f6, f6_19);
@@ -127,6 +253,7 @@ DAPOL_HD void fe_sq(fe& h, const fe& f) {
     int64_t c8 = M64(f0_2, f8) + M64(f1_2, f7_2) + M64(f2_2, f6) + M64(f3_2, f5_2) + M64(f4, f4) + M64(f9, f9_38);
     int64_t c9 = M64(f0_2, f9) + M64(f1_2, f8) + M64(f2_2, f7) + M64(f3_2, f6) + M64(f4_2, f5);
     fe_reduce_cols(h, c0, c1, c2, c3, c4, c5, c6, c7, c8, c9);
+#endif
 }
 #undef M64
 

@@ -195,8 +195,11 @@ __global__ __launch_bounds__(64) void k_rp_A(RangeArgs A, TableView tbl) {
 // the nwin signed W-bit windows from the top with W shared doublings per window (Straus), and looks every
 // digit up in the generator's row (one 128-byte cache line per lookup, L2 / Infinity-Cache resident).
 // Lanes 0-31 accumulate list 0, lanes 32-63 list 1; two 32-lane LDS tree reductions give P0 and P1.
+#ifndef DAPOL_MSM_OCC
+#define DAPOL_MSM_OCC 3          // resident wavefronts per SIMD the register allocation is bounded for
+#endif
 template <int MODE, int LPL>
-__global__ __launch_bounds__(64, 3) void k_rp_msm(RangeArgs A, TableView tbl, int round) {
+__global__ __launch_bounds__(64, DAPOL_MSM_OCC) void k_rp_msm(RangeArgs A, TableView tbl, int round) {
     // LPL = lanes per list.  32: one proof per wavefront (64 terms per lane at N = 2048).  16 / 8: two / four proofs per
     // wavefront with 128 / 256 terms per lane, which amortises the W * nwin shared doublings (22 % of the instructions
     // at LPL = 32) over more mixed adds.  The digit layout is the same for every LPL.
