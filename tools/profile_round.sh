@@ -1,0 +1,27 @@
+#!/bin/bash
+# One GPU call that refreshes the evidence under profiles/: tools/profile_round.sh <tag>   (run from the repo root on the GPU box)
+#   gpurun_out/<tag>_ubench_madd.txt      VALU-only cost of the point operations (the MSM's issue roof)
+#   gpurun_out/<tag>_bench.json           python bench.py (default workload, with the CPU baseline)
+#   gpurun_out/<tag>_stats/               rocprofv3 --kernel-trace --stats of the same command without the CPU leg
+#   gpurun_out/<tag>_pmc_*/               separate --pmc passes on 2^18 entities (full 73,728-proof launches)
+set -o pipefail
+tag=${1:-r01}
+R=$(pwd)
+OUT=$R/gpurun_out
+mkdir -p $OUT
+export TMPDIR=/tmp
+[ -x build/ubench_madd ] && build/ubench_madd > $OUT/${tag}_ubench_madd.txt 2>&1
+python3 bench.py > $OUT/${tag}_bench.json 2> $OUT/${tag}_bench.err || { tail -5 $OUT/${tag}_bench.err; exit 1; }
+tail -c 600 $OUT/${tag}_bench.json; echo
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${tag}_stats -o stats -- python3 $R/bench.py --no-cpu-baseline > $OUT/${tag}_stats.log 2>&1 || { tail -5 $OUT/${tag}_stats.log; exit 1; }
+echo "stats done"
+for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVE_CYCLES" "GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
+  n=$(echo $c | cut -d' ' -f1)
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/${tag}_pmc_$n -o pmc -- python3 $R/bench.py --no-cpu-baseline --log2-entities 18 --warmup 0 > $OUT/${tag}_pmc_$n.log 2>&1 || { tail -5 $OUT/${tag}_pmc_$n.log; exit 1; }
+  echo "pmc $n done"
+  # keep only the rows of the dominant kernel (the merged gpurun_out/ is capped at 64 MiB)
+  for f in $(find $OUT/${tag}_pmc_$n -name "*counter_collection.csv"); do head -1 $f > $f.tmp; grep "k_rp_msm" $f >> $f.tmp; mv $f.tmp $f; done
+done
+cd $R
+python3 tools/pmc_summary.py $(ls -d $OUT/${tag}_pmc_*/ ) --kernel "k_rp_msm<0" --out $OUT/${tag}_msm_pmc.json
