@@ -206,9 +206,10 @@ def main():
             roofline["traffic_GBps"] = pj.get("hbm_GBps")
             roofline["traffic_frac_of_peak"] = pj.get("hbm_GBps", 0.0) / PEAK_HBM_GBS
             roofline["valu_cycles_per_inst"] = pj.get("cycles_per_valu_inst_per_simd")
-            # the binding roof: integer-VALU issue (4.0 cycles per wave instruction for this MAD mix, profiles/r01_ubench_valu.txt)
+            # the binding roof: integer-VALU issue.  The same point additions in a register-only loop (tools/ubench_madd.hip,
+            # profiles/r01b_ubench_madd.txt) issue at 4,350 cycles / 1,075 instructions = 4.05 cycles per wave instruction.
             if pj.get("cycles_per_valu_inst_per_simd"):
-                roofline["valu_issue_frac"] = 4.0 / pj["cycles_per_valu_inst_per_simd"]
+                roofline["valu_issue_frac"] = 4.05 / pj["cycles_per_valu_inst_per_simd"]
         except Exception:
             pass
     cpu = None

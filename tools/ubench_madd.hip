@@ -28,7 +28,7 @@ __global__ __launch_bounds__(64, 3) void k(int32_t* out, const int32_t* in, int 
         if constexpr (OP == 1) ge_dbl(acc, acc, false);
         if constexpr (OP == 2) ge_dbl(acc, acc, true);
     }
-    if (blockIdx.x == 1000 && threadIdx.x == 0) { clk[0] = clock64() - c0; clk[1] = wall_clock64() - w0; }   // shader clocks vs 100 MHz ticks
+    if (blockIdx.x == 100 && threadIdx.x == 0) { clk[0] = clock64() - c0; clk[1] = wall_clock64() - w0; }   // shader clocks vs 100 MHz ticks
     int32_t* o = out + ((size_t)blockIdx.x * 64 + threadIdx.x) * 40;
     for (int i = 0; i < 10; i++) { o[i] = acc.X.v[i]; o[10 + i] = acc.Y.v[i]; o[20 + i] = acc.Z.v[i]; o[30 + i] = acc.T.v[i]; }
 }
@@ -48,8 +48,8 @@ template <int OP> int run(const char* name, int32_t* d_out, const int32_t* d_in,
     unsigned long long h_clk[2];
     CHECK(hipMemcpy(h_clk, d_clk, 16, hipMemcpyDeviceToHost));
     double ghz = (double)h_clk[0] / ((double)h_clk[1] * 10.0);          // wall_clock64 ticks at 100 MHz
-    printf("%-24s %8.3f ms  %9.1f ns of SIMD time per wave-op = %7.1f cycles at the measured %.3f GHz shader clock (3 waves per SIMD)\n", name, ms,
-           ns_per, ns_per * ghz, ghz);
+    printf("%-24s %8.3f ms  %9.1f ns of SIMD time per wave-op = %7.1f cycles at the measured %.3f GHz shader clock (grid of %d waves)\n", name, ms,
+           ns_per, ns_per * ghz, ghz, blocks);
     return 0;
 }
 
@@ -66,6 +66,11 @@ int main() {
         run<0>("ge_madd (mixed add)", d_out, d_in, blocks, 4096);
         run<1>("ge_dbl (no T)", d_out, d_in, blocks, 4096);
         run<2>("ge_dbl (with T)", d_out, d_in, blocks, 4096);
+    }
+    // fewer resident wavefronts: one round of w waves per SIMD (does one wave alone keep the VALU issuing?)
+    for (int w = 1; w <= 3; w++) {
+        printf("-- %d wave(s) per SIMD: ", w);
+        run<0>("ge_madd", d_out, d_in, 1024 * w, 4096);
     }
     return 0;
 }
