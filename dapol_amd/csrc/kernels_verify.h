@@ -12,7 +12,8 @@ struct VerifyState {                 // per proof
     sc y, z, y_inv, x, w, c, a, b, t_x, tau, mu;
     sc rho;                          // weight of this proof in a cross-proof batch (random linear combination)
     sc u[RV_MAX_ROUNDS], u_inv[RV_MAX_ROUNDS];
-    uint32_t ok, pad_[3];
+    uint32_t ok, st_pos, st_pos_begin, pad_;
+    uint64_t st[25];                 // STROBE state after the m commitments (k_rv_absorb_V -> k_rv_transcript)
 };
 struct VerifyArgs {
     RangeArgs R;                     // reuses n, m, N, lgN, TP, B, Vc, dig, P0, P1, PA(=P2), out(=proof words), out_words, seed
@@ -24,10 +25,26 @@ struct VerifyArgs {
     //   ZZ[m]               : z^2 z^j
     sc* tabs;
     int hb, lb, tab_stride;
+    int wave_transcript;             // 1: k_rv_absorb_V has absorbed the commitments, k_rv_transcript resumes from vs.st
 };
 __host__ __device__ inline int rv_tab_entries(int lgN, int m) {
     int lb = lgN / 2, hb = lgN - lb;
     return 2 * (1 << hb) + 2 * (1 << lb) + m;
+}
+// Cross-proof batching appends product tables (k_rvb_tables2) that bring the rho-weighted generator scalars down to one
+// (G side) and two (H side) products per proof and generator:
+//   SHa[h] = -rho a SH[h] | PHb[h] = -rho b YH[h] SH[nh-1-h] | QH[h] = rho YH[h] z^2 z^jh(h) 2^ih(h) | PL[l] = YL[l] SL[nl-1-l] |
+//   QL[l] = YL[l] z^jl(l) 2^il(l) | RZ = rho z,      where the party j = jh + jl and the bit i' = ih + il of position
+//   q = h 2^lb + l split between the halves (see rv_q_split).
+__host__ __device__ inline int rv_tab_entries_rlc(int lgN, int m) {
+    int lb = lgN / 2, hb = lgN - lb;
+    return rv_tab_entries(lgN, m) + 3 * (1 << hb) + 2 * (1 << lb) + 1;
+}
+// Position q = h 2^lb + l of an n-bit, m-party statement: party j = q / n and bit i' = q mod n, as sums of a part that
+// depends on h only and a part that depends on l only.
+__host__ __device__ inline void rv_q_split(int lgn, int lb, int h, int l, int& jh, int& ih, int& jl, int& il) {
+    if (lb >= lgn) { jh = h << (lb - lgn); ih = 0; jl = l >> lgn; il = l & ((1 << lgn) - 1); }
+    else { jh = h >> (lgn - lb); ih = (h & ((1 << (lgn - lb)) - 1)) << lb; jl = 0; il = l; }
 }
 
 __device__ __forceinline__ bool words_canonical_scalar(const uint32_t* w) {   // w < l
@@ -44,6 +61,118 @@ __device__ __forceinline__ bool words_zero(const uint32_t* w) {
     return o == 0;
 }
 
+// V0 (many parties): the m commitments, absorbed by ONE WAVEFRONT per proof.
+// The replay below keeps one lane per proof -- right for inclusion proofs (m = 32, tens of thousands of proofs), but a
+// 1,024-party proof appends 1,024 x 41 bytes = 253 STROBE blocks before its first challenge, and a lane needs ~12,000
+// instructions per Keccak-f[1600]: 17 ms of pure latency for configs[4] however small the batch.  Two observations
+// make this phase parallel:
+//  * nothing in it squeezes, so its byte stream is a closed-form function of the offset k: V number j = k / 41
+//    contributes  [pos_begin, M|A, 'V', LE32(32), pos_begin', A, 32 bytes]  (merlin_frame + strobe_begin_op above), and the
+//    two position bytes follow from k alone: STROBE sets pos_begin = pos + 1 at a begin_op and clears it in run_f, i.e.
+//    old_begin(k) = ((pos0 + k_prev) mod 166) + 1 if k_prev and k fall into the same 166-byte block, else 0.
+//    Every lane therefore assembles its own 8 bytes of a block without looking at any other;
+//  * the permutation runs with one 64-bit state word per lane (lane = x + 5 y): theta, rho/pi and chi are nine lane
+//    permutations (ds_bpermute) and a dozen ALU operations per round instead of ~500.
+// The state it leaves in vs.st / st_pos / st_pos_begin is bit for bit what the lane-per-proof loop would hold.
+__device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) {
+    uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src, 64), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+struct KeccakLanes {                 // per-lane source lanes of the round's permutations
+    int th1, th2, th3, th4, xm1, xp1, xp2, pi_src, rot;
+};
+__device__ __forceinline__ void keccak_lanes_init(KeccakLanes& K, int l) {
+    const int ROT[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+    if (l >= 25) { K.th1 = K.th2 = K.th3 = K.th4 = K.xm1 = K.xp1 = K.xp2 = K.pi_src = l; K.rot = 0; return; }
+    int x = l % 5, y = l / 5, row = 5 * y;
+    K.th1 = (l + 5) % 25; K.th2 = (l + 10) % 25; K.th3 = (l + 15) % 25; K.th4 = (l + 20) % 25;
+    K.xm1 = row + (x + 4) % 5; K.xp1 = row + (x + 1) % 5; K.xp2 = row + (x + 2) % 5;
+    // pi: B[x'][y'] = rot(A[x][y]) with (x', y') = (y, 2x + 3y): lane (x', y') pulls from y = x', x = 3 (y' - 3 x') mod 5
+    int sy = x, sx = (3 * ((y - 3 * x) % 5 + 5)) % 5;
+    K.pi_src = sx + 5 * sy;
+    int r = 0;
+    for (int i = 0; i < 25; i++) r = (i == l) ? ROT[i] : r;
+    K.rot = r;
+}
+__device__ __forceinline__ uint64_t keccak_f1600_wave(uint64_t a, const KeccakLanes& K, int l) {
+    const uint64_t RC[24] = {0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808Aull, 0x8000000080008000ull,
+                             0x000000000000808Bull, 0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull,
+                             0x000000000000008Aull, 0x0000000000000088ull, 0x0000000080008009ull, 0x000000008000000Aull,
+                             0x000000008000808Bull, 0x800000000000008Bull, 0x8000000000008089ull, 0x8000000000008003ull,
+                             0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800Aull, 0x800000008000000Aull,
+                             0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+    for (int r = 0; r < 24; r++) {
+        uint64_t c = a ^ shfl64(a, K.th1) ^ shfl64(a, K.th2) ^ shfl64(a, K.th3) ^ shfl64(a, K.th4);    // C[x] on every lane of column x
+        uint64_t cm = shfl64(c, K.xm1), cp = shfl64(c, K.xp1);
+        a ^= cm ^ ((cp << 1) | (cp >> 63));
+        uint64_t rt = K.rot ? ((a << K.rot) | (a >> (64 - K.rot))) : a;
+        uint64_t b = shfl64(rt, K.pi_src);
+        uint64_t b1 = shfl64(b, K.xp1), b2 = shfl64(b, K.xp2);
+        a = b ^ (~b1 & b2);
+        if (l == 0) a ^= RC[r];
+    }
+    return a;
+}
+
+enum { RV_V_BYTES = 41 };            // stream bytes per commitment
+__global__ __launch_bounds__(64) void k_rv_absorb_V(VerifyArgs V) {
+    __shared__ uint64_t sh[25];
+    const RangeArgs& A = V.R;
+    const size_t b = blockIdx.x;
+    const int l = threadIdx.x;
+    // the transcript's head is the same for every proof of the call (it depends on n and m only): each lane replays it
+    Strobe s;
+    merlin_init(s, "", 0);
+    merlin_append_bytes(s, "dom-sep", 7, "rangeproof v1", 13);
+    merlin_append_u64(s, "n", 1, (uint64_t)A.n);
+    merlin_append_u64(s, "m", 1, (uint64_t)A.m);
+    const uint32_t pos0 = s.pos, pb0 = s.pos_begin;
+    if (l == 0)
+        for (int i = 0; i < 25; i++) sh[i] = s.s[i];
+    __syncthreads();
+    uint64_t a = l < 25 ? sh[l] : 0;
+    KeccakLanes K;
+    keccak_lanes_init(K, l);
+    const uint8_t* Vb = reinterpret_cast<const uint8_t*>(A.Vc + b * (size_t)A.m * 8);
+    const uint32_t total = RV_V_BYTES * (uint32_t)A.m, end_abs = pos0 + total, nfull = end_abs / STROBE_R;
+    auto old_begin = [&](uint32_t k, uint32_t kp) -> uint32_t {
+        return (pos0 + k) / STROBE_R == (pos0 + kp) / STROBE_R ? (pos0 + kp) % STROBE_R + 1 : 0u;
+    };
+    auto stream_byte = [&](uint32_t k) -> uint32_t {
+        uint32_t j = k / RV_V_BYTES, t = k - j * RV_V_BYTES;
+        if (t >= 9) return Vb[32 * (size_t)j + (t - 9)];
+        if (t == 0) return j == 0 ? pb0 : old_begin(k, k - 34);
+        if (t == 7) return old_begin(k, k - 7);
+        return t == 1 ? (uint32_t)(SF_M | SF_A) : t == 2 ? (uint32_t)'V' : t == 3 ? 32u : t == 8 ? (uint32_t)SF_A : 0u;
+    };
+    auto block_word = [&](uint32_t beta) -> uint64_t {          // this lane's eight bytes of block beta
+        uint64_t w = 0;
+        for (int i = 0; i < 8; i++) {
+            uint32_t q = 8 * (uint32_t)l + i, at = beta * STROBE_R + q;
+            if (q < STROBE_R && at >= pos0 && at < end_abs) w |= (uint64_t)stream_byte(at - pos0) << (8 * i);
+        }
+        return w;
+    };
+    for (uint32_t beta = 0; beta < nfull; beta++) {
+        a ^= block_word(beta);
+        if (l == 20) {                                            // run_f: pos_begin at byte 166, 0x04 and 0x80 at byte 167
+            uint32_t k_end = beta * STROBE_R + (STROBE_R - 1) - pos0, je = k_end / RV_V_BYTES, te = k_end - je * RV_V_BYTES;
+            uint32_t kb = RV_V_BYTES * je + (te >= 7 ? 7u : 0u), ab = pos0 + kb;
+            uint32_t pbe = ab >= beta * STROBE_R ? ab % STROBE_R + 1 : (beta == 0 ? pb0 : 0u);
+            a ^= ((uint64_t)pbe << 48) | (0x84ull << 56);
+        }
+        a = keccak_f1600_wave(a, K, l);
+    }
+    a ^= block_word(nfull);                                       // the bytes after the last permutation
+    VerifyState& vs = V.vs[b];
+    if (l < 25) vs.st[l] = a;
+    if (l == 0) {
+        uint32_t kb = RV_V_BYTES * ((uint32_t)A.m - 1) + 7;       // the last begin_op
+        vs.st_pos = end_abs % STROBE_R;
+        vs.st_pos_begin = (pos0 + kb) / STROBE_R == nfull ? (pos0 + kb) % STROBE_R + 1 : 0u;
+    }
+}
+
 // V1: parse + replay the transcript (lane per proof).
 __global__ __launch_bounds__(64) void k_rv_transcript(VerifyArgs V) {
     const RangeArgs& A = V.R;
@@ -54,13 +183,19 @@ __global__ __launch_bounds__(64) void k_rv_transcript(VerifyArgs V) {
     bool ok = true;
     uint32_t w8[8];
     Strobe s;
-    merlin_init(s, "", 0);
-    merlin_append_bytes(s, "dom-sep", 7, "rangeproof v1", 13);
-    merlin_append_u64(s, "n", 1, (uint64_t)A.n);
-    merlin_append_u64(s, "m", 1, (uint64_t)A.m);
-    for (int j = 0; j < A.m; j++) {
-        ld8(w8, A.Vc + (b * A.m + j) * 8);
-        merlin_append_words(s, "V", 1, w8, 8);
+    if (V.wave_transcript) {                                     // k_rv_absorb_V has done the head and the commitments
+        for (int i = 0; i < 25; i++) s.s[i] = vs.st[i];
+        s.pos = vs.st_pos;
+        s.pos_begin = vs.st_pos_begin;
+    } else {
+        merlin_init(s, "", 0);
+        merlin_append_bytes(s, "dom-sep", 7, "rangeproof v1", 13);
+        merlin_append_u64(s, "n", 1, (uint64_t)A.n);
+        merlin_append_u64(s, "m", 1, (uint64_t)A.m);
+        for (int j = 0; j < A.m; j++) {
+            ld8(w8, A.Vc + (b * A.m + j) * 8);
+            merlin_append_words(s, "V", 1, w8, 8);
+        }
     }
     ld8(w8, pr);      ok &= !words_zero(w8); merlin_append_words(s, "A", 1, w8, 8);      // validate_and_append_point
     ld8(w8, pr + 8);  ok &= !words_zero(w8); merlin_append_words(s, "S", 1, w8, 8);
@@ -80,13 +215,34 @@ __global__ __launch_bounds__(64) void k_rv_transcript(VerifyArgs V) {
     challenge_scalar(vs.w, s, "w", 1);
     merlin_append_bytes(s, "dom-sep", 7, "ipp v1", 6);
     merlin_append_u64(s, "n", 1, (uint64_t)A.N);
+    // u_k^-1 and y^-1 by Montgomery's trick: one inversion (~265 products) instead of lgN + 1.  The running products wait in
+    // the u_inv slots.  A zero challenge (probability 2^-252) would zero every inverse, so that case inverts one by one.
+    sc run = vs.y;
+    bool any_zero = sc_is_zero(vs.y);
     for (int k = 0; k < A.lgN; k++) {
         ld8(w8, pr + 56 + 16 * k);     ok &= !words_zero(w8); merlin_append_words(s, "L", 1, w8, 8);
         ld8(w8, pr + 56 + 16 * k + 8); ok &= !words_zero(w8); merlin_append_words(s, "R", 1, w8, 8);
-        challenge_scalar(vs.u[k], s, "u", 1);
-        sc_invert_mont(vs.u_inv[k], vs.u[k]);
+        sc u;
+        challenge_scalar(u, s, "u", 1);
+        vs.u[k] = u;
+        any_zero |= sc_is_zero(u);
+        vs.u_inv[k] = run;                                       // y u_0 ... u_(k-1)
+        sc_montmul(run, run, u);
     }
-    sc_invert_mont(vs.y_inv, vs.y);
+    if (any_zero) {
+        for (int k = 0; k < A.lgN; k++) sc_invert_mont(vs.u_inv[k], vs.u[k]);
+        sc_invert_mont(vs.y_inv, vs.y);
+    } else {
+        sc inv;
+        sc_invert_mont(inv, run);
+        for (int k = A.lgN - 1; k >= 0; k--) {
+            sc t = vs.u_inv[k], u = vs.u[k];
+            sc_montmul(t, t, inv);                               // (y u_0 .. u_(k-1)) / (y u_0 .. u_k) = 1 / u_k
+            vs.u_inv[k] = t;
+            sc_montmul(inv, inv, u);
+        }
+        vs.y_inv = inv;
+    }
     sc_to_mont(vs.t_x, tx); sc_to_mont(vs.tau, tau); sc_to_mont(vs.mu, mu); sc_to_mont(vs.a, aw); sc_to_mont(vs.b, bw);
     // batching scalar c: Scalar::random(rng) in the crate; here seed mode, domain 3, keyed by the proof's position
     uint32_t seed[8], wide[16];
@@ -106,9 +262,9 @@ __global__ __launch_bounds__(64) void k_rv_tables(VerifyArgs V) {
     const int bpp = (V.tab_stride + 63) >> 6;
     size_t b = blockIdx.x / bpp;
     int e = (int)(blockIdx.x % bpp) * 64 + threadIdx.x;
-    if (e >= V.tab_stride) return;
-    const VerifyState& vs = V.vs[b];
     const int nh = 1 << V.hb, nl = 1 << V.lb;
+    if (e >= 2 * (nh + nl) + A.m) return;               // (a batch's stride also holds the product tables of k_rvb_tables2)
+    const VerifyState& vs = V.vs[b];
     sc r;
     if (e < nh + nl) {                                  // products of u_k^{+-1}: MSB of i <-> first round
         bool hi = e < nh;
@@ -311,20 +467,100 @@ struct RlcArgs {
     uint32_t* flag;            // [0] = 1: the combined check is the identity; [1] = 1: some point failed to decode
 };
 
+// The product tables of the batch (layout: rv_tab_entries_rlc).  Lane per entry; grid = B * ceil(extra / 64) blocks; runs
+// after k_rv_tables, whose entries it multiplies together.
+__global__ __launch_bounds__(64) void k_rvb_tables2(RlcArgs R) {
+    const VerifyArgs& V = R.V;
+    const RangeArgs& A = V.R;
+    const int nh = 1 << V.hb, nl = 1 << V.lb, base = 2 * (nh + nl) + A.m, extra = 3 * nh + 2 * nl + 1;
+    const int bpp = (extra + 63) >> 6;
+    size_t b = blockIdx.x / bpp;
+    int e = (int)(blockIdx.x % bpp) * 64 + threadIdx.x;
+    if (e >= extra) return;
+    const VerifyState& vs = V.vs[b];
+    sc* T = V.tabs + b * (size_t)V.tab_stride;
+    const sc *SH = T, *SL = T + nh, *YH = T + nh + nl, *YL = T + 2 * nh + nl, *ZZ = T + 2 * (nh + nl);
+    const int lgn = 31 - __clz(A.n);
+    int jh, ih, jl, il;
+    sc r, t;
+    if (e < nh) {                                                // SHa
+        ld_sc(t, SH + e);
+        sc_montmul(r, vs.rho, vs.a);
+        sc_montmul(r, r, t);
+        sc_neg(r, r);
+    } else if (e < 2 * nh) {                                     // PHb
+        int h = e - nh;
+        ld_sc(r, YH + h);
+        ld_sc(t, SH + (nh - 1 - h));
+        sc_montmul(r, r, t);
+        sc_montmul(t, vs.rho, vs.b);
+        sc_montmul(r, r, t);
+        sc_neg(r, r);
+    } else if (e < 3 * nh) {                                     // QH
+        int h = e - 2 * nh;
+        rv_q_split(lgn, V.lb, h, 0, jh, ih, jl, il);
+        ld_sc(r, YH + h);
+        ld_sc(t, ZZ + jh);
+        sc_montmul(r, r, t);
+        sc_from_u64_mont(t, 1ull << ih);
+        sc_montmul(r, r, t);
+        sc_montmul(r, r, vs.rho);
+    } else if (e < 3 * nh + nl) {                                // PL
+        int l = e - 3 * nh;
+        ld_sc(r, YL + l);
+        ld_sc(t, SL + (nl - 1 - l));
+        sc_montmul(r, r, t);
+    } else if (e < 3 * nh + 2 * nl) {                            // QL
+        int l = e - 3 * nh - nl;
+        rv_q_split(lgn, V.lb, 0, l, jh, ih, jl, il);
+        ld_sc(r, YL + l);
+        sc_pow_mont(t, vs.z, (uint32_t)jl);
+        sc_montmul(r, r, t);
+        sc_from_u64_mont(t, 1ull << il);
+        sc_montmul(r, r, t);
+    } else {                                                     // RZ
+        sc_montmul(r, vs.rho, vs.z);
+    }
+    st_sc(T + base + e, r);
+}
 // rho_p-weighted generator scalars, summed over the proofs p = g (mod G) of one group.  grid = (TP/64) * G blocks.
+//   G side: rho (-z - a s_i)                        = SHa[i_hi] SL[i_lo] - RZ
+//   H side: rho (z + y^-q (z^2 z^j 2^i' - b s_(N-1-q))) = QH[q_hi] QL[q_lo] + PHb[q_hi] PL[q_lo] + RZ
 __global__ __launch_bounds__(64) void k_rvb_gh_partial(RlcArgs R) {
-    const RangeArgs& A = R.V.R;
+    const VerifyArgs& V = R.V;
+    const RangeArgs& A = V.R;
     int nch = A.TP >> 6;
-    int g = blockIdx.x / nch, ch = blockIdx.x % nch, l = threadIdx.x, side = l >> 5, q = 32 * ch + (l & 31), pos = 64 * ch + l;
+    int g = blockIdx.x / nch, ch = blockIdx.x % nch, l = threadIdx.x, side = l >> 5, q = 32 * ch + (l & 31);
+    if (nch > 1) {                                               // N >= 64: a wavefront works on ONE side (64 positions of it), so
+        side = ch & 1;                                           // the one-product and the two-product branch never share a wave
+        q = 64 * (ch >> 1) + l;
+    }
+    const int pos = 64 * (q >> 5) + (q & 31) + 32 * side;
+    const int nh = 1 << V.hb, nl = 1 << V.lb, base = 2 * (nh + nl) + A.m;
+    const int qh = q >> V.lb, ql = q & (nl - 1);
     sc acc;
     sc_zero(acc);
     if (q < A.N) {
         for (size_t p = g; p < A.B; p += R.G) {
-            const VerifyState& vs = R.V.vs[p];
-            if (!vs.ok) continue;
-            sc r;
-            rv_gh_scalar(r, R.V, p, side, q);
-            sc_montmul(r, r, vs.rho);
+            if (!V.vs[p].ok) continue;
+            const sc* T = V.tabs + p * (size_t)V.tab_stride;
+            sc x, y, r, rz;
+            ld_sc(rz, T + base + 3 * nh + 2 * nl);
+            if (side == 0) {
+                ld_sc(x, T + base + qh);                         // SHa
+                ld_sc(y, T + nh + ql);                           // SL
+                sc_montmul(r, x, y);
+                sc_sub(r, r, rz);
+            } else {
+                ld_sc(x, T + base + 2 * nh + qh);                // QH
+                ld_sc(y, T + base + 3 * nh + nl + ql);           // QL
+                sc_montmul(r, x, y);
+                ld_sc(x, T + base + nh + qh);                    // PHb
+                ld_sc(y, T + base + 3 * nh + ql);                // PL
+                sc_montmul(x, x, y);
+                sc_add(r, r, x);
+                sc_add(r, r, rz);
+            }
             sc_add(acc, acc, r);
         }
     }

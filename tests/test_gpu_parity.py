@@ -796,6 +796,47 @@ def test_config4_shape_1024_party_verification(hip_lib):
     assert list(ctx.range_verify_batch(64, m, proofs, V2, verify_seed=SEED)) == [1, 1, 0]
 
 
+@pytest.mark.parametrize("n_bits,m,b", [(64, 32, 9), (64, 1, 5), (8, 2, 4), (16, 4, 70), (32, 8, 3), (64, 16, 6), (8, 32, 5)])
+def test_wavefront_transcript_equals_lane_transcript(gpu_ctx, n_bits, m, b):
+    """k_rv_absorb_V (one wavefront per proof absorbs the m commitments, the default for m >= 256) must leave the STROBE
+    state the lane-per-proof replay leaves: every honest proof verifies on either path (a single differing transcript byte
+    would change y and fail it), and tampered proofs / swapped commitments get the same verdicts -- with and without
+    cross-proof batching.  The shapes put the commitment stream at different offsets of the 166-byte STROBE block."""
+    import os
+    rng = np.random.default_rng(7 * n_bits + m)
+    v = rng.integers(0, 2**n_bits if n_bits < 64 else 2**63, size=(b, m), dtype=np.uint64)
+    r = rng.integers(0, 256, size=(b, m, 32), dtype=np.uint8)
+    r[:, :, 31] &= 0x0F
+    proofs = gpu_ctx.range_prove_batch(n_bits, m, v, r, nonce_seed=SEED, stream_id=np.arange(b, dtype=np.uint64))
+    C, _ = gpu_ctx.commit_hash_batch(v.reshape(-1), r.reshape(-1, 32))
+    V = C.reshape(b, m, 32)
+
+    def verdicts(p, vv):
+        out = []
+        try:
+            for wave in ("1", "0"):
+                for rlc in (None, "1"):
+                    os.environ["DAPOL_VERIFY_WAVE_TRANSCRIPT"] = wave
+                    if rlc:
+                        os.environ["DAPOL_VERIFY_NO_RLC"] = rlc
+                    else:
+                        os.environ.pop("DAPOL_VERIFY_NO_RLC", None)
+                    out.append(list(gpu_ctx.range_verify_batch(n_bits, m, p, vv, verify_seed=SEED)))
+        finally:
+            os.environ.pop("DAPOL_VERIFY_WAVE_TRANSCRIPT", None)
+            os.environ.pop("DAPOL_VERIFY_NO_RLC", None)
+        assert all(o == out[0] for o in out), out
+        return out[0]
+
+    assert verdicts(proofs, V) == [1] * b
+    bad = proofs.copy()
+    bad[b - 1, 70] ^= 2                                                         # T_1
+    assert verdicts(bad, V) == [1] * (b - 1) + [0]
+    V2 = V.copy()
+    V2[0, m - 1, 3] ^= 1                                                        # the last commitment byte stream of proof 0
+    assert verdicts(proofs, V2) == [0] + [1] * (b - 1)
+
+
 @pytest.mark.parametrize("n_bits,m,b", [(64, 32, 50), (64, 1, 200), (16, 4, 70), (8, 2, 3)])
 def test_cross_proof_batching_gives_the_per_proof_verdicts(gpu_ctx, n_bits, m, b):
     """The verifier checks a batch through one random linear combination and falls back to the per-proof check when

@@ -30,9 +30,11 @@ t_prove = time.perf_counter() - t0
 C, _ = ctx.commit_hash_batch(v.reshape(-1), r.reshape(-1, 32))
 Vs = C.reshape(B, m, 32)
 ok = ctx.range_verify_batch(n, m, proofs[:2], Vs[:2], verify_seed=seed)       # warm-up
-t0 = time.perf_counter()
-ok = ctx.range_verify_batch(n, m, proofs, Vs, verify_seed=seed)
-t_verify = time.perf_counter() - t0
+t_verify = 1e9
+for _ in range(3):                                                              # best of three
+    t0 = time.perf_counter()
+    ok = ctx.range_verify_batch(n, m, proofs, Vs, verify_seed=seed)
+    t_verify = min(t_verify, time.perf_counter() - t0)
 bad = proofs.copy()
 bad[0, 100] ^= 1
 ok_bad = ctx.range_verify_batch(n, m, bad[:2], Vs[:2], verify_seed=seed)
