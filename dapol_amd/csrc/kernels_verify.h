@@ -10,6 +10,7 @@ namespace dapol {
 enum { RV_MAX_ROUNDS = 20 };
 struct VerifyState {                 // per proof
     sc y, z, y_inv, x, w, c, a, b, t_x, tau, mu;
+    sc ym1_inv, zm1_inv;             // 1 / (y - 1), 1 / (z - 1) for the closed-form power sums (0 when y or z is 1)
     sc rho;                          // weight of this proof in a cross-proof batch (random linear combination)
     sc u[RV_MAX_ROUNDS], u_inv[RV_MAX_ROUNDS];
     uint32_t ok, st_pos, st_pos_begin, pad_;
@@ -135,21 +136,29 @@ __global__ __launch_bounds__(64) void k_rv_absorb_V(VerifyArgs V) {
     keccak_lanes_init(K, l);
     const uint8_t* Vb = reinterpret_cast<const uint8_t*>(A.Vc + b * (size_t)A.m * 8);
     const uint32_t total = RV_V_BYTES * (uint32_t)A.m, end_abs = pos0 + total, nfull = end_abs / STROBE_R;
-    auto old_begin = [&](uint32_t k, uint32_t kp) -> uint32_t {
-        return (pos0 + k) / STROBE_R == (pos0 + kp) / STROBE_R ? (pos0 + kp) % STROBE_R + 1 : 0u;
-    };
-    auto stream_byte = [&](uint32_t k) -> uint32_t {
-        uint32_t j = k / RV_V_BYTES, t = k - j * RV_V_BYTES;
-        if (t >= 9) return Vb[32 * (size_t)j + (t - 9)];
-        if (t == 0) return j == 0 ? pb0 : old_begin(k, k - 34);
-        if (t == 7) return old_begin(k, k - 7);
-        return t == 1 ? (uint32_t)(SF_M | SF_A) : t == 2 ? (uint32_t)'V' : t == 3 ? 32u : t == 8 ? (uint32_t)SF_A : 0u;
-    };
-    auto block_word = [&](uint32_t beta) -> uint64_t {          // this lane's eight bytes of block beta
+    // This lane's eight bytes of block beta, without branches: in-block position q = 8 l + i  <->  stream offset
+    // k = 166 beta + q - pos0  <->  commitment j = k / 41, byte t = k mod 41 of its record.  The two position bytes: the
+    // begin_op they belong to follows the previous one by d = 34 (t = 0) or 7 (t = 7) bytes, so STROBE's old pos_begin is
+    // (q - d) + 1 when that one lies in the same block (q >= d) and 0 after a run_f; the very first record inherits pb0.
+    auto block_word = [&](uint32_t beta) -> uint64_t {
+        const uint32_t q0 = 8 * (uint32_t)l, at0 = beta * STROBE_R + q0;
+        uint32_t k0 = at0 >= pos0 ? at0 - pos0 : 0u;             // (clamped: bytes before pos0 are masked out below)
+        uint32_t j = k0 / RV_V_BYTES, t = k0 - j * RV_V_BYTES;
+        if (at0 < pos0) { j = 0; t = 0; }
         uint64_t w = 0;
         for (int i = 0; i < 8; i++) {
-            uint32_t q = 8 * (uint32_t)l + i, at = beta * STROBE_R + q;
-            if (q < STROBE_R && at >= pos0 && at < end_abs) w |= (uint64_t)stream_byte(at - pos0) << (8 * i);
+            const uint32_t q = q0 + i, at = at0 + i;
+            const bool live = q < STROBE_R && at >= pos0 && at < end_abs;
+            const uint32_t jc = j < (uint32_t)A.m ? j : (uint32_t)A.m - 1, tc = t >= 9 ? t - 9 : 0u;
+            const uint32_t data = Vb[32 * (size_t)jc + tc];
+            const uint32_t ob0 = j == 0 ? pb0 : (q >= 34 ? q - 33 : 0u), ob7 = q >= 7 ? q - 6 : 0u;
+            const uint32_t fixed = t == 0 ? ob0 : t == 7 ? ob7 : t == 8 ? (uint32_t)SF_A : ((0x20561200u >> (8 * (t & 3))) & (t < 4 ? 0xffu : 0u));
+            const uint32_t byte = t >= 9 ? data : fixed;
+            w |= (uint64_t)(live ? byte : 0u) << (8 * i);
+            if (live) {                                          // advance (j, t) only along the stream
+                t++;
+                if (t == RV_V_BYTES) { t = 0; j++; }
+            }
         }
         return w;
     };
@@ -215,10 +224,16 @@ __global__ __launch_bounds__(64) void k_rv_transcript(VerifyArgs V) {
     challenge_scalar(vs.w, s, "w", 1);
     merlin_append_bytes(s, "dom-sep", 7, "ipp v1", 6);
     merlin_append_u64(s, "n", 1, (uint64_t)A.N);
-    // u_k^-1 and y^-1 by Montgomery's trick: one inversion (~265 products) instead of lgN + 1.  The running products wait in
-    // the u_inv slots.  A zero challenge (probability 2^-252) would zero every inverse, so that case inverts one by one.
-    sc run = vs.y;
-    bool any_zero = sc_is_zero(vs.y);
+    // y^-1, (y-1)^-1, (z-1)^-1 and the u_k^-1 by Montgomery's trick: one inversion (~265 products) instead of lgN + 3.  The
+    // running products of the u_k wait in the u_inv slots.  A zero among them (probability 2^-250) would zero every inverse,
+    // so that case inverts one by one.
+    sc one, ym1, zm1, p_zm1, run;
+    sc_one_mont(one);
+    sc_sub(ym1, vs.y, one);
+    sc_sub(zm1, vs.z, one);
+    sc_montmul(p_zm1, vs.y, ym1);                                // running product before z - 1
+    sc_montmul(run, p_zm1, zm1);
+    bool any_zero = sc_is_zero(vs.y) | sc_is_zero(ym1) | sc_is_zero(zm1);
     for (int k = 0; k < A.lgN; k++) {
         ld8(w8, pr + 56 + 16 * k);     ok &= !words_zero(w8); merlin_append_words(s, "L", 1, w8, 8);
         ld8(w8, pr + 56 + 16 * k + 8); ok &= !words_zero(w8); merlin_append_words(s, "R", 1, w8, 8);
@@ -226,21 +241,26 @@ __global__ __launch_bounds__(64) void k_rv_transcript(VerifyArgs V) {
         challenge_scalar(u, s, "u", 1);
         vs.u[k] = u;
         any_zero |= sc_is_zero(u);
-        vs.u_inv[k] = run;                                       // y u_0 ... u_(k-1)
+        vs.u_inv[k] = run;                                       // y (y-1) (z-1) u_0 ... u_(k-1)
         sc_montmul(run, run, u);
     }
     if (any_zero) {
         for (int k = 0; k < A.lgN; k++) sc_invert_mont(vs.u_inv[k], vs.u[k]);
         sc_invert_mont(vs.y_inv, vs.y);
+        sc_invert_mont(vs.ym1_inv, ym1);
+        sc_invert_mont(vs.zm1_inv, zm1);
     } else {
-        sc inv;
+        sc inv, t;
         sc_invert_mont(inv, run);
         for (int k = A.lgN - 1; k >= 0; k--) {
-            sc t = vs.u_inv[k], u = vs.u[k];
-            sc_montmul(t, t, inv);                               // (y u_0 .. u_(k-1)) / (y u_0 .. u_k) = 1 / u_k
+            sc u = vs.u[k];
+            t = vs.u_inv[k];
+            sc_montmul(t, t, inv);                               // (y .. u_(k-1)) / (y .. u_k) = 1 / u_k
             vs.u_inv[k] = t;
             sc_montmul(inv, inv, u);
         }
+        sc_montmul(t, inv, p_zm1); vs.zm1_inv = t;  sc_montmul(inv, inv, zm1);
+        sc_montmul(t, inv, vs.y);  vs.ym1_inv = t;  sc_montmul(inv, inv, ym1);
         vs.y_inv = inv;
     }
     sc_to_mont(vs.t_x, tx); sc_to_mont(vs.tau, tau); sc_to_mont(vs.mu, mu); sc_to_mont(vs.a, aw); sc_to_mont(vs.b, bw);
@@ -400,15 +420,19 @@ __device__ __forceinline__ void rv_base_scalars(sc& bb, sc& bs, const VerifyStat
     sc one, zz, sumy, py, sumz, pz, sum2, delta, s1, s2;
     sc_one_mont(one);
     sc_montmul(zz, vs.z, vs.z);
-    // sum_{i<N} y^i = (y^N - 1) / (y - 1)   (N a power of two: lgN squarings; y = 1 has probability 2^-252)
+    // sum_{i<N} y^i = (y^N - 1) / (y - 1) and sum_{j<m} z^j = (z^m - 1) / (z - 1): N and m are powers of two, so lg squarings
+    // each; the inverses come from the transcript replay's batch inversion (y = 1 or z = 1 has probability 2^-252).
+    sc ym1, zm1;
     py = vs.y;
     for (int i = 0; i < A.lgN; i++) sc_montmul(py, py, py);
-    sc ym1, ym1_inv;
     sc_sub(ym1, vs.y, one);
     if (sc_is_zero(ym1)) { sc_from_u64_mont(sumy, (uint64_t)A.N); }
-    else { sc_invert_mont(ym1_inv, ym1); sc_sub(py, py, one); sc_montmul(sumy, py, ym1_inv); }
-    sc_zero(sumz); pz = one;
-    for (int j = 0; j < A.m; j++) { sc_add(sumz, sumz, pz); sc_montmul(pz, pz, vs.z); }
+    else { sc_sub(py, py, one); sc_montmul(sumy, py, vs.ym1_inv); }
+    pz = vs.z;
+    for (int mm = A.m; mm > 1; mm >>= 1) sc_montmul(pz, pz, pz);
+    sc_sub(zm1, vs.z, one);
+    if (sc_is_zero(zm1)) { sc_from_u64_mont(sumz, (uint64_t)A.m); }
+    else { sc_sub(pz, pz, one); sc_montmul(sumz, pz, vs.zm1_inv); }
     sc_zero(sum2);
     { sc p2s = one; for (int i = 0; i < A.n; i++) { sc_add(sum2, sum2, p2s); sc_add(p2s, p2s, p2s); } }
     sc_sub(s1, vs.z, zz); sc_montmul(delta, s1, sumy);
