@@ -194,8 +194,8 @@ def main():
                 "kernel": "k_rp_msm", "launches": int(stats.msm_launches), "avg_launch_ms": msm_avg_ms,
                 "algorithmic_bytes_per_entity": ab,
                 "note": "achieved/frac use the ALGORITHMIC bytes of SURVEY 8d (6,384 B per entity); the kernel itself is integer-VALU "
-                        "bound (255-bit modular multiply-adds) and deliberately spends HBM bandwidth on wide (17-bit) window tables: see "
-                        "traffic (measured HBM bytes per launch) and DESIGN.md section 5"}
+                        "bound (255-bit modular multiply-adds) at the socket power cap and deliberately spends HBM bandwidth on wide "
+                        "(17-bit) window tables: see traffic (measured HBM bytes per launch), valu_roof and DESIGN.md sections 5 and 8"}
     # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; tools/pmc_summary.py),
     # measured on full 73,728-proof launches of this kernel; only quoted when this run's launches have that size too.
     pmc = os.path.join(ROOT, "profiles", "msm_pmc.json")
@@ -210,6 +210,13 @@ def main():
             # profiles/r01b_ubench_madd.txt) issue at 4,350 cycles / 1,075 instructions = 4.05 cycles per wave instruction.
             if pj.get("cycles_per_valu_inst_per_simd"):
                 roofline["valu_issue_frac"] = 4.05 / pj["cycles_per_valu_inst_per_simd"]
+        except Exception:
+            pass
+    # the binding roof in its own units (register-only cost of the kernel's point additions, clocks, socket power)
+    vr = os.path.join(ROOT, "profiles", "valu_roof.json")
+    if roofline.get("traffic") is not None and os.path.exists(vr):
+        try:
+            roofline["valu_roof"] = {k: v for k, v in json.load(open(vr)).items() if k != "source"}
         except Exception:
             pass
     cpu = None
