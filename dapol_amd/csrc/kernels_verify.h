@@ -7,12 +7,13 @@
 
 namespace dapol {
 
-enum { RV_MAX_ROUNDS = 20 };
+enum { RV_MAX_ROUNDS = 20, RV_MAX_LGM = 11 };
 struct VerifyState {                 // per proof
     sc y, z, y_inv, x, w, c, a, b, t_x, tau, mu;
     sc ym1_inv, zm1_inv;             // 1 / (y - 1), 1 / (z - 1) for the closed-form power sums (0 when y or z is 1)
     sc rho;                          // weight of this proof in a cross-proof batch (random linear combination)
     sc u[RV_MAX_ROUNDS], u_inv[RV_MAX_ROUNDS];
+    sc ypow[RV_MAX_ROUNDS], zpow[RV_MAX_LGM];   // y^-(2^k), z^(2^k): a table entry is the product over the set bits of its exponent
     uint32_t ok, st_pos, st_pos_begin, pad_;
     uint64_t st[25];                 // STROBE state after the m commitments (k_rv_absorb_V -> k_rv_transcript)
 };
@@ -263,6 +264,12 @@ __global__ __launch_bounds__(64) void k_rv_transcript(VerifyArgs V) {
         sc_montmul(t, inv, vs.y);  vs.ym1_inv = t;  sc_montmul(inv, inv, ym1);
         vs.y_inv = inv;
     }
+    {   // power-of-two powers for k_rv_tables
+        sc p = vs.y_inv;
+        for (int k = 0; k < A.lgN; k++) { vs.ypow[k] = p; sc_montsq(p, p); }
+        p = vs.z;
+        for (int k = 0; k < RV_MAX_LGM; k++) { vs.zpow[k] = p; sc_montsq(p, p); }
+    }
     sc_to_mont(vs.t_x, tx); sc_to_mont(vs.tau, tau); sc_to_mont(vs.mu, mu); sc_to_mont(vs.a, aw); sc_to_mont(vs.b, bw);
     // batching scalar c: Scalar::random(rng) in the crate; here seed mode, domain 3, keyed by the proof's position
     uint32_t seed[8], wide[16];
@@ -294,14 +301,17 @@ __global__ __launch_bounds__(64) void k_rv_tables(VerifyArgs V) {
             bool bit = (x >> (nbits - 1 - k)) & 1;
             sc_montmul(r, r, bit ? vs.u[k0 + k] : vs.u_inv[k0 + k]);
         }
-    } else if (e < 2 * (nh + nl)) {
+    } else if (e < 2 * (nh + nl)) {                     // y^-(x 2^lb) | y^-x: product of the y^-(2^k) of the set bits
         int x = e - nh - nl;
-        sc_pow_mont(r, vs.y_inv, x < nh ? (uint32_t)x << V.lb : (uint32_t)(x - nh));
-    } else {
-        sc zz;
-        sc_montmul(zz, vs.z, vs.z);
-        sc_pow_mont(r, vs.z, (uint32_t)(e - 2 * (nh + nl)));
-        sc_montmul(r, r, zz);
+        uint32_t ex = x < nh ? (uint32_t)x << V.lb : (uint32_t)(x - nh);
+        sc_one_mont(r);
+        for (int k = 0; ex; k++, ex >>= 1)
+            if (ex & 1) sc_montmul(r, r, vs.ypow[k]);
+    } else {                                            // z^2 z^j
+        uint32_t ex = (uint32_t)(e - 2 * (nh + nl));
+        r = vs.zpow[1];
+        for (int k = 0; ex; k++, ex >>= 1)
+            if (ex & 1) sc_montmul(r, r, vs.zpow[k]);
     }
     st_sc(V.tabs + b * (size_t)V.tab_stride + e, r);
 }
