@@ -486,6 +486,10 @@ __global__ __launch_bounds__(64) void k_rv_finish(VerifyArgs V, TableView tbl) {
 // per-point 4-bit tables (the prover's tail kernel) instead of K separate double-and-add ladders.  A batch that passes
 // means every proof passes (error 2^-250); a batch that fails is re-checked proof by proof by the path above, so the
 // verdicts are always the per-proof ones.
+// Bucket method: 11-bit signed windows.  23 x 11 = 253 bits exactly, so there is no carry-only top window -- with 12 bits the
+// 22nd window held nothing but the recoding carry and its bucket 1 half of all points (one 200 ms bucket).  The top window
+// keeps its carry (sc_recode_w): its digit is 0..1024 (bit 252 of a canonical scalar comes with zeros below it).
+enum { RVP_C = 11, RVP_NW = 23, RVP_NB = 1 << (RVP_C - 1), RVP_S = 16 };   // window bits, windows, buckets per window, lanes per bucket
 enum { PT_WBITS = 4, PT_NWIN = 253 / PT_WBITS + 1, PT_ENTRIES = (1 << (PT_WBITS - 1)) + 1, PT_ROW_WORDS = PT_ENTRIES * 32 };
 struct RlcArgs {
     VerifyArgs V;              // the batch: V.R.B proofs; V.R.dig / P0 / P1 / nsplit serve the ONE generator MSM
@@ -499,6 +503,15 @@ struct RlcArgs {
     dig_t* dig2;               // [PT_NWIN][TP2]
     int32_t* Q0; int32_t* Q1;  // [ns2][40] partial sums of the point MSM
     uint32_t* flag;            // [0] = 1: the combined check is the identity; [1] = 1: some point failed to decode
+    // Bucket method for large batches (k_rvp_*): the points as affine niels, their 11-bit signed digits, and per window the
+    // points sorted by |digit| (counting sort: hist -> offs -> cursor)
+    int32_t* pN;               // [npts][32]
+    int16_t* pdig;             // [RVP_NW][npts]
+    uint32_t* psorted;         // [RVP_NW][npts]   point index | sign << 31
+    uint32_t* phist;           // [RVP_NW][RVP_NB + 1]   (then offs and cursor, same shape)
+    uint32_t* poffs;
+    uint32_t* pcursor;
+    int32_t* pbsum;            // [RVP_NW][RVP_NB][40]   bucket sums
 };
 
 // The product tables of the batch (layout: rv_tab_entries_rlc).  Lane per entry; grid = B * ceil(extra / 64) blocks; runs
@@ -652,6 +665,134 @@ __global__ __launch_bounds__(64) void k_rvb_points(RlcArgs R) {
     sc_recode_w(PT_WBITS, PT_NWIN, c, [&](int i, int digit) { d[(size_t)i * TP2] = (dig_t)digit; });
     st_p3(row, pt);
     build_niels_row<PT_ENTRIES>(row);
+}
+// ------------------------------------------------------------------------------------------------------------------
+// The batch's own points by the bucket method.  With per-point tables (k_rvb_points + Straus) a point costs ~80 additions:
+// 8 for its table, the normalisation, and one per 4-bit window.  A batch is ONE sum over all its points -- 1.08 M of them
+// for 1,024 proofs x 1,024 parties, 3 M for 65,536 inclusion proofs -- which is where Pippenger's method pays: per
+// 11-bit window every point is added once into the bucket of its digit (23 additions per point in total), and the 1,024
+// buckets of a window are combined with running sums.  Steps: decode + digits + histogram (lane per point) -> offsets
+// (wave per window) -> scatter (counting sort by |digit|) -> bucket sums (8 lanes per bucket, tree-reduced) -> window sums
+// (wave per window: sum_k k B_k by running sums over 16-bucket segments, then 2^(11 w)).  The order inside a bucket is
+// whatever the atomics give; the sum -- and so the verdict -- does not depend on it.
+__global__ __launch_bounds__(64) void k_rvp_points(RlcArgs R) {
+    size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (t >= R.npts) return;
+    size_t p = t / R.K;
+    ge_p3 pt;
+    ge_identity(pt);
+    sc sm;
+    sc_zero(sm);
+    if (R.V.vs[p].ok) {
+        uint32_t w8[8];
+        rv_own_point(w8, sm, R.V, p, (int)(t - p * R.K));
+        if (ge_decompress(pt, w8)) sc_montmul(sm, sm, R.V.vs[p].rho);
+        else { atomicOr(&R.flag[1], 1u); ge_identity(pt); sc_zero(sm); }
+    }
+    uint32_t c[8];
+    sc_from_mont(c, sm);
+    const size_t np = R.npts;
+    sc_recode_w(RVP_C, RVP_NW, c, [&](int i, int digit) {
+        R.pdig[(size_t)i * np + t] = (int16_t)digit;
+        if (digit) atomicAdd(&R.phist[(size_t)i * (RVP_NB + 1) + (digit < 0 ? -digit : digit)], 1u);
+    });
+    // affine niels (the decoded point has Z = 1)
+    fe a, b2, c2;
+    fe_addc(a, pt.Y, pt.X);
+    fe_sub(b2, pt.Y, pt.X);
+    fe_carry(b2, b2);
+    fe_mul(c2, pt.T, FE_D2);
+    int32_t* o = R.pN + t * 32;
+    for (int i = 0; i < 10; i++) { o[i] = a.v[i]; o[10 + i] = b2.v[i]; o[20 + i] = c2.v[i]; }
+}
+// offs[w][d] = number of points of window w with 0 < |digit| < d; cursor = offs.  One wavefront per window.
+__global__ __launch_bounds__(64) void k_rvp_scan(RlcArgs R) {
+    __shared__ uint32_t tot[64];
+    const int w = blockIdx.x, l = threadIdx.x, per = (RVP_NB + 1 + 63) / 64;
+    const uint32_t* h = R.phist + (size_t)w * (RVP_NB + 1);
+    int lo = l * per, hi = lo + per < RVP_NB + 1 ? lo + per : RVP_NB + 1;
+    uint32_t sum = 0;
+    for (int i = lo; i < hi; i++) sum += i ? h[i] : 0u;
+    tot[l] = sum;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int i = 0; i < l; i++) base += tot[i];
+    for (int i = lo; i < hi; i++) {
+        R.poffs[(size_t)w * (RVP_NB + 1) + i] = base;
+        R.pcursor[(size_t)w * (RVP_NB + 1) + i] = base;
+        base += i ? h[i] : 0u;
+    }
+}
+__global__ __launch_bounds__(64) void k_rvp_scatter(RlcArgs R) {
+    size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (t >= R.npts) return;
+    const size_t np = R.npts;
+    for (int w = 0; w < RVP_NW; w++) {
+        int d = R.pdig[(size_t)w * np + t];
+        if (!d) continue;
+        uint32_t pos = atomicAdd(&R.pcursor[(size_t)w * (RVP_NB + 1) + (d < 0 ? -d : d)], 1u);
+        R.psorted[(size_t)w * np + pos] = (uint32_t)t | (d < 0 ? 0x80000000u : 0u);
+    }
+}
+// Bucket sums: RVP_S adjacent lanes share a bucket (every RVP_S-th point each), then a tree reduction.  grid = NW * NB * S / 64.
+__global__ __launch_bounds__(64) void k_rvp_buckets(RlcArgs R) {
+    __shared__ int32_t lds[40 * 64];
+    const int l = threadIdx.x;
+    const size_t gid = (size_t)blockIdx.x * 64 + l;
+    const int s = (int)(gid % RVP_S), bidx = (int)((gid / RVP_S) % RVP_NB), w = (int)(gid / ((size_t)RVP_S * RVP_NB));
+    const uint32_t start = R.poffs[(size_t)w * (RVP_NB + 1) + bidx + 1], n = R.phist[(size_t)w * (RVP_NB + 1) + bidx + 1];
+    const uint32_t* srt = R.psorted + (size_t)w * R.npts + start;
+    ge_p3 acc;
+    ge_identity(acc);
+    for (uint32_t i = s; i < n; i += RVP_S) {
+        uint32_t e = srt[i];
+        const int4* q4 = reinterpret_cast<const int4*>(R.pN + (size_t)(e & 0x7fffffffu) * 32);
+        int4 a0 = q4[0], a1 = q4[1], a2 = q4[2], a3 = q4[3], a4 = q4[4], a5 = q4[5], a6 = q4[6], a7 = q4[7];
+        ge_niels q;                                               // stored as ypx[10] ymx[10] xy2d[10]
+        q.ypx.v[0] = a0.x; q.ypx.v[1] = a0.y; q.ypx.v[2] = a0.z; q.ypx.v[3] = a0.w; q.ypx.v[4] = a1.x; q.ypx.v[5] = a1.y;
+        q.ypx.v[6] = a1.z; q.ypx.v[7] = a1.w; q.ypx.v[8] = a2.x; q.ypx.v[9] = a2.y;
+        q.ymx.v[0] = a2.z; q.ymx.v[1] = a2.w; q.ymx.v[2] = a3.x; q.ymx.v[3] = a3.y; q.ymx.v[4] = a3.z; q.ymx.v[5] = a3.w;
+        q.ymx.v[6] = a4.x; q.ymx.v[7] = a4.y; q.ymx.v[8] = a4.z; q.ymx.v[9] = a4.w;
+        q.xy2d.v[0] = a5.x; q.xy2d.v[1] = a5.y; q.xy2d.v[2] = a5.z; q.xy2d.v[3] = a5.w; q.xy2d.v[4] = a6.x; q.xy2d.v[5] = a6.y;
+        q.xy2d.v[6] = a6.z; q.xy2d.v[7] = a6.w; q.xy2d.v[8] = a7.x; q.xy2d.v[9] = a7.y;
+        (void)a7;
+        ge_madd(acc, acc, q, (e >> 31) != 0);
+    }
+    wave_reduce_point(acc, lds, l, RVP_S);
+    if (s == 0) st_p3(R.pbsum + ((size_t)w * RVP_NB + bidx) * 40, acc);
+}
+// Window sums: W_w = sum_k k B_k, scaled by 2^(C w), into Q0[w] (Q1[w] = identity) for k_rvb_finish.  One wavefront per
+// window: lane l owns the L = NB / 64 buckets of weights l L + 1 .. l L + L.
+__global__ __launch_bounds__(64) void k_rvp_window(RlcArgs R) {
+    __shared__ int32_t lds[40 * 64];
+    const int w = blockIdx.x, l = threadIdx.x, L = RVP_NB / 64;
+    ge_p3 run, aseg, b, t;
+    ge_identity(run);
+    ge_identity(aseg);
+    for (int k = L - 1; k >= 0; k--) {                            // running sums from the segment's heaviest bucket down:
+        ld_p3(b, R.pbsum + ((size_t)w * RVP_NB + (size_t)l * L + k) * 40);
+        ge_add(t, run, b); run = t;                               // run  = B_(lL+k) + .. + B_(lL+L-1)
+        ge_add(t, aseg, run); aseg = t;                           // aseg = sum_k (k + 1) B_(lL+k) when the loop ends
+    }
+    // W = sum_l aseg_l + L * sum_l l * C_l (C_l = run): the second sum bit by bit of l, most significant first
+    ge_p3 U;
+    ge_identity(U);
+    for (int j = 5; j >= 0; j--) {
+        ge_p3 m;
+        if ((l >> j) & 1) m = run; else ge_identity(m);
+        wave_reduce_point(m, lds, l, 64);
+        if (l == 0) { ge_dbl(t, U, true); ge_add(U, t, m); }
+    }
+    wave_reduce_point(aseg, lds, l, 64);
+    if (l == 0) {
+        for (int i = 1; i < L; i <<= 1) { ge_dbl(t, U, 2 * i >= L); U = t; }  // times L
+        ge_add(t, aseg, U);
+        const int nd = RVP_C * w;
+        for (int i = 0; i < nd; i++) { ge_p3 d2; ge_dbl(d2, t, i == nd - 1); t = d2; }
+        st_p3(R.Q0 + (size_t)w * 40, t);
+        ge_identity(t);
+        st_p3(R.Q1 + (size_t)w * 40, t);
+    }
 }
 // Sums everything and tests for the identity (one wavefront).
 __global__ __launch_bounds__(64) void k_rvb_finish(RlcArgs R, TableView tbl) {

@@ -837,6 +837,54 @@ def test_wavefront_transcript_equals_lane_transcript(gpu_ctx, n_bits, m, b):
     assert verdicts(proofs, V2) == [0] + [1] * (b - 1)
 
 
+@pytest.mark.parametrize("n_bits,m,b", [(16, 4, 1300), (8, 32, 300)])
+def test_bucket_method_gives_the_per_proof_verdicts(gpu_ctx, n_bits, m, b):
+    """Large batches sum the proofs' own points by the bucket (Pippenger) method instead of per-point tables; the switch is
+    lowered here so that a moderate batch takes it.  Verdicts must equal those of the table path and of the proof-by-proof
+    check: all honest, a tampered proof, a swapped commitment, an undecodable point."""
+    import os
+    rng = np.random.default_rng(11 * n_bits + m)
+    v = rng.integers(0, 2**n_bits, size=(b, m), dtype=np.uint64)
+    r = rng.integers(0, 256, size=(b, m, 32), dtype=np.uint8)
+    r[:, :, 31] &= 0x0F
+    proofs = gpu_ctx.range_prove_batch(n_bits, m, v, r, nonce_seed=SEED, stream_id=np.arange(b, dtype=np.uint64))
+    C, _ = gpu_ctx.commit_hash_batch(v.reshape(-1), r.reshape(-1, 32))
+    V = C.reshape(b, m, 32)
+
+    def verdicts(p, vv):
+        out = []
+        try:
+            for pip, rlc in (("12288", None), ("0", None), ("0", "1")):
+                os.environ["DAPOL_VERIFY_PIPPENGER_MIN"] = pip
+                if rlc:
+                    os.environ["DAPOL_VERIFY_NO_RLC"] = rlc
+                else:
+                    os.environ.pop("DAPOL_VERIFY_NO_RLC", None)
+                out.append(list(gpu_ctx.range_verify_batch(n_bits, m, p, vv, verify_seed=SEED)))
+        finally:
+            os.environ.pop("DAPOL_VERIFY_PIPPENGER_MIN", None)
+            os.environ.pop("DAPOL_VERIFY_NO_RLC", None)
+        assert all(o == out[0] for o in out)
+        return out[0]
+
+    assert verdicts(proofs, V) == [1] * b
+    bad = proofs.copy()
+    bad[7, 40] ^= 1                                                             # S
+    want = [1] * b
+    want[7] = 0
+    assert verdicts(bad, V) == want
+    V2 = V.copy()
+    V2[b - 1, 0], V2[b - 1, 1] = V[b - 1, 1].copy(), V[b - 1, 0].copy()        # two commitments of one proof swapped
+    want = [1] * b
+    want[b - 1] = 0
+    assert verdicts(proofs, V2) == want
+    mal = proofs.copy()
+    mal[3, 0:32] = 0xFF                                                         # A is not a point
+    want = [1] * b
+    want[3] = 0
+    assert verdicts(mal, V) == want
+
+
 @pytest.mark.parametrize("n_bits,m,b", [(64, 32, 50), (64, 1, 200), (16, 4, 70), (8, 2, 3)])
 def test_cross_proof_batching_gives_the_per_proof_verdicts(gpu_ctx, n_bits, m, b):
     """The verifier checks a batch through one random linear combination and falls back to the per-proof check when
