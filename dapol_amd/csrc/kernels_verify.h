@@ -530,6 +530,11 @@ __global__ __launch_bounds__(64) void k_rvb_tables2(RlcArgs R) {
     const int lgn = 31 - __clz(A.n);
     int jh, ih, jl, il;
     sc r, t;
+    if (!vs.ok) {                                                // a proof that did not parse takes no part in the batch sum
+        sc_zero(r);
+        st_sc(T + base + e, r);
+        return;
+    }
     if (e < nh) {                                                // SHa
         ld_sc(t, SH + e);
         sc_montmul(r, vs.rho, vs.a);
@@ -588,27 +593,31 @@ __global__ __launch_bounds__(64) void k_rvb_gh_partial(RlcArgs R) {
     sc acc;
     sc_zero(acc);
     if (q < A.N) {
-        for (size_t p = g; p < A.B; p += R.G) {
-            if (!V.vs[p].ok) continue;
-            const sc* T = V.tabs + p * (size_t)V.tab_stride;
-            sc x, y, r, rz;
-            ld_sc(rz, T + base + 3 * nh + 2 * nl);
-            if (side == 0) {
-                ld_sc(x, T + base + qh);                         // SHa
-                ld_sc(y, T + nh + ql);                           // SL
-                sc_montmul(r, x, y);
-                sc_sub(r, r, rz);
-            } else {
-                ld_sc(x, T + base + 2 * nh + qh);                // QH
-                ld_sc(y, T + base + 3 * nh + nl + ql);           // QL
-                sc_montmul(r, x, y);
-                ld_sc(x, T + base + nh + qh);                    // PHb
-                ld_sc(y, T + base + 3 * nh + ql);                // PL
-                sc_montmul(x, x, y);
-                sc_add(r, r, x);
-                sc_add(r, r, rz);
-            }
+        // Two proofs per trip, all loads first: every proof's tables are another 15-65 KB region of HBM, so a trip is one memory
+        // latency plus three products.  (A proof that failed to parse has zero tables -- k_rvb_tables2 -- and adds nothing.)
+        const size_t o_rz = base + 3 * nh + 2 * nl;
+        const size_t o_x1 = side == 0 ? (size_t)base + qh : (size_t)base + 2 * nh + qh;            // SHa | QH
+        const size_t o_y1 = side == 0 ? (size_t)nh + ql : (size_t)base + 3 * nh + nl + ql;         // SL  | QL
+        const size_t o_x2 = (size_t)base + nh + qh, o_y2 = (size_t)base + 3 * nh + ql;             //     | PHb, PL
+        for (size_t p = g; p < A.B; p += 2 * (size_t)R.G) {
+            const size_t pb = p + R.G;
+            const bool two = pb < A.B;
+            const sc* Ta = V.tabs + p * (size_t)V.tab_stride;
+            const sc* Tb = V.tabs + (two ? pb : p) * (size_t)V.tab_stride;
+            sc xa, ya, za, xb, yb, zb, ua, va, ub, vb, r;
+            ld_sc(za, Ta + o_rz); ld_sc(xa, Ta + o_x1); ld_sc(ya, Ta + o_y1);
+            ld_sc(zb, Tb + o_rz); ld_sc(xb, Tb + o_x1); ld_sc(yb, Tb + o_y1);
+            if (side != 0) { ld_sc(ua, Ta + o_x2); ld_sc(va, Ta + o_y2); ld_sc(ub, Tb + o_x2); ld_sc(vb, Tb + o_y2); }
+            sc_montmul(r, xa, ya);
+            if (side == 0) sc_sub(r, r, za);
+            else { sc_montmul(ua, ua, va); sc_add(r, r, ua); sc_add(r, r, za); }
             sc_add(acc, acc, r);
+            if (two) {
+                sc_montmul(r, xb, yb);
+                if (side == 0) sc_sub(r, r, zb);
+                else { sc_montmul(ub, ub, vb); sc_add(r, r, ub); sc_add(r, r, zb); }
+                sc_add(acc, acc, r);
+            }
         }
     }
     st_sc(R.partial + (size_t)g * A.TP + pos, acc);
