@@ -23,48 +23,104 @@ DAPOL_HD bool sc_is_zero(const sc& a) {
     return o == 0;
 }
 
+// 32-bit add / subtract with carry: clang's builtins become v_addc_co_u32 / v_subb_co_u32 chains on the device (one
+// instruction per word; a uint64_t emulation costs a 64-bit add plus register moves per word); plain C elsewhere.
+DAPOL_HD uint32_t sc_addc(uint32_t a, uint32_t b, uint32_t cin, uint32_t& cout) {
+#if defined(__clang__) && !defined(DAPOL_SC_NO_BUILTIN_CARRY)
+    return __builtin_addc(a, b, cin, &cout);
+#else
+    uint32_t s = a + b, c1 = s < a ? 1u : 0u, s2 = s + cin;
+    cout = c1 | (s2 < s ? 1u : 0u);
+    return s2;
+#endif
+}
+DAPOL_HD uint32_t sc_subb(uint32_t a, uint32_t b, uint32_t bin, uint32_t& bout) {
+#if defined(__clang__) && !defined(DAPOL_SC_NO_BUILTIN_CARRY)
+    return __builtin_subc(a, b, bin, &bout);
+#else
+    uint32_t d = a - b, b1 = a < b ? 1u : 0u, d2 = d - bin;
+    bout = b1 | (d < bin ? 1u : 0u);
+    return d2;
+#endif
+}
+
 // r = (t >= L) ? t - L : t, where t = (hi : t[0..8)) < 2L
 DAPOL_HD void sc_cond_sub(sc& r, const uint32_t* t, uint32_t hi) {
-    uint32_t d[8];
-    uint64_t borrow = 0;
-    for (int i = 0; i < 8; i++) {
-        uint64_t x = (uint64_t)t[i] - SC_L[i] - borrow;
-        d[i] = (uint32_t)x;
-        borrow = (x >> 32) & 1;
-    }
+    uint32_t d[8], borrow = 0;
+    for (int i = 0; i < 8; i++) d[i] = sc_subb(t[i], SC_L[i], borrow, borrow);
     bool ge = (hi != 0) | (borrow == 0);
     for (int i = 0; i < 8; i++) r.v[i] = ge ? d[i] : t[i];
 }
 
-// Montgomery product a*b/R mod L.  a < 2^256 (any), b < L  ->  result < L.
+// a * b + c as ONE v_mad_u64_u32 on the device.  Explicit because with the reduction's constant 2^20 (the top limb of L)
+// written as a C product, hipcc -O1 and above dropped the term in two of the nine reduction steps
+// (tools/sc_selftest.hip: device != host at -O3, equal at -O0); an opaque multiply-add leaves nothing to re-associate.
+DAPOL_HD uint64_t sc_mad(uint32_t a, uint32_t b, uint64_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint64_t d, carry_out;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry_out) : "v"(a), "v"(b), "v"(c));
+    return d;
+#else
+    return (uint64_t)a * b + c;
+#endif
+}
+
+// Montgomery product a*b/R mod L (R = 2^256).  a < 2^256 (any), b < L  ->  result < L.
+// Computed on nine 29-bit limbs so that every column of the product and of the reduction is a plain sum of 64-bit
+// multiply-adds (at most 15 terms of 58 bits): ~250 VALU instructions, against ~600 for the word-serial form with its
+// 64-bit carry additions -- the same lesson as fe.h.  L = 2^252 + delta has only six non-zero 29-bit limbs, so a
+// reduction step is six MADs.  Eight steps retire 29 bits each and a ninth the remaining 24 (8 * 29 + 24 = 256), which
+// keeps R = 2^256 and with it every constant and every stored Montgomery value.
 DAPOL_HD void sc_montmul(sc& r, const sc& a, const sc& b) {
-    uint32_t t[10];
-    for (int i = 0; i < 10; i++) t[i] = 0;
+    const uint32_t M29 = 0x1fffffffu;
+    const uint32_t L0 = 0x1cf5d3edu, L1 = 0x009318d2u, L2 = 0x1de73596u, L3 = 0x1df3bd45u, L4 = 0x0000014du, L8 = 0x00100000u;
+    uint32_t A[9], B[9];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint64_t c = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            uint64_t s = (uint64_t)a.v[j] * b.v[i] + t[j] + c;
-            t[j] = (uint32_t)s;
-            c = s >> 32;
-        }
-        uint64_t s = (uint64_t)t[8] + c;
-        t[8] = (uint32_t)s;
-        t[9] = (uint32_t)(s >> 32);
-        uint32_t m = t[0] * SC_LFACTOR;
-        c = ((uint64_t)m * SC_L[0] + t[0]) >> 32;
-#pragma unroll
-        for (int j = 1; j < 8; j++) {
-            uint64_t s2 = (uint64_t)m * SC_L[j] + t[j] + c;
-            t[j - 1] = (uint32_t)s2;
-            c = s2 >> 32;
-        }
-        s = (uint64_t)t[8] + c;
-        t[7] = (uint32_t)s;
-        t[8] = t[9] + (uint32_t)(s >> 32);
+    for (int k = 0; k < 9; k++) {
+        const int o = 29 * k, w = o >> 5, sh = o & 31;
+        uint32_t xa = a.v[w] >> sh, xb = b.v[w] >> sh;
+        if (sh > 3 && w + 1 < 8) { xa |= a.v[w + 1] << (32 - sh); xb |= b.v[w + 1] << (32 - sh); }
+        A[k] = xa & M29;
+        B[k] = xb & M29;
     }
-    sc_cond_sub(r, t, t[8]);
+    uint64_t c[18];
+#pragma unroll
+    for (int k = 0; k < 18; k++) c[k] = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+#pragma unroll
+        for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)A[i] * B[j];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const uint32_t mask = i < 8 ? M29 : 0x00ffffffu;                     // the ninth step retires 24 bits
+        const uint32_t m = ((uint32_t)c[i] * SC_LFACTOR) & mask;
+        c[i] = sc_mad(m, L0, c[i]);
+        c[i + 1] = sc_mad(m, L1, c[i + 1]);
+        c[i + 2] = sc_mad(m, L2, c[i + 2]);
+        c[i + 3] = sc_mad(m, L3, c[i + 3]);
+        c[i + 4] = sc_mad(m, L4, c[i + 4]);
+        c[i + 8] = sc_mad(m, L8, c[i + 8]);
+        if (i < 8) c[i + 1] += c[i] >> 29;                                   // c[i] is now a multiple of 2^29
+    }
+    // normalise columns 8..17 (column 8 keeps its bits 24..28) and read the 256 bits that start at bit 24 of column 8
+    uint32_t lim[11];
+#pragma unroll
+    for (int k = 8; k < 17; k++) {
+        lim[k - 8] = (uint32_t)c[k] & M29;
+        c[k + 1] += c[k] >> 29;
+    }
+    lim[9] = (uint32_t)c[17];
+    lim[10] = 0;
+    uint32_t t[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int o = 24 + 32 * j, q = o / 29, sh = o % 29;
+        uint32_t x = lim[q] >> sh;
+        x |= lim[q + 1] << (29 - sh);
+        if (58 - sh < 32) x |= lim[q + 2] << (58 - sh);
+        t[j] = x;
+    }
+    sc_cond_sub(r, t, 0);
 }
 DAPOL_HD void sc_montsq(sc& r, const sc& a) {
     sc_montmul(r, a, a);
@@ -72,30 +128,15 @@ DAPOL_HD void sc_montsq(sc& r, const sc& a) {
 
 // a + b mod L (both < L)
 DAPOL_HD void sc_add(sc& r, const sc& a, const sc& b) {
-    uint32_t t[8];
-    uint64_t c = 0;
-    for (int i = 0; i < 8; i++) {
-        uint64_t s = (uint64_t)a.v[i] + b.v[i] + c;
-        t[i] = (uint32_t)s;
-        c = s >> 32;
-    }
-    sc_cond_sub(r, t, (uint32_t)c);
+    uint32_t t[8], c = 0;
+    for (int i = 0; i < 8; i++) t[i] = sc_addc(a.v[i], b.v[i], c, c);
+    sc_cond_sub(r, t, c);
 }
 // a - b mod L (both < L)
 DAPOL_HD void sc_sub(sc& r, const sc& a, const sc& b) {
-    uint32_t t[8];
-    uint64_t borrow = 0;
-    for (int i = 0; i < 8; i++) {
-        uint64_t x = (uint64_t)a.v[i] - b.v[i] - borrow;
-        t[i] = (uint32_t)x;
-        borrow = (x >> 32) & 1;
-    }
-    uint64_t c = 0;
-    for (int i = 0; i < 8; i++) {
-        uint64_t s = (uint64_t)t[i] + (borrow ? SC_L[i] : 0u) + c;
-        r.v[i] = (uint32_t)s;
-        c = s >> 32;
-    }
+    uint32_t t[8], borrow = 0, c = 0;
+    for (int i = 0; i < 8; i++) t[i] = sc_subb(a.v[i], b.v[i], borrow, borrow);
+    for (int i = 0; i < 8; i++) r.v[i] = sc_addc(t[i], borrow ? SC_L[i] : 0u, c, c);
 }
 DAPOL_HD void sc_neg(sc& r, const sc& a) {
     sc z;

@@ -81,9 +81,13 @@ def test_add_of_decompressed_points(host_shim, pyref):
 def test_scalar_field(host_shim, pyref):
     L = pyref.L
     rnd = random.Random(3)
+    edge = [(2**256 - 1, L - 1), (L - 1, L - 1), (0, L - 1), (2**256 - 1, 0), (2**256 - 1, 1), (L, L - 1), (2**255, 2**252), (2**29 - 1, 2**29 - 1),
+            (2**232, 2**232), ((1 << 256) - (1 << 232), L - 2)]
     for it in range(600):
         a = rnd.randrange(2**256) if it % 3 else rnd.randrange(L)
         b = rnd.randrange(L)
+        if it < len(edge):
+            a, b = edge[it]
         for k, f in ((0, a * b % L), (1, (a + b) % L), (2, (a - b) % L)):
             o = buf(32)
             host_shim.t_sc_op(k, (a % L if k else a).to_bytes(32, "little"), b.to_bytes(32, "little"), o)
