@@ -110,9 +110,9 @@ __device__ __forceinline__ int term_generator(int round, int N, int lgN, int sid
     int half = 1 << lgh, Nh = N >> 1;
     isH = q >= Nh;
     int qq = isH ? q - Nh : q;
-    int blk = qq >> lgh, off = qq & (half - 1);
     bool upper = isH ? (side != 0) : (side == 0);   // L takes G_R (upper half) and H_L (lower half)
-    return (blk << (lgh + 1)) + off + (upper ? half : 0);
+    // block b = qq / half, offset o = qq % half  ->  2 b half + o = qq + b half = qq + (qq & ~(half - 1))
+    return qq + (qq & ~(half - 1)) + (upper ? half : 0);
 }
 __device__ __forceinline__ int gen_row(const TableView& t, int n, int j, bool isH) {
     int lgn = 31 - __clz(n);                  // n is 8, 16, 32 or 64

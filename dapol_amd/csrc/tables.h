@@ -47,7 +47,8 @@ struct TableView {
 #if defined(__HIPCC__)
 // Load entry |d| of `row`; the sign is applied by ge_madd.
 __device__ __forceinline__ void tbl_load(ge_niels& q, const TableView& t, int row, int absd) {
-    const int4* p = reinterpret_cast<const int4*>(t.base + (size_t)row * t.row_words() + (size_t)absd * TBL_ENTRY_WORDS);
+    // one 64-bit multiply-add for the entry's word offset (row and |d| are non-negative; the offset stays below 2^40)
+    const int4* p = reinterpret_cast<const int4*>(t.base + ((uint64_t)(uint32_t)row * (uint32_t)t.row_words() + (uint32_t)(absd * TBL_ENTRY_WORDS)));
     int4 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3], a4 = p[4], a5 = p[5], a6 = p[6], a7 = p[7];
     q.ypx.v[0] = a0.x; q.ypx.v[1] = a0.y; q.ypx.v[2] = a0.z; q.ypx.v[3] = a0.w;
     q.ypx.v[4] = a1.x; q.ypx.v[5] = a1.y; q.ypx.v[6] = a1.z; q.ypx.v[7] = a1.w;
