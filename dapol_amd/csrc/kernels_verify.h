@@ -81,21 +81,26 @@ __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) {
     return ((uint64_t)hi << 32) | lo;
 }
 struct KeccakLanes {                 // per-lane source lanes of the round's permutations
-    int th1, th2, th3, th4, xm1, xp1, xp2, pi_src, rot;
+    int th1, th2, th3, th4, xp1, xp2, pi_src, cm_src, cp_src, rot_src;
 };
 __device__ __forceinline__ void keccak_lanes_init(KeccakLanes& K, int l) {
     const int ROT[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
-    if (l >= 25) { K.th1 = K.th2 = K.th3 = K.th4 = K.xm1 = K.xp1 = K.xp2 = K.pi_src = l; K.rot = 0; return; }
+    if (l >= 25) { K.th1 = K.th2 = K.th3 = K.th4 = K.xp1 = K.xp2 = K.pi_src = K.cm_src = K.cp_src = l; K.rot_src = 0; return; }
     int x = l % 5, y = l / 5, row = 5 * y;
     K.th1 = (l + 5) % 25; K.th2 = (l + 10) % 25; K.th3 = (l + 15) % 25; K.th4 = (l + 20) % 25;
-    K.xm1 = row + (x + 4) % 5; K.xp1 = row + (x + 1) % 5; K.xp2 = row + (x + 2) % 5;
+    K.xp1 = row + (x + 1) % 5; K.xp2 = row + (x + 2) % 5;
     // pi: B[x'][y'] = rot(A[x][y]) with (x', y') = (y, 2x + 3y): lane (x', y') pulls from y = x', x = 3 (y' - 3 x') mod 5
     int sy = x, sx = (3 * ((y - 3 * x) % 5 + 5)) % 5;
     K.pi_src = sx + 5 * sy;
+    K.cm_src = (sx + 4) % 5;         // any lane of column sx - 1 / sx + 1 holds that column's parity: row 0
+    K.cp_src = (sx + 1) % 5;
     int r = 0;
-    for (int i = 0; i < 25; i++) r = (i == l) ? ROT[i] : r;
-    K.rot = r;
+    for (int i = 0; i < 25; i++) r = (i == K.pi_src) ? ROT[i] : r;
+    K.rot_src = r;
 }
+// Three dependent permutation stages per round: (1) the column parities and, alongside, every lane's pi source word;
+// (2) the two parities theta needs for the SOURCE's column -- theta, rho and pi are then applied at the destination;
+// (3) chi's two row neighbours.
 __device__ __forceinline__ uint64_t keccak_f1600_wave(uint64_t a, const KeccakLanes& K, int l) {
     const uint64_t RC[24] = {0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808Aull, 0x8000000080008000ull,
                              0x000000000000808Bull, 0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull,
@@ -104,11 +109,11 @@ __device__ __forceinline__ uint64_t keccak_f1600_wave(uint64_t a, const KeccakLa
                              0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800Aull, 0x800000008000000Aull,
                              0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
     for (int r = 0; r < 24; r++) {
+        uint64_t as = shfl64(a, K.pi_src);
         uint64_t c = a ^ shfl64(a, K.th1) ^ shfl64(a, K.th2) ^ shfl64(a, K.th3) ^ shfl64(a, K.th4);    // C[x] on every lane of column x
-        uint64_t cm = shfl64(c, K.xm1), cp = shfl64(c, K.xp1);
-        a ^= cm ^ ((cp << 1) | (cp >> 63));
-        uint64_t rt = K.rot ? ((a << K.rot) | (a >> (64 - K.rot))) : a;
-        uint64_t b = shfl64(rt, K.pi_src);
+        uint64_t cm = shfl64(c, K.cm_src), cp = shfl64(c, K.cp_src);
+        as ^= cm ^ ((cp << 1) | (cp >> 63));
+        uint64_t b = K.rot_src ? ((as << K.rot_src) | (as >> (64 - K.rot_src))) : as;
         uint64_t b1 = shfl64(b, K.xp1), b2 = shfl64(b, K.xp2);
         a = b ^ (~b1 & b2);
         if (l == 0) a ^= RC[r];
@@ -163,17 +168,19 @@ __global__ __launch_bounds__(64) void k_rv_absorb_V(VerifyArgs V) {
         }
         return w;
     };
+    uint64_t w = block_word(0);
     for (uint32_t beta = 0; beta < nfull; beta++) {
-        a ^= block_word(beta);
+        a ^= w;
         if (l == 20) {                                            // run_f: pos_begin at byte 166, 0x04 and 0x80 at byte 167
             uint32_t k_end = beta * STROBE_R + (STROBE_R - 1) - pos0, je = k_end / RV_V_BYTES, te = k_end - je * RV_V_BYTES;
             uint32_t kb = RV_V_BYTES * je + (te >= 7 ? 7u : 0u), ab = pos0 + kb;
             uint32_t pbe = ab >= beta * STROBE_R ? ab % STROBE_R + 1 : (beta == 0 ? pb0 : 0u);
             a ^= ((uint64_t)pbe << 48) | (0x84ull << 56);
         }
+        w = block_word(beta + 1);                                 // the next block's bytes load while this one is permuted
         a = keccak_f1600_wave(a, K, l);
     }
-    a ^= block_word(nfull);                                       // the bytes after the last permutation
+    a ^= w;                                                       // the bytes after the last permutation
     VerifyState& vs = V.vs[b];
     if (l < 25) vs.st[l] = a;
     if (l == 0) {
