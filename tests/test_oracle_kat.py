@@ -130,3 +130,63 @@ def test_policy_serialization_roundtrip(pyref):
         import pytest
         with pytest.raises(ValueError):
             pyref.policy_deserialize(c["policy"], ser[:-5], single_size=single)
+
+
+def test_commitment_phase_of_the_transcript_is_a_closed_form_stream(pyref):
+    """k_rv_absorb_V (kernels_verify.h) absorbs the m commitments of a range-proof transcript block by block, every lane
+    computing its own bytes of a 166-byte STROBE block from the stream offset alone.  This restates that closed form in
+    Python -- record j contributes [pos_begin, M|A, 'V', LE32(32), pos_begin', A, 32 bytes], the two position bytes being
+    (q - d) + 1 when the previous begin_op (d = 34 or 7 bytes earlier) lies in the same block and 0 after a run_f -- and
+    checks state, pos and pos_begin against merlin's byte-by-byte Strobe for heads that leave the stream at every offset."""
+    R = pyref
+    rate = R.STROBE_R
+    import random
+    rnd = random.Random(11)
+    seen = set()
+    for m in (1, 2, 4, 8, 32, 64):
+        for pad in range(0, 170, 7):
+            t = R.Transcript(b"")
+            t.append_message(b"dom-sep", b"rangeproof v1")
+            t.append_message(b"x", bytes(pad))                    # moves the start of the stream through the block
+            t.append_message(b"m", m.to_bytes(8, "little"))
+            V = [bytes(rnd.randrange(256) for _ in range(32)) for _ in range(m)]
+            ref = t.strobe.clone()
+            tt = R.Transcript.__new__(R.Transcript)
+            tt.strobe = ref
+            for v in V:
+                tt.append_message(b"V", v)
+            st = t.strobe.clone()
+            pos0, pb0 = st.pos, st.pos_begin
+            seen.add(pos0)
+            total, end_abs = 41 * m, pos0 + 41 * m
+            nfull = end_abs // rate
+            state = bytearray(st.state)
+
+            def stream_byte(k, q):
+                j, tb = divmod(k, 41)
+                if tb >= 9:
+                    return V[j][tb - 9]
+                if tb == 0:
+                    return pb0 if j == 0 else (q - 33 if q >= 34 else 0)
+                if tb == 7:
+                    return q - 6 if q >= 7 else 0
+                return {1: 0x12, 2: ord("V"), 3: 32, 8: 0x02}.get(tb, 0)
+
+            for beta in range(nfull + 1):
+                for q in range(rate):
+                    at = beta * rate + q
+                    if pos0 <= at < end_abs:
+                        state[q] ^= stream_byte(at - pos0, q)
+                if beta < nfull:
+                    k_end = beta * rate + rate - 1 - pos0
+                    je, te = divmod(k_end, 41)
+                    kb = 41 * je + (7 if te >= 7 else 0)
+                    ab = pos0 + kb
+                    pbe = ab % rate + 1 if ab >= beta * rate else (pb0 if beta == 0 else 0)
+                    state[rate] ^= pbe
+                    state[rate + 1] ^= 0x04 ^ 0x80
+                    R.keccak_f1600(state)
+            kb = 41 * (m - 1) + 7
+            pos_begin = (pos0 + kb) % rate + 1 if (pos0 + kb) // rate == nfull else 0
+            assert bytes(state) == bytes(ref.state) and end_abs % rate == ref.pos and pos_begin == ref.pos_begin, (m, pad)
+    assert len(seen) > 20
