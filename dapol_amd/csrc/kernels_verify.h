@@ -365,6 +365,15 @@ __global__ __launch_bounds__(64) void k_rv_scalars(VerifyArgs V) {
 
 // The t-th of a proof's own K = 4 + 2 lgN + m points and its scalar:  A, x S, c x T1, c x^2 T2, u_k^2 L_k, u_k^-2 R_k,
 // c z^(2+j) V_j.
+// ... its encoding alone (needs nothing from the transcript: the bucket method decodes the points while the replay runs)
+__device__ __forceinline__ void rv_own_point_bytes(uint32_t* w8, const VerifyArgs& V, size_t b, int t) {
+    const RangeArgs& A = V.R;
+    const uint32_t* pr = A.out + b * A.out_words;
+    if (t < 4) ld8(w8, pr + 8 * t);
+    else if (t < 4 + A.lgN) ld8(w8, pr + 56 + 16 * (t - 4));
+    else if (t < 4 + 2 * A.lgN) ld8(w8, pr + 56 + 16 * (t - 4 - A.lgN) + 8);
+    else ld8(w8, A.Vc + (b * A.m + (t - 4 - 2 * A.lgN)) * 8);
+}
 __device__ __forceinline__ void rv_own_point(uint32_t* w8, sc& sm, const VerifyArgs& V, size_t b, int t) {
     const RangeArgs& A = V.R;
     const VerifyState& vs = V.vs[b];
@@ -687,23 +696,45 @@ __global__ __launch_bounds__(64) void k_rvb_points(RlcArgs R) {
 // 8 for its table, the normalisation, and one per 4-bit window.  A batch is ONE sum over all its points -- 1.08 M of them
 // for 1,024 proofs x 1,024 parties, 3 M for 65,536 inclusion proofs -- which is where Pippenger's method pays: per
 // 11-bit window every point is added once into the bucket of its digit (23 additions per point in total), and the 1,024
-// buckets of a window are combined with running sums.  Steps: decode + digits + histogram (lane per point) -> offsets
+// buckets of a window are combined with running sums.  Steps: decode (early, second stream) -> digits + histogram -> offsets
 // (wave per window) -> scatter (counting sort by |digit|) -> bucket sums (8 lanes per bucket, tree-reduced) -> window sums
 // (wave per window: sum_k k B_k by running sums over 16-bucket segments, then 2^(11 w)).  The order inside a bucket is
 // whatever the atomics give; the sum -- and so the verdict -- does not depend on it.
-__global__ __launch_bounds__(64) void k_rvp_points(RlcArgs R) {
+// Decode (lane per point).  Independent of the challenges, so it runs on a second stream beside the transcript replay, whose
+// lane- or wavefront-per-proof kernels leave most of the chip idle.  Word 30 of the entry records a failed decode.
+__global__ __launch_bounds__(64) void k_rvp_decode(RlcArgs R) {
     size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (t >= R.npts) return;
     size_t p = t / R.K;
+    uint32_t w8[8];
+    rv_own_point_bytes(w8, R.V, p, (int)(t - p * R.K));
     ge_p3 pt;
-    ge_identity(pt);
+    bool good = ge_decompress(pt, w8);
+    if (!good) ge_identity(pt);
+    fe a, b2, c2;                                                 // affine niels (the decoded point has Z = 1)
+    fe_addc(a, pt.Y, pt.X);
+    fe_sub(b2, pt.Y, pt.X);
+    fe_carry(b2, b2);
+    fe_mul(c2, pt.T, FE_D2);
+    int32_t* o = R.pN + t * 32;
+    for (int i = 0; i < 10; i++) { o[i] = a.v[i]; o[10 + i] = b2.v[i]; o[20 + i] = c2.v[i]; }
+    o[30] = good ? 0 : 1;
+}
+// Scalars -> digits + histogram (lane per point), after the replay.  A point that did not decode sends the chunk to the
+// proof-by-proof check if its proof is still in the running.
+__global__ __launch_bounds__(64) void k_rvp_digits(RlcArgs R) {
+    size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (t >= R.npts) return;
+    size_t p = t / R.K;
     sc sm;
     sc_zero(sm);
     if (R.V.vs[p].ok) {
-        uint32_t w8[8];
-        rv_own_point(w8, sm, R.V, p, (int)(t - p * R.K));
-        if (ge_decompress(pt, w8)) sc_montmul(sm, sm, R.V.vs[p].rho);
-        else { atomicOr(&R.flag[1], 1u); ge_identity(pt); sc_zero(sm); }
+        if (R.pN[t * 32 + 30]) atomicOr(&R.flag[1], 1u);
+        else {
+            uint32_t w8[8];
+            rv_own_point(w8, sm, R.V, p, (int)(t - p * R.K));
+            sc_montmul(sm, sm, R.V.vs[p].rho);
+        }
     }
     uint32_t c[8];
     sc_from_mont(c, sm);
@@ -712,14 +743,6 @@ __global__ __launch_bounds__(64) void k_rvp_points(RlcArgs R) {
         R.pdig[(size_t)i * np + t] = (int16_t)digit;
         if (digit) atomicAdd(&R.phist[(size_t)i * (RVP_NB + 1) + (digit < 0 ? -digit : digit)], 1u);
     });
-    // affine niels (the decoded point has Z = 1)
-    fe a, b2, c2;
-    fe_addc(a, pt.Y, pt.X);
-    fe_sub(b2, pt.Y, pt.X);
-    fe_carry(b2, b2);
-    fe_mul(c2, pt.T, FE_D2);
-    int32_t* o = R.pN + t * 32;
-    for (int i = 0; i < 10; i++) { o[i] = a.v[i]; o[10 + i] = b2.v[i]; o[20 + i] = c2.v[i]; }
 }
 // offs[w][d] = number of points of window w with 0 < |digit| < d; cursor = offs.  One wavefront per window.
 __global__ __launch_bounds__(64) void k_rvp_scan(RlcArgs R) {
