@@ -85,7 +85,9 @@ DAPOL_HD void fe_reduce_cols(fe& h, int64_t c0, int64_t c1, int64_t c2, int64_t 
 // a separate instruction; one statement per column (not per MAD) keeps the hazard recogniser from padding the
 // dependent MADs with s_nop.
 #define DAPOL_MAD_CHAIN 1
-__device__ __forceinline__ int64_t mad_col10z(int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2, int32_t a3, int32_t b3, int32_t a4, int32_t b4, int32_t a5, int32_t b5, int32_t a6, int32_t b6, int32_t a7, int32_t b7, int32_t a8, int32_t b8, int32_t a9, int32_t b9) {
+__device__ __forceinline__ int64_t mad_col10z(int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2,
+        int32_t a3, int32_t b3, int32_t a4, int32_t b4, int32_t a5, int32_t b5, int32_t a6, int32_t b6, int32_t a7,
+        int32_t b7, int32_t a8, int32_t b8, int32_t a9, int32_t b9) {
     int64_t d;
     uint64_t sdst;               // VOP3b scalar destination (carry out), unused
     asm("v_mad_i64_i32 %0, %1, %2, %3, 0\n\t"
@@ -99,10 +101,13 @@ __device__ __forceinline__ int64_t mad_col10z(int32_t a0, int32_t b0, int32_t a1
         "v_mad_i64_i32 %0, %1, %18, %19, %0\n\t"
         "v_mad_i64_i32 %0, %1, %20, %21, %0"
         : "=&v"(d), "=s"(sdst)
-        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), "v"(a6), "v"(b6), "v"(a7), "v"(b7), "v"(a8), "v"(b8), "v"(a9), "v"(b9));
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5),
+          "v"(a6), "v"(b6), "v"(a7), "v"(b7), "v"(a8), "v"(b8), "v"(a9), "v"(b9));
     return d;
 }
-__device__ __forceinline__ int64_t mad_col10c(int64_t d, int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2, int32_t a3, int32_t b3, int32_t a4, int32_t b4, int32_t a5, int32_t b5, int32_t a6, int32_t b6, int32_t a7, int32_t b7, int32_t a8, int32_t b8, int32_t a9, int32_t b9) {
+__device__ __forceinline__ int64_t mad_col10c(int64_t d, int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2,
+        int32_t b2, int32_t a3, int32_t b3, int32_t a4, int32_t b4, int32_t a5, int32_t b5, int32_t a6, int32_t b6,
+        int32_t a7, int32_t b7, int32_t a8, int32_t b8, int32_t a9, int32_t b9) {
     uint64_t sdst;               // VOP3b scalar destination (carry out), unused
     asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t"
         "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
@@ -115,10 +120,12 @@ __device__ __forceinline__ int64_t mad_col10c(int64_t d, int32_t a0, int32_t b0,
         "v_mad_i64_i32 %0, %1, %18, %19, %0\n\t"
         "v_mad_i64_i32 %0, %1, %20, %21, %0"
         : "+v"(d), "=s"(sdst)
-        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), "v"(a6), "v"(b6), "v"(a7), "v"(b7), "v"(a8), "v"(b8), "v"(a9), "v"(b9));
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5),
+          "v"(a6), "v"(b6), "v"(a7), "v"(b7), "v"(a8), "v"(b8), "v"(a9), "v"(b9));
     return d;
 }
-__device__ __forceinline__ int64_t mad_col6z(int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2, int32_t a3, int32_t b3, int32_t a4, int32_t b4, int32_t a5, int32_t b5) {
+__device__ __forceinline__ int64_t mad_col6z(int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2,
+        int32_t a3, int32_t b3, int32_t a4, int32_t b4, int32_t a5, int32_t b5) {
     int64_t d;
     uint64_t sdst;               // VOP3b scalar destination (carry out), unused
     asm("v_mad_i64_i32 %0, %1, %2, %3, 0\n\t"
@@ -131,7 +138,8 @@ __device__ __forceinline__ int64_t mad_col6z(int32_t a0, int32_t b0, int32_t a1,
         : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5));
     return d;
 }
-__device__ __forceinline__ int64_t mad_col6c(int64_t d, int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2, int32_t a3, int32_t b3, int32_t a4, int32_t b4, int32_t a5, int32_t b5) {
+__device__ __forceinline__ int64_t mad_col6c(int64_t d, int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2,
+        int32_t b2, int32_t a3, int32_t b3, int32_t a4, int32_t b4, int32_t a5, int32_t b5) {
     uint64_t sdst;               // VOP3b scalar destination (carry out), unused
     asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t"
         "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
@@ -143,7 +151,8 @@ __device__ __forceinline__ int64_t mad_col6c(int64_t d, int32_t a0, int32_t b0, 
         : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5));
     return d;
 }
-__device__ __forceinline__ int64_t mad_col5c(int64_t d, int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2, int32_t a3, int32_t b3, int32_t a4, int32_t b4) {
+__device__ __forceinline__ int64_t mad_col5c(int64_t d, int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2,
+        int32_t b2, int32_t a3, int32_t b3, int32_t a4, int32_t b4) {
     uint64_t sdst;               // VOP3b scalar destination (carry out), unused
     asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t"
         "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
