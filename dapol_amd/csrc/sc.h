@@ -58,7 +58,7 @@ DAPOL_HD void sc_cond_sub(sc& r, const uint32_t* t, uint32_t hi) {
 DAPOL_HD uint64_t sc_mad(uint32_t a, uint32_t b, uint64_t c) {
 #if defined(__HIP_DEVICE_COMPILE__)
     uint64_t d, carry_out;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry_out) : "v"(a), "v"(b), "v"(c));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry_out) : "v"(a), "s"(b), "v"(c));   // b: a limb of L, kept in an SGPR
     return d;
 #else
     return (uint64_t)a * b + c;
