@@ -71,25 +71,28 @@ DAPOL_HD uint64_t sc_mad(uint32_t a, uint32_t b, uint64_t c) {
 // 64-bit carry additions -- the same lesson as fe.h.  L = 2^252 + delta has only six non-zero 29-bit limbs, so a
 // reduction step is six MADs.  Eight steps retire 29 bits each and a ninth the remaining 24 (8 * 29 + 24 = 256), which
 // keeps R = 2^256 and with it every constant and every stored Montgomery value.
-DAPOL_HD void sc_montmul(sc& r, const sc& a, const sc& b) {
-    const uint32_t M29 = 0x1fffffffu;
-    const uint32_t L0 = 0x1cf5d3edu, L1 = 0x009318d2u, L2 = 0x1de73596u, L3 = 0x1df3bd45u, L4 = 0x0000014du, L8 = 0x00100000u;
-    uint32_t A[9], B[9];
+// The three parts of the product, also used on their own where sums of products are reduced once (k_rvb_gh_lazy):
+// nine 29-bit limbs of a 256-bit word array; columns += A x B; Montgomery reduction of the columns.
+DAPOL_HD void sc_split29(uint32_t* A, const uint32_t* v) {
 #pragma unroll
     for (int k = 0; k < 9; k++) {
         const int o = 29 * k, w = o >> 5, sh = o & 31;
-        uint32_t xa = a.v[w] >> sh, xb = b.v[w] >> sh;
-        if (sh > 3 && w + 1 < 8) { xa |= a.v[w + 1] << (32 - sh); xb |= b.v[w + 1] << (32 - sh); }
-        A[k] = xa & M29;
-        B[k] = xb & M29;
+        uint32_t x = v[w] >> sh;
+        if (sh > 3 && w + 1 < 8) x |= v[w + 1] << (32 - sh);
+        A[k] = x & 0x1fffffffu;
     }
-    uint64_t c[18];
-#pragma unroll
-    for (int k = 0; k < 18; k++) c[k] = 0;
+}
+DAPOL_HD void sc_mac29(uint64_t* c, const uint32_t* A, const uint32_t* B) {
 #pragma unroll
     for (int i = 0; i < 9; i++)
 #pragma unroll
         for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)A[i] * B[j];
+}
+// r = (sum of the columns) / R mod L for a column array holding at most 6 products of values < L (columns < 2^64,
+// result < 2L before the final subtraction).  Destroys c.
+DAPOL_HD void sc_redc29(sc& r, uint64_t* c) {
+    const uint32_t M29 = 0x1fffffffu;
+    const uint32_t L0 = 0x1cf5d3edu, L1 = 0x009318d2u, L2 = 0x1de73596u, L3 = 0x1df3bd45u, L4 = 0x0000014du, L8 = 0x00100000u;
 #pragma unroll
     for (int i = 0; i < 9; i++) {
         const uint32_t mask = i < 8 ? M29 : 0x00ffffffu;                     // the ninth step retires 24 bits
@@ -121,6 +124,16 @@ DAPOL_HD void sc_montmul(sc& r, const sc& a, const sc& b) {
         t[j] = x;
     }
     sc_cond_sub(r, t, 0);
+}
+DAPOL_HD void sc_montmul(sc& r, const sc& a, const sc& b) {
+    uint32_t A[9], B[9];
+    sc_split29(A, a.v);
+    sc_split29(B, b.v);
+    uint64_t c[18];
+#pragma unroll
+    for (int k = 0; k < 18; k++) c[k] = 0;
+    sc_mac29(c, A, B);
+    sc_redc29(r, c);
 }
 DAPOL_HD void sc_montsq(sc& r, const sc& a) {
     sc_montmul(r, a, a);
