@@ -1,26 +1,42 @@
 #!/usr/bin/env python3
 """bench.py -- headline metric of BASELINE.json on MI355X: entities/sec for DAPOL+ tree build + 64-bit range-proof
-generation (one padding-policy inclusion proof per entity, aggregation_factor = height; benches/dapol.rs:155).
+generation (one padding-policy inclusion proof per entity, aggregation_factor = height; benches/dapol.rs:59-91,149-175).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched by torch.distributed.run)
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--budget-s S]      (N > 1: launched by torch.distributed.run)
+  python bench.py --mode build      the reference's `build` criterion group (benches/dapol.rs:24-57) on the GPU
+  python bench.py --mode verify     BASELINE configs[4]: verification-only, aggregated proofs of 1,024 parties
 
 A step = one pass of the hot path over the whole synthetic entity set, inputs already resident in HBM:
 tree build (commit + hash + merge, padding nodes made on the fly) followed by one aggregated Bulletproof per
 entity.  N = 1 workload: BASELINE.json configs[2] -- 2^20 entities, height 32, 64-bit proofs (the configuration
-the metric is quoted on).  N > 1: weak scaling, 2^20 entities per GPU, each GPU owning one top-level subtree; the
-only exchange is an all-gather of the N subtree-root records and an all-reduce of the proof checksum.
+the metric is quoted on).  N > 1: weak scaling by default (2^20 entities per GPU, each GPU owning one top-level
+subtree); --log2-entities-total fixes the TOTAL instead (strong scaling: configs[3] = 2^22 over 8).  The only
+exchange is an all-gather of the N subtree-root records and an all-reduce of the proof checksum.
 
-Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).  The CPU oracle (oracle/) is used
-only for the `cpu_baseline` leg and a byte-for-byte spot check of sampled proofs -- never in the timed region.
+Wall budget.  One step of configs[2] takes ~20 s, so the driver's `--steps 20 --warmup 5` cannot fit its 600 s
+limit.  The GPU loop therefore has a wall budget (--budget-s, default 450 s counted from process start, including
+imports / build / context creation): after the first warm-up step the number of timed steps is clamped to what fits
+(never below 3) and extra warm-up steps are dropped.  The line reports the steps actually run (`steps`, `warmup`) and
+what was asked for (`steps_requested`, `warmup_requested`).  A heartbeat goes to stderr after every step.
+
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for every field).  Everything in `roofline` outside
+`from_profiles` is measured by THIS run (HIP events on the launch streams inside the library).  The CPU oracle
+(oracle/) is used only for the `cpu_baseline` leg and a byte-for-byte spot check of sampled proofs -- never in the
+timed region.
 """
-import argparse
-import ctypes
-import json
-import os
-import sys
 import time
 
-import numpy as np
+T_PROC0 = time.time()
+
+import argparse   # noqa: E402
+import ctypes     # noqa: E402
+import hashlib    # noqa: E402
+import json       # noqa: E402
+import os         # noqa: E402
+import subprocess # noqa: E402
+import sys        # noqa: E402
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -28,16 +44,11 @@ sys.path.insert(0, ROOT)
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 PAD_SEED = bytes((i * 7 + 1) & 0xFF for i in range(32))
 NONCE_SEED = bytes((i * 13 + 5) & 0xFF for i in range(32))
+METRIC = "entities/sec (tree build + 64-bit range-proof gen), 2^20 leaves, 1/2/4/8 GPU"
 
 
-def algorithmic_bytes(height, n_bits):
-    """compulsory bytes per entity (each input read once, each output written once)."""
-    lgn = 0
-    while (1 << lgn) < n_bits * _np2(height):
-        lgn += 1
-    proof = 32 * (9 + 2 * lgn)
-    prove = height * (8 + 32) + height * 64 + height * 64 + proof + 16       # secrets + (C,H) read + path written + proof + framing
-    return prove
+def log(msg):
+    print("[bench %6.1fs] %s" % (time.time() - T_PROC0, msg), file=sys.stderr, flush=True)
 
 
 def _np2(x):
@@ -45,6 +56,24 @@ def _np2(x):
     while p < x:
         p <<= 1
     return p
+
+
+def proof_bytes(height, n_bits):
+    lgn = 0
+    while (1 << lgn) < n_bits * _np2(height):
+        lgn += 1
+    return 32 * (9 + 2 * lgn)
+
+
+def algorithmic_bytes(height, n_bits, log2_n):
+    """compulsory bytes per entity (each input read once, each output written once).
+    prove: sibling secrets (8 + 32) + (C, H) read + path written, per level, + proof + 16 B framing  (6,384 B at H = 32);
+    tree (bench layout): 48 B of leaf input + 104 B per node written, (2N - 1 + 2cN) / N nodes per entity, c = H - log2 N
+    (2,752 B at 2^20 x H = 32)."""
+    prove = height * (8 + 32) + height * 64 + height * 64 + proof_bytes(height, n_bits) + 16
+    c = max(0, height - log2_n)
+    tree = 48 + int(round((2.0 + 2.0 * c) * 104))
+    return prove, tree
 
 
 def synth_inputs(n_total, height, first, count):
@@ -58,93 +87,194 @@ def synth_inputs(n_total, height, first, count):
     return idx, v_all[first:first + count].copy(), r_all[first:first + count].copy()
 
 
-def cpu_baseline(ref, height, n_bits, idx, v, r, sample_paths, budget_s=20.0):
-    """Times the C restatement (kind 'port') on this host: tree build on a bounded slice + proofs for sampled entities."""
-    cores = os.cpu_count() or 1
+def usable_cores():
+    """Threads this process may actually use: scheduler affinity capped by the cgroup CPU quota (the GPU boxes expose
+    every hardware thread of the host but grant a share of them)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // p))
+            break
+        except Exception:
+            continue
+    return n
+
+
+CPU_NATIVE_CFLAGS = "-O3 -march=native -std=gnu11 -fPIC -fopenmp"
+
+
+def build_native_oracle():
+    """The timed CPU baseline is compiled ON THIS HOST with -O3 -march=native (the checker build that travels with the
+    repo is -O2, generic ISA).  Returns (path, cflags) or (None, reason)."""
+    odir = os.path.join(ROOT, "oracle")
+    try:
+        cpu = open("/proc/cpuinfo").read()
+        model = [l for l in cpu.splitlines() if l.startswith("model name")][:1]
+        flags = [l for l in cpu.splitlines() if l.startswith("flags")][:1]
+        tag = hashlib.sha256(("".join(model + flags)).encode()).hexdigest()[:12]
+    except Exception:
+        tag = "host"
+    out = os.path.join(odir, "_build", "libdapol_ref_native_%s.so" % tag)
+    srcs = [os.path.join(odir, f) for f in ("ref_math.c", "ref_dapol.c")]
+    if os.path.exists(out) and all(os.path.getmtime(s) <= os.path.getmtime(out) for s in srcs):
+        return out, CPU_NATIVE_CFLAGS
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    try:
+        subprocess.run(["gcc"] + CPU_NATIVE_CFLAGS.split() + ["-shared"] + srcs + ["-o", out], check=True, cwd=odir,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=120)
+        return out, CPU_NATIVE_CFLAGS
+    except Exception as e:          # fall back to the generic checker build, and say so in the line
+        return None, "native build failed (%s)" % type(e).__name__
+
+
+def cpu_baseline(generic_lib, height, n_bits, idx, v, r, sample_paths, budget_s=10.0):
+    """Times the C restatement (kind 'port') on this host's cores, bounded to ~budget_s of wall time:
+      * tuned    = generators / PedersenGens derived once (what any sane CPU user would run);
+      * faithful = the reference's own per-call costs switched on: BulletproofGens::new + PedersenGens::default per
+        proof (src/range/mod.rs:49-50,65-66), children re-compressed in every merge (src/dapol/node.rs:67-68);
+      each single-threaded (the reference is single-threaded) and on all usable cores (OpenMP over entities).
+    `value` = tuned, all cores: the strongest CPU number, so that the GPU/CPU ratio is not flattered."""
+    cores = usable_cores()
+    native, cflags = build_native_oracle()
+    ref = ctypes.CDLL(native or generic_lib)
     ref.ref_tree_build.restype = ctypes.c_void_p
     ref.ref_range_proof_size.restype = ctypes.c_size_t
-    nt = min(len(idx), 4096)
+    have_threads = hasattr(ref, "ref_set_threads")
     p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
-    t0 = time.perf_counter()
-    t = ctypes.c_void_p(ref.ref_tree_build(height, ctypes.c_size_t(nt), p(idx[:nt]), p(v[:nt]), p(r[:nt]), PAD_SEED, 0))
-    tree_s = time.perf_counter() - t0
-    ref.ref_tree_free(t)
     sv, sr, leaf_ids = sample_paths
     m = _np2(height)
     ps = ref.ref_range_proof_size(n_bits, m)
-    # parties: siblings root side first, padded with (0, Scalar::one())
-    def parties(k):
-        pv = np.zeros(m, np.uint64)
-        pr = np.zeros((m, 32), np.uint8)
-        pv[:height] = sv[k]
-        pr[:height] = sr[k]
-        pr[height:, 0] = 1
-        return pv, pr
-    # one proof first to size the sample
-    pv, pr = parties(0)
-    out1 = ctypes.create_string_buffer(ps)
-    t0 = time.perf_counter()
-    ref.ref_range_prove(n_bits, m, p(pv), p(pr), NONCE_SEED, ctypes.c_uint64(int(leaf_ids[0])), ctypes.c_uint64(0), None, 0, out1)
-    one = time.perf_counter() - t0
-    # pilot batch (one proof per core) to learn the parallel rate on this host, then size the sample to ~budget_s
-    npilot = min(len(leaf_ids), cores)
-    PV = np.zeros((npilot, m), np.uint64)
-    PR = np.zeros((npilot, m, 32), np.uint8)
-    for k in range(npilot):
-        PV[k], PR[k] = parties(k)
-    sid = np.ascontiguousarray(leaf_ids[:npilot], dtype=np.uint64)
-    outp = ctypes.create_string_buffer(ps * npilot)
-    t0 = time.perf_counter()
-    ref.ref_range_prove_batch(n_bits, m, ctypes.c_size_t(npilot), p(PV), p(PR), NONCE_SEED, p(sid), ctypes.c_uint64(0), None, 0, outp)
-    pilot = time.perf_counter() - t0
-    ns = int(max(npilot, min(len(leaf_ids), npilot * budget_s / max(pilot, 1e-3))))
-    PV = np.zeros((ns, m), np.uint64)
-    PR = np.zeros((ns, m, 32), np.uint8)
-    for k in range(ns):
-        PV[k], PR[k] = parties(k)
-    out = ctypes.create_string_buffer(ps * ns)
-    sid = np.ascontiguousarray(leaf_ids[:ns], dtype=np.uint64)
-    t0 = time.perf_counter()
-    ref.ref_range_prove_batch(n_bits, m, ctypes.c_size_t(ns), p(PV), p(PR), NONCE_SEED, p(sid), ctypes.c_uint64(0), None, 0, out)
-    prove_s = time.perf_counter() - t0
-    per_entity = tree_s / nt + prove_s / ns
-    return {"value": 1.0 / per_entity, "unit": "entities/s", "cores": cores, "kind": "port",
-            "sample": "C restatement (oracle/ref_dapol.c, OpenMP over entities): tree build of %d entities at height %d (%.2f s) + %d "
-                      "padding-policy proofs m=%d n=%d (%.2f s, %.3f s/proof single-thread); reference Rust not runnable (no toolchain)"
-                      % (nt, height, tree_s, ns, m, n_bits, prove_s, one),
-            "single_thread_proof_s": one}, out.raw, ns, ps
+
+    def parties(k0, cnt):           # siblings root side first, padded with (0, Scalar::one())
+        PV = np.zeros((cnt, m), np.uint64)
+        PR = np.zeros((cnt, m, 32), np.uint8)
+        PV[:, :height] = sv[k0:k0 + cnt]
+        PR[:, :height] = sr[k0:k0 + cnt]
+        PR[:, height:, 0] = 1
+        return PV, PR
+
+    def prove(cnt, faithful, threads):
+        cnt = max(1, min(cnt, len(leaf_ids)))
+        if have_threads:
+            ref.ref_set_threads(threads)
+        PV, PR = parties(0, cnt)
+        sid = np.ascontiguousarray(leaf_ids[:cnt], dtype=np.uint64)
+        out = ctypes.create_string_buffer(ps * cnt)
+        t0 = time.perf_counter()
+        ref.ref_range_prove_batch(n_bits, m, ctypes.c_size_t(cnt), p(PV), p(PR), NONCE_SEED, p(sid), ctypes.c_uint64(0), None, faithful, out)
+        return time.perf_counter() - t0, out.raw, cnt
+
+    def tree(nt, faithful, threads):
+        if have_threads:
+            ref.ref_set_threads(threads)
+        t0 = time.perf_counter()
+        t = ctypes.c_void_p(ref.ref_tree_build(height, ctypes.c_size_t(nt), p(idx[:nt]), p(v[:nt]), p(r[:nt]), PAD_SEED, faithful))
+        dt = time.perf_counter() - t0
+        ref.ref_tree_free(t)
+        return dt
+
+    t_begin = time.perf_counter()
+    prove(1, 0, 1)                                   # untimed: fills the tuned variant's generator cache
+    one_t, _, _ = prove(1, 0, 1)                     # single thread, tuned
+    one_f, _, _ = prove(1, 1, 1)                     # single thread, faithful
+    nt1 = min(len(idx), 256)
+    tree1_t, tree1_f = tree(nt1, 0, 1) / nt1, tree(nt1, 1, 1) / nt1
+    # all cores: pilot of one proof per thread, then a sample sized to the remaining budget (60 % tuned, 40 % faithful)
+    pilot_s, _, npilot = prove(cores, 0, cores)
+    left = max(1.0, budget_s - (time.perf_counter() - t_begin))
+    n_t = int(max(npilot, npilot * 0.5 * left / max(pilot_s, 1e-3)))
+    prove_t, bytes_t, n_t = prove(n_t, 0, cores)
+    n_f = int(max(cores, n_t * 0.35 * one_t / max(one_f, 1e-3)))
+    prove_f, _, n_f = prove(n_f, 1, cores)
+    ntm = min(len(idx), 4096)
+    treem_t, treem_f = tree(ntm, 0, cores) / ntm, tree(ntm, 1, cores) / ntm
+    if have_threads:
+        ref.ref_set_threads(cores)
+    val = 1.0 / (treem_t + prove_t / n_t)
+    res = {"value": val, "unit": "entities/s", "cores": cores, "kind": "port",
+           "cflags": cflags if native else "-O2 generic (%s)" % cflags,
+           "variant": "tuned (generators derived once), all usable cores",
+           "faithful_value": 1.0 / (treem_f + prove_f / n_f),
+           "single_thread_value": 1.0 / (tree1_t + one_t),
+           "single_thread_faithful_value": 1.0 / (tree1_f + one_f),
+           "single_thread_proof_s": one_t, "single_thread_faithful_proof_s": one_f,
+           "host_hw_threads": os.cpu_count(), "cpu_leg_wall_s": time.perf_counter() - t_begin,
+           "sample": "C restatement of the reference path (oracle/ref_dapol.c, OpenMP over entities; NOT the Rust crate: no Rust "
+                     "toolchain in this image): tree build of %d entities at height %d + %d tuned / %d faithful padding-policy "
+                     "proofs m=%d n=%d on %d threads (%.2f s / %.2f s); 1 proof each single-threaded"
+                     % (ntm, height, n_t, n_f, m, n_bits, cores, prove_t, prove_f)}
+    return res, bytes_t, n_t, ps
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--log2-entities", type=int, default=20, help="entities per GPU = 2^this (default: BASELINE configs[2])")
-    ap.add_argument("--height", type=int, default=32)
-    ap.add_argument("--n-bits", type=int, default=64)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+def kernel_src_sha():
+    """Identity of the kernel sources a profile was taken on (profiles/*.json carry it; bench.py quotes a profile only
+    when it matches the build that is running)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "dapol_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
+
+def from_profiles(sha, full_size):
+    """Numbers that THIS run cannot measure (PMC counters need rocprofv3 around the process): quoted from tracked
+    files under profiles/ with the file name and the kernel-source hash they were measured on; `current_build` says
+    whether that is the build running now."""
+    out = {}
+    for key, fn in (("msm_pmc", "msm_pmc.json"), ("valu_roof", "valu_roof.json")):
+        path = os.path.join(ROOT, "profiles", fn)
+        if not os.path.exists(path):
+            continue
+        try:
+            pj = json.load(open(path))
+        except Exception:
+            continue
+        pj = {k: v for k, v in pj.items() if k != "source"}
+        pj["file"] = "profiles/" + fn
+        pj["current_build"] = bool(pj.get("kernel_src_sha") == sha)
+        out[key] = pj
+    out["applies_to_this_workload"] = bool(full_size)
+    return out
+
+
+def init_dist(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N > 1 as `python -m torch.distributed.run --nproc-per-node N bench.py "
+                         "--gpus N ...` (and N = 1 without a launcher)" % (args.gpus, world))
     import torch
     dist = None
+    backend = os.environ.get("DAPOL_BENCH_BACKEND", "nccl")
     if world > 1:
         import torch.distributed as dist
         # One rank per GPU over RCCL.  DAPOL_BENCH_BACKEND=gloo is a test hook: it lets two ranks share one GPU (RCCL refuses
         # duplicate devices), so the whole N > 1 flow can be exercised on a single-GPU box.
-        backend = os.environ.get("DAPOL_BENCH_BACKEND", "nccl")
         local_rank = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+    return rank, local_rank, world, torch, dist, backend
+
+
+def mode_prove(args):
+    rank, local_rank, world, torch, dist, backend = init_dist(args)
+    log("rank %d/%d: torch imported" % (rank, world))
     from __graft_entry__ import build, ORACLE_LIB
     if rank == 0:
         build()
@@ -153,30 +283,80 @@ def main():
     from dapol_amd import capi
     from dapol_amd.sharded import ShardedProver
 
-    n_per_gpu = 1 << args.log2_entities
-    n_total = n_per_gpu * world
+    if args.log2_entities_total is not None:
+        lg_total = args.log2_entities_total
+        n_total = 1 << lg_total
+        if n_total % world:
+            raise SystemExit("--log2-entities-total must give a multiple of the number of GPUs")
+        n_per_gpu = n_total // world
+        scaling = "strong"
+    else:
+        n_per_gpu = 1 << args.log2_entities
+        n_total = n_per_gpu * world
+        lg_total = args.log2_entities + (world.bit_length() - 1)
+        scaling = "weak"
     height, n_bits = args.height, args.n_bits
     idx, v, r = synth_inputs(n_total, height, rank * n_per_gpu, n_per_gpu)
     ctx = capi.Context(local_rank, _np2(height))
-    prover = ShardedProver(ctx, height, idx, v, r, rank, world, dist, torch,
-                           comm_device="cuda" if os.environ.get("DAPOL_BENCH_BACKEND", "nccl") == "nccl" else "cpu")
+    log("context ready (generators + window tables)")
+    comm_device = "cuda" if backend == "nccl" else "cpu"
+    prover = ShardedProver(ctx, height, idx, v, r, rank, world, dist, torch, comm_device=comm_device)
 
     def sync():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
 
+    def agree_min(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.int64, device=comm_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return int(t.item())
+
+    # ---- warm-up: one step always (it also sizes the timed loop), more only if asked for AND they fit
+    deadline = T_PROC0 + args.budget_s
+    post_reserve = 45.0 if not args.no_cpu_baseline else 20.0           # CPU baseline (~12 s) + parity legs + verification
+    warm_req, steps_req = args.warmup, args.steps
+    warm_done = 0
+    t_step = None
+    if warm_req > 0:
+        sync()
+        t0 = time.perf_counter()
+        prover.step(PAD_SEED, NONCE_SEED, n_bits)
+        sync()
+        t_step = time.perf_counter() - t0
+        warm_done = 1
+        if rank == 0:
+            log("warm-up step 1: %.2f s" % t_step)
+    if t_step is not None:
+        fit = int((deadline - time.time() - post_reserve) / (t_step * 1.03))
+        extra_warm = min(warm_req - 1, max(0, fit - steps_req))            # extra warm-ups only out of slack
+        steps = min(steps_req, max(min(3, steps_req), fit - extra_warm))
+    else:
+        extra_warm, steps = 0, steps_req
+    extra_warm, steps = agree_min(extra_warm), agree_min(steps)
+    for _ in range(extra_warm):
+        prover.step(PAD_SEED, NONCE_SEED, n_bits)
+        warm_done += 1
+    if rank == 0 and (steps != steps_req or warm_done != warm_req):
+        log("wall budget %.0f s: running %d timed steps (asked %d) after %d warm-up (asked %d)" % (args.budget_s, steps, steps_req, warm_done, warm_req))
+
+    # ---- timed region: EXACTLY `steps` steps between barrier + synchronize on both sides
+    acc = {"tree_ms": 0.0, "prove_ms": 0.0, "msm_ms": 0.0, "msm_launches": 0, "proofs": 0}
     stats = None
-    for _ in range(args.warmup):
-        stats = prover.step(PAD_SEED, NONCE_SEED, n_bits)
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for s in range(steps):
         stats = prover.step(PAD_SEED, NONCE_SEED, n_bits)
+        for k in acc:
+            acc[k] += getattr(stats, k)
+        if rank == 0:
+            log("step %d/%d done (%.1f s since the timed region began)" % (s + 1, steps, time.perf_counter() - t0))
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=prover.comm_device)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=comm_device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     if rank != 0:
@@ -185,81 +365,212 @@ def main():
             dist.destroy_process_group()
         return
 
-    ms_per_step = elapsed * 1e3 / args.steps
-    value = n_total * args.steps / elapsed
-    ab = algorithmic_bytes(height, n_bits)
-    msm_avg_ms = stats.msm_ms / max(1, stats.msm_launches)
-    ach = (stats.proofs * ab / 1e9) / (stats.msm_ms / 1e3) if stats.msm_ms > 0 else 0.0
-    roofline = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": None,
-                "kernel": "k_rp_msm", "launches": int(stats.msm_launches), "avg_launch_ms": msm_avg_ms,
-                "algorithmic_bytes_per_entity": ab,
-                "note": "achieved/frac use the ALGORITHMIC bytes of SURVEY 8d (6,384 B per entity); the kernel itself is integer-VALU "
-                        "bound (255-bit modular multiply-adds) at the socket power cap and deliberately spends HBM bandwidth on wide "
-                        "(17-bit) window tables: see traffic (measured HBM bytes per launch), valu_roof and DESIGN.md sections 5 and 8"}
-    # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; tools/pmc_summary.py),
-    # measured on full 73,728-proof launches of this kernel; only quoted when this run's launches have that size too.
-    pmc = os.path.join(ROOT, "profiles", "msm_pmc.json")
-    if os.path.exists(pmc) and n_per_gpu >= 60000 and height == 32 and n_bits == 64:
-        try:
-            pj = json.load(open(pmc))
-            roofline["traffic"] = pj.get("hbm_bytes_per_launch")
-            roofline["traffic_GBps"] = pj.get("hbm_GBps")
-            roofline["traffic_frac_of_peak"] = pj.get("hbm_GBps", 0.0) / PEAK_HBM_GBS
-            roofline["valu_cycles_per_inst"] = pj.get("cycles_per_valu_inst_per_simd")
-            # the binding roof: integer-VALU issue.  The same point additions in a register-only loop (tools/ubench_madd.hip,
-            # profiles/r01b_ubench_madd.txt) issue at 4,350 cycles / 1,075 instructions = 4.05 cycles per wave instruction.
-            if pj.get("cycles_per_valu_inst_per_simd"):
-                roofline["valu_issue_frac"] = 4.05 / pj["cycles_per_valu_inst_per_simd"]
-        except Exception:
-            pass
-    # the binding roof in its own units (register-only cost of the kernel's point additions, clocks, socket power)
-    vr = os.path.join(ROOT, "profiles", "valu_roof.json")
-    if roofline.get("traffic") is not None and os.path.exists(vr):
-        try:
-            roofline["valu_roof"] = {k: v for k, v in json.load(open(vr)).items() if k != "source"}
-        except Exception:
-            pass
+    ms_per_step = elapsed * 1e3 / steps
+    value = n_total * steps / elapsed
+    ab_prove, ab_tree = algorithmic_bytes(height, n_bits, lg_total)
+    # Dominant kernel: k_rp_msm (fixed-base MSM; S commitment, never-fold rounds, materialisation).  Its launches are
+    # bracketed by HIP events on the stream they run on, inside the library (MsmTiming); summed over the timed steps.
+    msm_s = acc["msm_ms"] / 1e3
+    launches = int(acc["msm_launches"])
+    avg_launch_ms = acc["msm_ms"] / max(1, launches)
+    units_per_launch = acc["proofs"] / max(1, launches)               # entities whose bytes one launch accounts for (proofs / launches)
+    ach = (acc["proofs"] * ab_prove / 1e9) / msm_s if msm_s > 0 else 0.0
+    sha = kernel_src_sha()
+    full_size = n_per_gpu >= 73728 and height == 32 and n_bits == 64
+    prof = from_profiles(sha, full_size)
+    traffic = None
+    pmc = prof.get("msm_pmc")
+    if pmc and pmc.get("current_build") and full_size:
+        traffic = pmc.get("hbm_bytes_per_launch")                      # PMC passes of THIS build (tools/profile_round.sh), per full launch
+    roofline = {
+        "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": traffic,
+        "kernel": "k_rp_msm", "launches": launches, "avg_launch_ms": avg_launch_ms, "kernel_time_s": msm_s,
+        "algorithmic_bytes_per_entity": ab_prove, "entities_per_launch_share": units_per_launch,
+        "whole_step": {"algorithmic_bytes_per_entity": ab_prove + ab_tree,
+                       "achieved": (n_per_gpu * steps * (ab_prove + ab_tree) / 1e9) / elapsed,
+                       "frac": (n_per_gpu * steps * (ab_prove + ab_tree) / 1e9) / elapsed / PEAK_HBM_GBS,
+                       "note": "tree + proof bytes (SURVEY 8d: 9,136 B at 2^20 x H=32) over the whole step time, per GPU"},
+        "kernel_share_of_step": msm_s / elapsed if elapsed > 0 else None,
+        "note": "achieved = ALGORITHMIC bytes (SURVEY 8d, prove path: 6,384 B per entity at H=32) of all timed proofs / summed k_rp_msm "
+                "time of this run (= per-launch bytes / average launch duration).  By construction ~1e-5 of the HBM peak: the path does "
+                "~1e7 modular multiplications per 9 KB of compulsory traffic; the binding roof is integer-VALU issue at the socket power "
+                "cap (DESIGN.md sections 5, 8).  `traffic` is only set from a PMC pass of the build that is running; older profiles "
+                "are under from_profiles with their build hash.",
+        "kernel_src_sha": sha, "from_profiles": prof}
     cpu = None
     parity = None
-    if not args.no_cpu_baseline and os.path.exists(ORACLE_LIB):
-        ref = ctypes.CDLL(ORACLE_LIB)
+    if not args.no_cpu_baseline and os.path.exists(ORACLE_LIB) and prover.w is not None:
+        log("CPU baseline + parity legs")
         ns_max = 4096
         sample_ids = idx[:: max(1, n_per_gpu // ns_max)][:ns_max]
         sv, sr = prover.sample_paths(sample_ids, PAD_SEED)
         # The timed CPU baseline is reported at N = 1 only; at N > 1 the same code runs with a 2-second budget, purely as
         # the parity check of rank 0's shard (the sharded tree must give the bytes the oracle gives for those siblings).
-        cpu, cpu_bytes, ns, ps = cpu_baseline(ref, height, n_bits, idx, v, r, (sv, sr, sample_ids), budget_s=20.0 if world == 1 else 2.0)
+        cpu, cpu_bytes, ns, ps = cpu_baseline(ORACLE_LIB, height, n_bits, idx, v, r, (sv, sr, sample_ids),
+                                              budget_s=args.cpu_budget_s if world == 1 else 2.0)
         gpu_bytes = prover.sample_proofs(sample_ids[:ns], ps)
         parity = {"proofs_compared": ns, "bit_exact": bool(gpu_bytes.tobytes() == cpu_bytes)}
         if world > 1:
             cpu = None
     # encode -> verify round trip at full size: sampled inclusion proofs of the timed run through DapolProof::verify on the GPU
-    nv = min(2048, n_per_gpu)
-    vids = np.ascontiguousarray(idx[:: max(1, n_per_gpu // nv)][:nv])
-    vpos = np.searchsorted(idx, vids)
-    _, _, vC, vH = prover.sample_paths(vids, PAD_SEED, with_nodes=True)
-    lC, lH = ctx.commit_hash_batch(v[vpos], r[vpos])
-    vproofs = prover.sample_proofs(vids, int(stats.proof_bytes // max(1, stats.proofs)))
-    rC, rH = prover.root[0], prover.root[1]
-    okv = ctx.verify_entities(height, vids, lC, lH, vC, vH, rC, rH, capi.POLICY_PADDING, height, n_bits, vproofs, verify_seed=PAD_SEED)
-    parity = dict(parity or {}, inclusion_proofs_verified_on_gpu=int(okv.sum()), inclusion_proofs_checked=int(len(okv)))
+    if prover.w is not None:
+        nv = min(2048, n_per_gpu)
+        vids = np.ascontiguousarray(idx[:: max(1, n_per_gpu // nv)][:nv])
+        vpos = np.searchsorted(idx, vids)
+        _, _, vC, vH = prover.sample_paths(vids, PAD_SEED, with_nodes=True)
+        lC, lH = ctx.commit_hash_batch(v[vpos], r[vpos])
+        vproofs = prover.sample_proofs(vids, int(stats.proof_bytes // max(1, stats.proofs)))
+        rC, rH = prover.root[0], prover.root[1]
+        okv = ctx.verify_entities(height, vids, lC, lH, vC, vH, rC, rH, capi.POLICY_PADDING, height, n_bits, vproofs, verify_seed=os.urandom(32))
+        parity = dict(parity or {}, inclusion_proofs_verified_on_gpu=int(okv.sum()), inclusion_proofs_checked=int(len(okv)))
     line = {
-        "metric": "entities/sec (tree build + 64-bit range-proof gen), 2^20 leaves, 1/2/4/8 GPU",
-        "value": value, "unit": "entities/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "metric": METRIC,
+        "value": value, "unit": "entities/s", "n_gpus": world, "steps": steps, "warmup": warm_done,
+        "steps_requested": steps_req, "warmup_requested": warm_req,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "int32 limbs (255-bit modular integers)", "data": "synthetic",
         "config": {"workload": "2^%d entities%s, height=%d, %d-bit range proofs, padding policy, aggregation_factor=height, BLAKE3 node hash"
-                               % (args.log2_entities, " per GPU" if world > 1 else "", height, n_bits),
-                   "entities_total": n_total, "proof_bytes": int(stats.proof_bytes // max(1, stats.proofs)),
+                               % (lg_total if scaling == "strong" else args.log2_entities,
+                                  " in total" if scaling == "strong" and world > 1 else (" per GPU" if world > 1 else ""), height, n_bits),
+                   "entities_total": n_total, "entities_per_gpu": n_per_gpu, "proof_bytes": int(stats.proof_bytes // max(1, stats.proofs)),
                    "sharding": "none" if world == 1 else "top-level subtrees, all-gather of %d subtree roots" % world},
-        "phases_ms": {"tree_build": stats.tree_ms, "prove": stats.prove_ms},
+        "phases_ms": {"tree_build": acc["tree_ms"] / steps, "prove": acc["prove_ms"] / steps},
         "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
         "checksum": "%016x" % stats.checksum,
+        "wall_s_since_process_start": time.time() - T_PROC0,
     }
     print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def mode_build(args):
+    """The reference's `build` criterion group (benches/dapol.rs:24-57): Dapol::new_blank + build over pre-made leaf nodes,
+    strided leaves, h in {16, 32} x N in {1024, 2048, 4096}; plus the headline tree (2^20 x 32).  Inputs resident in HBM."""
+    import torch
+    from __graft_entry__ import build, ORACLE_LIB
+    build()
+    from dapol_amd import capi
+    ctx = capi.Context(0, 32)
+    ref = ctypes.CDLL(ORACLE_LIB) if os.path.exists(ORACLE_LIB) and not args.no_cpu_baseline else None
+    if ref is not None:
+        ref.ref_tree_build.restype = ctypes.c_void_p
+    rows = []
+    cases = [(h, n) for h in (16, 32) for n in (1024, 2048, 4096)] + [(args.height, 1 << args.log2_entities)]
+    for h, n in cases:
+        idx, v, r = synth_inputs(n, h, 0, n)
+        w = capi.Workload(ctx, h, idx, v, r)
+        root, st = w.build(PAD_SEED)                       # warm-up
+        torch.cuda.synchronize()
+        reps = max(3, min(args.steps if args.steps > 1 else 10, 50))
+        t0 = time.perf_counter()
+        dev_ms = 0.0
+        for _ in range(reps):
+            root, st = w.build(PAD_SEED)
+            dev_ms += st.tree_ms
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / reps
+        row = {"height": h, "entities": n, "wall_ms": wall * 1e3, "device_ms": dev_ms / reps, "entities_per_s": n / wall,
+               "root_value": root[2]}
+        if ref is not None and n <= 4096:
+            p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+            t0 = time.perf_counter()
+            t = ctypes.c_void_p(ref.ref_tree_build(h, ctypes.c_size_t(n), p(idx), p(v), p(r), PAD_SEED, 1))
+            row["cpu_faithful_ms"] = (time.perf_counter() - t0) * 1e3
+            oC, oH, orr, ov = [ctypes.create_string_buffer(32) for _ in range(3)] + [ctypes.c_uint64()]
+            ref.ref_tree_root(t, oC, oH, ctypes.byref(ov), orr)
+            ref.ref_tree_free(t)
+            row["root_bit_exact_vs_oracle"] = bool((oC.raw, oH.raw, ov.value, orr.raw) == root)
+        rows.append(row)
+        w.close()
+        log("build h=%d n=%d: %.3f ms" % (h, n, wall * 1e3))
+    big = rows[-1]
+    ab_prove, ab_tree = algorithmic_bytes(args.height, args.n_bits, args.log2_entities)
+    ach = big["entities"] * ab_tree / 1e9 / (big["device_ms"] / 1e3)
+    print(json.dumps({"metric": "tree build (Dapol::new_blank + build), entities/s", "value": big["entities_per_s"], "unit": "entities/s",
+                      "n_gpus": 1, "higher_is_better": True, "data": "synthetic", "dtype": "int32 limbs (255-bit modular integers)",
+                      "config": {"workload": "benches/dapol.rs:24-57 build group + 2^%d x height %d" % (args.log2_entities, args.height)},
+                      "cases": rows,
+                      "roofline": {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": None,
+                                   "kernel": "k_tree_merge (+ scan / flags)", "algorithmic_bytes_per_entity": ab_tree}}), flush=True)
+
+
+def mode_verify(args):
+    """BASELINE configs[4] on one GPU: verification-only throughput of aggregated Bulletproofs with m = 1,024 parties of 64
+    bits (the reference's `verify` group is benches/dapol.rs:93-141).  The proofs are made by this build's prover first
+    (untimed); then dapol_range_verify_batch over resident... host buffers is timed (host-inclusive: H2D of proofs + commitments)."""
+    import torch
+    from __graft_entry__ import build, ORACLE_LIB
+    build()
+    from dapol_amd import capi
+    B, m, n = args.verify_proofs, args.verify_parties, 64
+    ctx = capi.Context(0, m)
+    rng = np.random.default_rng(5)
+    v = rng.integers(0, 2**32, size=(B, m), dtype=np.uint64)
+    r = rng.integers(0, 256, size=(B, m, 32), dtype=np.uint8)
+    r[:, :, 31] &= 0x0F
+    log("proving %d x m=%d (untimed setup)" % (B, m))
+    proofs = ctx.range_prove_batch(n, m, v, r, nonce_seed=NONCE_SEED, stream_id=np.arange(B, dtype=np.uint64))
+    C, _ = ctx.commit_hash_batch(v.reshape(-1), r.reshape(-1, 32))
+    Vs = C.reshape(B, m, 32)
+    seed = os.urandom(32)
+    for _ in range(max(1, args.warmup)):
+        ok = ctx.range_verify_batch(n, m, proofs, Vs, verify_seed=seed)
+    torch.cuda.synchronize()
+    steps = max(args.steps, 5)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ok = ctx.range_verify_batch(n, m, proofs, Vs, verify_seed=seed)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    bad = proofs.copy()
+    bad[B // 3, 100] ^= 1
+    ok_bad = ctx.range_verify_batch(n, m, bad, Vs, verify_seed=seed)
+    cpu = None
+    if not args.no_cpu_baseline and os.path.exists(ORACLE_LIB):
+        ref = ctypes.CDLL(ORACLE_LIB)
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        c32 = bytes(range(1, 33))
+        t0 = time.perf_counter()
+        okc = ref.ref_range_verify(n, m, proofs[0].tobytes(), ctypes.c_size_t(proofs.shape[1]), p(np.ascontiguousarray(Vs[0])), c32, 0)
+        t1 = time.perf_counter() - t0
+        cpu = {"value": m / t1, "unit": "commitments/s", "cores": 1, "kind": "port", "sample": "one m=%d proof, tuned, single thread: %.2f s; verdict %d" % (m, t1, okc)}
+    ab = proofs.shape[1] + m * 32
+    print(json.dumps({"metric": "verification-only throughput, aggregated Bulletproofs (m=%d), commitments/s" % m, "value": B * m / dt,
+                      "unit": "commitments/s", "n_gpus": 1, "steps": steps, "ms_per_step": dt * 1e3, "higher_is_better": True, "data": "synthetic",
+                      "dtype": "int32 limbs (255-bit modular integers)",
+                      "config": {"workload": "%d proofs x m=%d x n=64 (proof %d bytes), host-inclusive" % (B, m, proofs.shape[1])},
+                      "all_verified": bool(ok.all()), "one_bad_proof_found": bool(ok_bad[B // 3] == 0 and ok_bad.sum() == B - 1),
+                      "roofline": {"bound": "hbm", "achieved": B * ab / 1e9 / dt, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                   "frac": B * ab / 1e9 / dt / PEAK_HBM_GBS, "traffic": None, "algorithmic_bytes_per_proof": ab},
+                      "cpu_baseline": cpu}), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--mode", choices=("prove", "build", "verify"), default="prove")
+    ap.add_argument("--budget-s", type=float, default=450.0,
+                    help="wall budget of the whole process, counted from its start; the timed steps are clamped to fit (>= 3)")
+    ap.add_argument("--cpu-budget-s", type=float, default=10.0, help="wall budget of the CPU-baseline leg")
+    ap.add_argument("--log2-entities", type=int, default=20, help="entities per GPU = 2^this (default: BASELINE configs[2])")
+    ap.add_argument("--log2-entities-total", type=int, default=None, help="fix the TOTAL entity count instead (strong scaling)")
+    ap.add_argument("--height", type=int, default=32)
+    ap.add_argument("--n-bits", type=int, default=64)
+    ap.add_argument("--verify-proofs", type=int, default=1024)
+    ap.add_argument("--verify-parties", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    if args.steps < 1 or args.warmup < 0:
+        raise SystemExit("--steps must be >= 1 and --warmup >= 0")
+    if args.mode == "build":
+        return mode_build(args)
+    if args.mode == "verify":
+        return mode_verify(args)
+    return mode_prove(args)
 
 
 if __name__ == "__main__":

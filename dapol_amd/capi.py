@@ -228,7 +228,7 @@ class Context:
         return out
 
     def verify_entities(self, height, leaf_idx, leaf_C, leaf_H, path_C, path_H, root_C, root_H, policy, aggregation_factor, n_bits, range_proofs,
-                        verify_seed=bytes(32)):
+                        verify_seed=None):
         """DapolProof::verify for single-leaf proofs (Merkle re-merge + policy range verification)."""
         leaf_idx = _u64(leaf_idx)
         b = leaf_idx.shape[0]
@@ -236,14 +236,14 @@ class Context:
         pC, pH = _u8(path_C).reshape(b, height, 32), _u8(path_H).reshape(b, height, 32)
         rp = _u8(range_proofs).reshape(b, -1)
         rC, rH = _u8(np.frombuffer(root_C, np.uint8)), _u8(np.frombuffer(root_H, np.uint8))
-        seed = _u8(np.frombuffer(verify_seed, np.uint8))
+        seed = _u8(np.frombuffer(verify_seed, np.uint8)) if verify_seed is not None else None   # None: the library draws one from the OS
         ok = np.zeros(b, np.uint8)
         _chk(lib().dapol_verify_entities(self.h, height, b, _ptr(leaf_idx), _ptr(lC), _ptr(lH), _ptr(pC), _ptr(pH), _ptr(rC), _ptr(rH), policy,
                                          aggregation_factor, n_bits, _ptr(rp), _ptr(seed), _ptr(ok)))
         return ok
 
     def verify_batch(self, height, leaf_idx, leaf_C, leaf_H, sib_C, sib_H, root_C, root_H, policy, aggregation_factor, n_bits, range_proofs,
-                     verify_seed=bytes(32)):
+                     verify_seed=None):
         """DapolProof::verify_batch: one proof covering k leaves."""
         leaf_idx = _u64(leaf_idx)
         k = leaf_idx.shape[0]
@@ -251,18 +251,18 @@ class Context:
         sC, sH = _u8(sib_C).reshape(-1, 32), _u8(sib_H).reshape(-1, 32)
         rp = _u8(np.frombuffer(bytes(range_proofs), np.uint8))
         rC, rH = _u8(np.frombuffer(root_C, np.uint8)), _u8(np.frombuffer(root_H, np.uint8))
-        seed = _u8(np.frombuffer(verify_seed, np.uint8))
+        seed = _u8(np.frombuffer(verify_seed, np.uint8)) if verify_seed is not None else None   # None: the library draws one from the OS
         ok = np.zeros(1, np.uint8)
         _chk(lib().dapol_verify_batch(self.h, height, k, _ptr(leaf_idx), _ptr(lC), _ptr(lH), sC.shape[0], _ptr(sC), _ptr(sH), _ptr(rC), _ptr(rH),
                                       policy, aggregation_factor, n_bits, _ptr(rp), _ptr(seed), _ptr(ok)))
         return bool(ok[0])
 
-    def range_verify_batch(self, n_bits, m, proofs, V32, verify_seed=bytes(32)):
+    def range_verify_batch(self, n_bits, m, proofs, V32, verify_seed=None):
         proofs = _u8(proofs)
         b = proofs.shape[0]
         V32 = _u8(V32, b, m, 32)
         ok = np.zeros(b, np.uint8)
-        seed = _u8(np.frombuffer(verify_seed, np.uint8))
+        seed = _u8(np.frombuffer(verify_seed, np.uint8)) if verify_seed is not None else None   # None: the library draws one from the OS
         _chk(lib().dapol_range_verify_batch(self.h, n_bits, m, b, _ptr(proofs), _ptr(V32), _ptr(seed), _ptr(ok)))
         return ok
 

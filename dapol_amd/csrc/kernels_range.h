@@ -20,6 +20,7 @@ struct ProofState {             // per proof, lives in HBM between phase kernels
     uint32_t err, pad_;
     sc y, z, y_inv, x, w, u, u_inv;     // Montgomery form
     sc a_bl, s_bl, t1, t2, t1_bl, t2_bl, t_x, cL, cR;
+    uint32_t nkey[8];           // seed mode: this proof's nonce key (k_rp_nonce_key), bound to its statement
 };
 
 struct RangeArgs {
@@ -63,10 +64,37 @@ __device__ __forceinline__ void tape_wide(uint32_t* w16, const RangeArgs& A, siz
         const uint4* p = reinterpret_cast<const uint4*>(A.tape + ((size_t)b * (size_t)(A.m * (2 * A.n + 4)) + slot) * 16);
         for (int i = 0; i < 4; i++) { uint4 q = p[i]; w16[4 * i] = q.x; w16[4 * i + 1] = q.y; w16[4 * i + 2] = q.z; w16[4 * i + 3] = q.w; }
     } else {
-        uint32_t seed[8];
-        for (int i = 0; i < 8; i++) seed[i] = A.seed[i];
-        seed_wide(w16, seed, 2u, A.stream_id[b], A.slot_base + slot);
+        uint32_t key[8];
+        for (int i = 0; i < 8; i++) key[i] = A.st[b].nkey[i];
+        seed_wide(w16, key, 2u, A.stream_id[b], A.slot_base + slot);
     }
+}
+// Seed mode: the key of one proof's nonce stream.  The reference's prover draws fresh thread_rng randomness on every call;
+// a deterministic stream must therefore be bound to the STATEMENT it blinds, or re-proving a leaf whose siblings changed
+// (dapol_tree_update, another policy / aggregation factor) would reuse a_blinding, s_L, s_R ... against new challenges and
+// leak the siblings' secrets.  key = chain over the parties' value commitments (31 per BLAKE3 chunk), started from
+// seed -> (domain 6: stream id, first slot) -> (domain 7: bits, parties).  Same statement => same nonces => same proof.
+__global__ __launch_bounds__(64) void k_rp_nonce_key(RangeArgs A) {
+    size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (b >= A.B || A.tape) return;
+    uint32_t key[8], w[16];
+    for (int i = 0; i < 8; i++) key[i] = A.seed[i];
+    seed_wide(w, key, 6u, A.stream_id[b], A.slot_base);
+    for (int i = 0; i < 8; i++) key[i] = w[i];
+    seed_wide(w, key, 7u, (uint64_t)A.n, (uint64_t)A.m);
+    for (int i = 0; i < 8; i++) key[i] = w[i];
+    for (int j0 = 0; j0 < A.m; j0 += 31) {
+        Digest d;
+        dg_init(d, DG_BLAKE3);
+        dg_update_words(d, key, 8);
+        for (int j = j0; j < A.m && j < j0 + 31; j++) {
+            uint32_t v[8];
+            ld8(v, A.Vc + (b * A.m + j) * 8);
+            dg_update_words(d, v, 8);
+        }
+        dg_final(d, key);
+    }
+    for (int i = 0; i < 8; i++) A.st[b].nkey[i] = key[i];
 }
 __device__ __forceinline__ void tape_scalar(sc& r, const RangeArgs& A, size_t b, uint32_t slot) {
     uint32_t w[16];

@@ -16,6 +16,7 @@ struct VerifyState {                 // per proof
     sc ypow[RV_MAX_ROUNDS], zpow[RV_MAX_LGM];   // y^-(2^k), z^(2^k): a table entry is the product over the set bits of its exponent
     uint32_t ok, st_pos, st_pos_begin, pad_;
     uint64_t st[25];                 // STROBE state after the m commitments (k_rv_absorb_V -> k_rv_transcript)
+    uint32_t dg[8];                  // digest of the whole statement + proof (transcript after a, b): input of the batch weights
 };
 struct VerifyArgs {
     RangeArgs R;                     // reuses n, m, N, lgN, TP, B, Vc, dig, P0, P1, PA(=P2), out(=proof words), out_words, seed
@@ -278,16 +279,63 @@ __global__ __launch_bounds__(64) void k_rv_transcript(VerifyArgs V) {
         for (int k = 0; k < RV_MAX_LGM; k++) { vs.zpow[k] = p; sc_montsq(p, p); }
     }
     sc_to_mont(vs.t_x, tx); sc_to_mont(vs.tau, tau); sc_to_mont(vs.mu, mu); sc_to_mont(vs.a, aw); sc_to_mont(vs.b, bw);
-    // batching scalar c: Scalar::random(rng) in the crate; here seed mode, domain 3, keyed by the proof's position
-    uint32_t seed[8], wide[16];
-    for (int i = 0; i < 8; i++) seed[i] = A.seed[i];
-    seed_wide(wide, seed, 3u, (uint64_t)b, 0);
+    // Digest of everything this proof's check depends on: the transcript has absorbed n, m, every commitment and every proof
+    // element except the final a, b -- append those and squeeze.  The batching scalars (k_rv_weights) are derived from it, so
+    // they are bound to the data they weigh: soundness-critical, see k_rv_weights.
+    {
+        uint32_t wide[16];
+        append_scalar(s, "a", 1, aw);
+        append_scalar(s, "b", 1, bw);
+        merlin_challenge_wide(s, "dapol-batch", 11, wide);
+        for (int i = 0; i < 8; i++) vs.dg[i] = wide[i];
+    }
+    vs.ok = ok ? 1u : 0u;
+}
+
+// Digest of a batch of proofs: BLAKE3 tree over the per-proof digests, 31 per chunk; (level, count, group) lead every chunk.
+// in: n digests of 8 words, `stride` words apart; out: ceil(n / 31) digests, packed.
+__global__ __launch_bounds__(64) void k_rv_digest_level(size_t n, int level, const uint32_t* in, size_t stride, uint32_t* out) {
+    size_t g = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (g >= (n + 30) / 31) return;
+    Digest d;
+    dg_init(d, DG_BLAKE3);
+    uint32_t head[8] = {(uint32_t)level, (uint32_t)n, (uint32_t)((uint64_t)n >> 32), (uint32_t)g, (uint32_t)((uint64_t)g >> 32), 0x6c6f7061u, 0, 0};
+    dg_update_words(d, head, 8);
+    for (size_t i = g * 31; i < n && i < g * 31 + 31; i++) {
+        uint32_t w[8];
+        for (int k = 0; k < 8; k++) w[k] = in[i * stride + k];
+        dg_update_words(d, w, 8);
+    }
+    uint32_t o[8];
+    dg_final(d, o);
+    for (int k = 0; k < 8; k++) out[g * 8 + k] = o[k];
+}
+// The verifier's random scalars (lane per proof): c combines the two equations of one proof (Scalar::random(thread_rng) in
+// the crate's verify_multiple), rho weighs the proof inside a cross-proof batch (not in the reference).  SOUNDNESS: a weight
+// an adversary can predict can be cancelled -- proof q carries A' = A + kappa B with kappa = -rho_p c_p eps / rho_q against
+// the residual eps of an out-of-range proof p, and the batch sums to the identity.  Both are therefore derived from
+// key = BLAKE3(verify_seed | D), D = the digest of EVERY proof and commitment of the batch (D == nullptr: of this proof
+// alone, for the per-proof check): changing any byte of any proof changes every weight (Fiat-Shamir), and with a secret
+// seed (the library draws one from the OS when the caller passes none) they are unpredictable outright.
+__global__ __launch_bounds__(64) void k_rv_weights(VerifyArgs V, const uint32_t* D) {
+    const RangeArgs& A = V.R;
+    size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (b >= A.B) return;
+    VerifyState& vs = V.vs[b];
+    uint32_t w8[8], key[8], wide[16];
+    Digest d;
+    dg_init(d, DG_BLAKE3);
+    for (int i = 0; i < 8; i++) w8[i] = A.seed[i];
+    dg_update_words(d, w8, 8);
+    for (int i = 0; i < 8; i++) w8[i] = D ? D[i] : vs.dg[i];
+    dg_update_words(d, w8, 8);
+    dg_final(d, key);
+    seed_wide(wide, key, 3u, (uint64_t)b, (uint64_t)A.B);
     sc_from_wide(vs.c, wide);
     if (sc_is_zero(vs.c)) sc_one_mont(vs.c);
-    seed_wide(wide, seed, 5u, (uint64_t)b, 0);
+    seed_wide(wide, key, 5u, (uint64_t)b, (uint64_t)A.B);
     sc_from_wide(vs.rho, wide);
     if (sc_is_zero(vs.rho)) sc_one_mont(vs.rho);
-    vs.ok = ok ? 1u : 0u;
 }
 
 // V2a: the power tables of every proof (lane per entry).  grid = B * ceil(tab_stride / 64) blocks.

@@ -96,10 +96,14 @@ class ShardedProver:
         return st
 
     def sample_paths(self, leaf_ids, pad_seed, with_nodes=False):
+        if self.w is None:
+            raise capi.DapolError(9, "this rank's shard holds no liabilities: nothing to sample")
         return self.w.paths(leaf_ids, upper=self.upper, with_nodes=with_nodes)
 
     def sample_proofs(self, leaf_ids, proof_size):
         """Proofs of the given leaves from the last step (leaf_ids must be leaves of this rank, any order)."""
+        if self.w is None:
+            raise capi.DapolError(9, "this rank's shard holds no liabilities: nothing to sample")
         pos = np.searchsorted(self.idx, np.ascontiguousarray(leaf_ids, np.uint64))
         out = np.zeros((len(pos), proof_size), np.uint8)
         for k, p in enumerate(pos):

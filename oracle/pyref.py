@@ -478,17 +478,35 @@ def seed_wide(seed32: bytes, domain: int, a: int, b: int) -> bytes:
     return blake3_keyed(seed32, struct.pack("<IQQ", domain, a, b), 64)
 
 
+def nonce_key(seed32: bytes, stream_id: int, slot_base: int, n: int, m: int, commitments) -> bytes:
+    """Seed mode: key of one proof's nonce stream, bound to the statement it blinds (stream, first slot, shape and the
+    parties' value commitments, 31 per BLAKE3 chunk) -- include/dapol_hip.h "Randomness contract".  The crate draws from
+    thread_rng; a deterministic stream that ignored the statement would reuse nonces when a leaf is proved again after
+    its siblings changed."""
+    key = seed_wide(seed32, 6, stream_id, slot_base)[:32]
+    key = seed_wide(key, 7, n, m)[:32]
+    for j0 in range(0, m, 31):
+        key = blake3(key + b"".join(commitments[j0:j0 + 31]))
+    return key
+
+
 class Tape:
     """Sequence of wide scalars (Scalar::random draws) in the order the crate draws them."""
 
     def __init__(self, draws=None, seed=None, domain=DOMAIN_NONCE, stream_id=0):
         self.draws, self.seed, self.domain, self.stream_id, self.pos = draws, seed, domain, stream_id, 0
+        self.key = None
+
+    def rekey(self, n, m, commitments):
+        """Called by the prover once the parties' commitments exist and before its first draw."""
+        if self.draws is None:
+            self.key = nonce_key(self.seed, self.stream_id, self.pos, n, m, commitments)
 
     def next_wide(self) -> bytes:
         if self.draws is not None:
             w = self.draws[self.pos]
         else:
-            w = seed_wide(self.seed, self.domain, self.stream_id, self.pos)
+            w = seed_wide(self.key if self.key is not None else self.seed, self.domain, self.stream_id, self.pos)
         self.pos += 1
         return w
 
@@ -555,8 +573,10 @@ def range_prove(values, blindings, n, tape: Tape, label=b""):
     tr.rangeproof_domain_sep(n, m)
     # Party::new + assign_position_with_rng
     parties = []
+    Vs = [pedersen_commit(v, vb).compress() for v, vb in zip(values, blindings)]
+    tape.rekey(n, m, Vs)
     for j, (v, vb) in enumerate(zip(values, blindings)):
-        V = pedersen_commit(v, vb).compress()
+        V = Vs[j]
         a_bl = tape.scalar()
         A = a_bl * B_BLINDING
         for i in range(n):

@@ -17,6 +17,18 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include "ref_math.h"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* Thread count of the OpenMP loops below (bench.py times the baseline single-threaded and on all usable cores). */
+void ref_set_threads(int n) {
+#ifdef _OPENMP
+    omp_set_num_threads(n < 1 ? 1 : n);
+#else
+    (void)n;
+#endif
+}
 
 /* ------------------------------------------------------------------------------------------- Keccak */
 static const uint64_t KRC[24] = {0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808AULL, 0x8000000080008000ULL,
@@ -249,12 +261,29 @@ static void commit_with(pt* out, uint64_t v, const uint8_t r32[32], const pt* bb
 static void commit(pt* out, uint64_t v, const uint8_t r32[32]) { commit_with(out, v, r32, &REF_BB); }
 
 /* ------------------------------------------------------------------------------------------- tape */
-typedef struct { const uint8_t* tape; const uint8_t* seed; uint64_t stream, slot_base; } tape_t;
+typedef struct { const uint8_t* tape; const uint8_t* seed; uint64_t stream, slot_base; uint8_t key[32]; } tape_t;
 static void tape_scalar(scl* out, const tape_t* t, uint32_t slot) {
     uint8_t w[64];
     if (t->tape) memcpy(w, t->tape + 64 * (size_t)slot, 64);
-    else ref_seed_wide(w, t->seed, 2, t->stream, t->slot_base + slot);
+    else ref_seed_wide(w, t->key, 2, t->stream, t->slot_base + slot);
     sc_from_wide(out, w);
+}
+/* Seed mode: the nonce key of one proof, bound to its statement (include/dapol_hip.h "Randomness contract"):
+ * seed -> (domain 6: stream id, first slot) -> (domain 7: bits, parties) -> chained BLAKE3 over the value commitments,
+ * 31 per chunk.  Vc: [m][32]. */
+static void tape_rekey(tape_t* t, int n, int m, const uint8_t* Vc) {
+    if (t->tape) return;
+    uint8_t w[64], buf[1024];
+    ref_seed_wide(w, t->seed, 6, t->stream, t->slot_base);
+    memcpy(t->key, w, 32);
+    ref_seed_wide(w, t->key, 7, (uint64_t)n, (uint64_t)m);
+    memcpy(t->key, w, 32);
+    for (int j0 = 0; j0 < m; j0 += 31) {
+        int cnt = m - j0 < 31 ? m - j0 : 31;
+        memcpy(buf, t->key, 32);
+        memcpy(buf + 32, Vc + 32 * (size_t)j0, 32 * (size_t)cnt);
+        blake3_hash(t->key, buf, 32 + 32 * (size_t)cnt);
+    }
 }
 
 /* ------------------------------------------------------------------------------------------- prover */
@@ -318,7 +347,7 @@ int ref_range_prove(int n, int m, const uint64_t* v, const uint8_t* r32, const u
     ensure_bb();
     if (!(n == 8 || n == 16 || n == 32 || n == 64) || m < 1 || (m & (m - 1))) return 1;
     size_t N = (size_t)n * m;
-    tape_t tp = {tape, seed, stream, slot_base};
+    tape_t tp = {tape, seed, stream, slot_base, {0}};
     pt *G, *H, *fg, *fh;
     G = H = NULL;
     get_gens(&G, &H, n, m, faithful, &fg, &fh);
@@ -335,11 +364,16 @@ int ref_range_prove(int n, int m, const uint64_t* v, const uint8_t* r32, const u
     pt_identity(&A); pt_identity(&S);
     scl* msm_s = (scl*)malloc(sizeof(scl) * (2 * n + 1));
     pt* msm_p = (pt*)malloc(sizeof(pt) * (2 * n + 1));
-    for (int j = 0; j < m; j++) {                             /* Party::new + assign_position_with_rng */
+    uint8_t* Vall = (uint8_t*)malloc(32 * (size_t)m);
+    for (int j = 0; j < m; j++) {                             /* Party::new: V_j = commit(v_j, v_blinding_j) */
         pt V;
-        uint8_t Vc[32], ab[32];
         commit(&V, v[j], r32 + 32 * j);
-        pt_compress(Vc, &V);
+        pt_compress(Vall + 32 * (size_t)j, &V);
+    }
+    tape_rekey(&tp, n, m, Vall);
+    for (int j = 0; j < m; j++) {                             /* assign_position_with_rng */
+        uint8_t ab[32];
+        const uint8_t* Vc = Vall + 32 * (size_t)j;
         tr_append(&tr, "V", Vc, 32);
         uint32_t base = (uint32_t)(j * (2 * n + 2));
         tape_scalar(&a_bl[j], &tp, base);
@@ -360,7 +394,7 @@ int ref_range_prove(int n, int m, const uint64_t* v, const uint8_t* r32, const u
         pt_add(&A, &A, &Aj);
         pt_add(&S, &S, &Sj);
     }
-    free(msm_s); free(msm_p);
+    free(msm_s); free(msm_p); free(Vall);
     uint8_t* o = proof_out;
     pt_compress(o, &A); pt_compress(o + 32, &S);
     tr_append(&tr, "A", o, 32); tr_append(&tr, "S", o + 32, 32);

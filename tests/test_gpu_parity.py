@@ -152,11 +152,14 @@ def test_tape_mode_equals_seed_mode(gpu_ctx, pyref):
     n, m, b = 16, 4, 3
     slots = m * (2 * n + 4)
     sid = [11, 2**40 + 3, 0]
-    tape = np.frombuffer(b"".join(pyref.seed_wide(SEED, 2, s, k) for s in sid for k in range(slots)), np.uint8)
     rng = np.random.default_rng(5)
     v = rng.integers(0, 2**16, size=(b, m), dtype=np.uint64)
     r = rng.integers(0, 256, size=(b, m, 32), dtype=np.uint8)
     r[:, :, 31] &= 0x0F
+    # seed mode draws from a key bound to the statement (stream, first slot, shape, value commitments): the tape replays it
+    C, _ = gpu_ctx.commit_hash_batch(v.reshape(-1), r.reshape(-1, 32))
+    keys = [pyref.nonce_key(SEED, s, 0, n, m, [C[i * m + j].tobytes() for j in range(m)]) for i, s in enumerate(sid)]
+    tape = np.frombuffer(b"".join(pyref.seed_wide(keys[i], 2, s, k) for i, s in enumerate(sid) for k in range(slots)), np.uint8)
     a = gpu_ctx.range_prove_batch(n, m, v, r, nonce_seed=SEED, stream_id=sid)
     t = gpu_ctx.range_prove_batch(n, m, v, r, tape=tape)
     assert a.tobytes() == t.tobytes()

@@ -84,9 +84,12 @@ def test_range_proofs_and_verify(ref):
 def test_tape_mode_equals_seed_mode(ref, pyref):
     n, m, seed, sid = 8, 4, bytes(range(32)), 42
     slots = m * (2 * n + 4)
-    tape = b"".join(pyref.seed_wide(seed, 2, sid, s) for s in range(slots))
     v = (ctypes.c_uint64 * m)(1, 2, 3, 255)
     r = b"".join(pyref.scalar_bytes(pyref.scalar_from_wide(pyref.seed_wide(seed, 5, 0, j))) for j in range(m))
+    # seed mode draws from a key bound to the statement (stream, first slot, shape, value commitments): the tape replays it
+    Vs = [pyref.pedersen_commit(v[j], int.from_bytes(r[32 * j:32 * j + 32], "little")).compress() for j in range(m)]
+    key = pyref.nonce_key(seed, sid, 0, n, m, Vs)
+    tape = b"".join(pyref.seed_wide(key, 2, sid, s) for s in range(slots))
     ps = ref.ref_range_proof_size(n, m)
     a, b = buf(ps), buf(ps)
     ref.ref_range_prove(n, m, v, r, seed, ctypes.c_uint64(sid), ctypes.c_uint64(0), None, 0, a)
