@@ -260,6 +260,8 @@ def init_dist(args):
     dist = None
     backend = os.environ.get("DAPOL_BENCH_BACKEND", "nccl")
     if world > 1:
+        # one node: RCCL's bootstrap sockets (torch's communicator and the library's own) stay on loopback, like MASTER_ADDR
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         import torch.distributed as dist
         # One rank per GPU over RCCL.  DAPOL_BENCH_BACKEND=gloo is a test hook: it lets two ranks share one GPU (RCCL refuses
         # duplicate devices), so the whole N > 1 flow can be exercised on a single-GPU box.
@@ -433,7 +435,8 @@ def mode_prove(args):
                                % (lg_total if scaling == "strong" else args.log2_entities,
                                   " in total" if scaling == "strong" and world > 1 else (" per GPU" if world > 1 else ""), height, n_bits),
                    "entities_total": n_total, "entities_per_gpu": n_per_gpu, "proof_bytes": int(stats.proof_bytes // max(1, stats.proofs)),
-                   "sharding": "none" if world == 1 else "top-level subtrees, all-gather of %d subtree roots" % world},
+                   "sharding": "none" if world == 1 else "top-level subtrees, all-gather of %d subtree roots" % world,
+                   "exchange": prover.exchange_path},
         "phases_ms": {"tree_build": acc["tree_ms"] / steps, "prove": acc["prove_ms"] / steps},
         "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
         "checksum": "%016x" % stats.checksum,

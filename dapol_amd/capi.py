@@ -73,6 +73,20 @@ _SIG = {
     "dapol_workload_destroy": (ctypes.c_int32, [_P]),
     "dapol_workload_run": (ctypes.c_int32, [_P, _P, _P, ctypes.c_int32, ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(WorkloadStats)]),
     "dapol_workload_proofs": (ctypes.c_int32, [_P, ctypes.c_size_t, ctypes.c_size_t, _P]),
+    "dapol_comm_unique_id": (ctypes.c_int32, [_P]),
+    "dapol_comm_create": (ctypes.c_int32, [_P, _P, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(_P)]),
+    "dapol_comm_destroy": (ctypes.c_int32, [_P]),
+    "dapol_shard_exchange": (ctypes.c_int32, [_P, _P, _P, ctypes.c_uint64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "dapol_shard_top_levels": (ctypes.c_int32, [_P, ctypes.c_int32, ctypes.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "dapol_comm_allreduce_u64": (ctypes.c_int32, [_P, ctypes.c_int32, _P, ctypes.c_size_t]),
+    "dapol_wire_config_get": (ctypes.c_int32, [_P]),
+    "dapol_wire_config_set": (ctypes.c_int32, [_P]),
+    "dapol_proof_nodes_serialize": (ctypes.c_int32, [ctypes.c_size_t, _P, _P, _P]),
+    "dapol_proof_nodes_deserialize": (ctypes.c_int32, [_P, ctypes.c_size_t, _P, ctypes.c_size_t, _P, _P]),
+    "dapol_proof_wire_size": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
+    "dapol_proof_serialize": (ctypes.c_int32, [ctypes.c_int32, ctypes.c_size_t, _P, ctypes.c_size_t, _P, _P, ctypes.c_int32, ctypes.c_int32,
+                                               ctypes.c_int32, _P, _P]),
+    "dapol_proof_deserialize": (ctypes.c_int32, [_P, ctypes.c_int32, ctypes.c_int32, _P, ctypes.c_size_t, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 EXPORTED_SYMBOLS = sorted(_SIG)
 
@@ -138,8 +152,71 @@ def range_proofs_deserialize(policy, n_bits, wire):
     return agg, ind, cons.value
 
 
+class WireConfig(ctypes.Structure):
+    """dapol_wire_config: the smtree assumptions (byte order, field widths, sibling order), one field each."""
+    _fields_ = [("int_big_endian", ctypes.c_int32), ("batch_num_bytes", ctypes.c_int32), ("sibling_num_bytes", ctypes.c_int32),
+                ("tree_height_bytes", ctypes.c_int32), ("path_bytes_full", ctypes.c_int32), ("siblings_leaf_first", ctypes.c_int32)]
+
+
+def wire_config_get():
+    c = WireConfig()
+    _chk(lib().dapol_wire_config_get(ctypes.byref(c)))
+    return c
+
+
+def wire_config_set(**fields):
+    """Updates the given fields of the process-wide dapol_wire_config; returns the previous config (restore with
+    wire_config_restore)."""
+    old = wire_config_get()
+    new = WireConfig.from_buffer_copy(bytes(old))
+    for k, v in fields.items():
+        setattr(new, k, int(v))
+    _chk(lib().dapol_wire_config_set(ctypes.byref(new)))
+    return old
+
+
+def wire_config_restore(cfg):
+    _chk(lib().dapol_wire_config_set(ctypes.byref(cfg)))
+
+
+def proof_serialize(height, leaf_idx, sib_C, sib_H, policy, aggregation_factor, n_bits, range_blob):
+    """DapolProof::serialize (range_proof || merkle_path) for a proof over the given leaves and siblings (host-only)."""
+    leaf_idx = _u64(leaf_idx)
+    sC, sH = _u8(sib_C).reshape(-1, 32), _u8(sib_H).reshape(-1, 32)
+    S = sC.shape[0]
+    n = lib().dapol_proof_wire_size(height, leaf_idx.shape[0], S, policy, aggregation_factor, n_bits)
+    if n == 0:
+        raise DapolError(8, "bad policy / aggregation_factor / n_bits")
+    blob = _u8(np.frombuffer(bytes(range_blob), np.uint8))
+    out = np.zeros(n, np.uint8)
+    _chk(lib().dapol_proof_serialize(height, leaf_idx.shape[0], _ptr(leaf_idx), S, _ptr(sC) if S else None, _ptr(sH) if S else None, policy,
+                                     aggregation_factor, n_bits, _ptr(blob), _ptr(out)))
+    return out.tobytes()
+
+
 class Context:
     """dapol_ctx: generators + window tables on one GPU."""
+
+    def proof_deserialize(self, policy, n_bits, wire):
+        """DapolProof::deserialize -> dict(height, leaf_idx, sib_C, sib_H, aggregation_factor, range_blob, consumed); the sibling
+        commitments are decompress-validated on the GPU (DapolError 6 / 7 = BytesNotEnough / ValueDecodingError)."""
+        w = _u8(np.frombuffer(bytes(wire), np.uint8)) if len(wire) else np.zeros(1, np.uint8)
+        h, agg = ctypes.c_int32(), ctypes.c_int32()
+        k, S, bl, cons = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+        args = (self.h, policy, n_bits, _ptr(w), len(wire), ctypes.byref(h), ctypes.byref(k), ctypes.byref(S), ctypes.byref(agg), ctypes.byref(bl))
+        _chk(lib().dapol_proof_deserialize(*args, None, None, None, None, ctypes.byref(cons)))
+        leaf = np.zeros(max(k.value, 1), np.uint64)
+        sC, sH = np.zeros((max(S.value, 1), 32), np.uint8), np.zeros((max(S.value, 1), 32), np.uint8)
+        blob = np.zeros(max(bl.value, 1), np.uint8)
+        _chk(lib().dapol_proof_deserialize(*args, _ptr(leaf), _ptr(sC), _ptr(sH), _ptr(blob), ctypes.byref(cons)))
+        return dict(height=h.value, leaf_idx=leaf[:k.value], sib_C=sC[:S.value], sib_H=sH[:S.value], aggregation_factor=agg.value,
+                    range_blob=blob[:bl.value].tobytes(), consumed=cons.value)
+
+    def proof_nodes_deserialize(self, wire, n):
+        w = _u8(np.frombuffer(bytes(wire), np.uint8)) if len(wire) else np.zeros(1, np.uint8)
+        C, H = np.zeros((max(n, 1), 32), np.uint8), np.zeros((max(n, 1), 32), np.uint8)
+        _chk(lib().dapol_proof_nodes_deserialize(self.h, n, _ptr(w), len(wire), _ptr(C), _ptr(H)))
+        return C[:n], H[:n]
 
     def __init__(self, device=0, max_parties=32, digest=DIGEST_BLAKE3):
         """digest: the node hash D of Dapol<D, R> (DIGEST_BLAKE3 or DIGEST_BLAKE2S)."""
@@ -275,6 +352,75 @@ def batch_siblings(height, leaf_idx):
     level, index = np.zeros(n.value, np.uint8), np.zeros(n.value, np.uint64)
     _chk(lib().dapol_batch_siblings(height, leaf_idx.shape[0], _ptr(leaf_idx), ctypes.byref(n), _ptr(level), _ptr(index)))
     return level, index
+
+
+COMM_ID_BYTES, RECORD_BYTES = 128, 104
+REDUCE_SUM, REDUCE_MIN, REDUCE_MAX = 0, 1, 2
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through the C ABI (rank 0 calls it; the host distributes the 128 bytes)."""
+    out = np.zeros(COMM_ID_BYTES, np.uint8)
+    _chk(lib().dapol_comm_unique_id(_ptr(out)))
+    return out.tobytes()
+
+
+def _top_out(bits):
+    return (np.zeros(32, np.uint8), np.zeros(32, np.uint8), np.zeros(1, np.uint64), np.zeros(32, np.uint8),
+            np.zeros((max(bits, 1), 32), np.uint8), np.zeros((max(bits, 1), 32), np.uint8), np.zeros(max(bits, 1), np.uint64),
+            np.zeros((max(bits, 1), 32), np.uint8))
+
+
+def _top_result(o, bits):
+    rC, rH, rv, rr, uC, uH, uv, ur = o
+    return (rC.tobytes(), rH.tobytes(), int(rv[0]), rr.tobytes()), (uC[:bits], uH[:bits], uv[:bits], ur[:bits])
+
+
+class Comm:
+    """dapol_comm: the RCCL communicator of the sharded path (one rank per GPU), created inside the library."""
+
+    def __init__(self, ctx, unique_id, rank, world):
+        self.ctx, self.rank, self.world = ctx, rank, world
+        self.bits = world.bit_length() - 1
+        uid = _u8(np.frombuffer(unique_id, np.uint8))
+        self.h = _P()
+        _chk(lib().dapol_comm_create(ctx.h, _ptr(uid), rank, world, ctypes.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().dapol_comm_destroy(self.h)
+            self.h = _P()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def exchange(self, root, with_records=False):
+        """ncclAllGather of the subtree-root records + the replicated top levels: (global root record, upper siblings)."""
+        C, H, v, r = root
+        o = _top_out(self.bits)
+        rec = np.zeros((self.world, RECORD_BYTES), np.uint8) if with_records else None
+        _chk(lib().dapol_shard_exchange(self.h, _ptr(_u8(np.frombuffer(C, np.uint8))), _ptr(_u8(np.frombuffer(H, np.uint8))), int(v),
+                                        _ptr(_u8(np.frombuffer(r, np.uint8))), *[_ptr(x) for x in o], _ptr(rec)))
+        res = _top_result(o, self.bits)
+        return res + (rec,) if with_records else res
+
+    def allreduce(self, words, op=REDUCE_SUM):
+        w = _u64(words).copy()
+        _chk(lib().dapol_comm_allreduce_u64(self.h, op, _ptr(w), w.shape[0]))
+        return w
+
+
+def shard_top_levels(ctx, records, rank):
+    """The merge half of the exchange for records gathered by other means: records [world][104]."""
+    rec = _u8(records).reshape(-1, RECORD_BYTES)
+    world = rec.shape[0]
+    bits = world.bit_length() - 1
+    o = _top_out(bits)
+    _chk(lib().dapol_shard_top_levels(ctx.h, world, rank, _ptr(rec), *[_ptr(x) for x in o]))
+    return _top_result(o, bits)
 
 
 class Tree:

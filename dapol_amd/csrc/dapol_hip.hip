@@ -59,6 +59,11 @@ struct DevBuf {
 
 static inline unsigned nblk(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
 
+// The assumptions about smtree 0.1.2 that nothing in the reference repository pins (include/dapol_hip.h, dapol_wire_config):
+// byte order and widths of the wire integers, path width, and the order of a proof's siblings.  One field each; the
+// defaults are the believed ones.  Set / read through dapol_wire_config_set / _get (host_wire.inc).
+static dapol_wire_config g_wire = {1, 8, 8, 2, 0, 0};
+
 // ------------------------------------------------------------------------------------------------ context
 struct dapol_ctx {
     // One reference for the caller's handle plus one per tree / workload built on the context: dapol_ctx_destroy only
@@ -66,6 +71,10 @@ struct dapol_ctx {
     std::atomic<int> refs{1};
     int device = 0;
     int max_parties = 0;
+    int n_cu = 256;                                      // hipDeviceProp_t::multiProcessorCount (MI355X: 256)
+    // wavefronts the MSM kernels keep resident: CUs x 4 SIMDs x DAPOL_MSM_OCC (launch bound of k_rp_msm); launches are sized
+    // in whole rounds of this many wavefronts
+    size_t resident_waves() const { return (size_t)n_cu * 4 * DAPOL_MSM_OCC; }
     hipStream_t stream = nullptr;
     hipStream_t side[3] = {nullptr, nullptr, nullptr};   // further pipelines of the range prover (several chunks in flight)
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
@@ -90,6 +99,7 @@ const char* dapol_strerror(int32_t code) {
         case DAPOL_ERR_NO_DEVICE: return "no usable HIP device (the proving path has no CPU fallback)";
         case DAPOL_ERR_HIP: return "HIP runtime error";
         case DAPOL_ERR_OUT_OF_MEMORY: return "out of device memory";
+        case DAPOL_ERR_COMM: return "RCCL error";
         default: return "unknown status";
     }
 }
@@ -109,6 +119,11 @@ int32_t dapol_ctx_create(int32_t device, int32_t max_parties, int32_t digest_id,
     dapol_ctx* c = new dapol_ctx();
     c->device = device;
     c->max_parties = max_parties;
+    {
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, device));
+        if (prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
+    }
     struct Guard { dapol_ctx* c; ~Guard() { if (c) dapol_ctx_destroy(c); } } guard{c};
     HIPCHK(hipStreamCreate(&c->stream));
     HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -117,12 +132,16 @@ int32_t dapol_ctx_create(int32_t device, int32_t max_parties, int32_t digest_id,
         HIPCHK(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
     }
     const int P = max_parties;
-    // window width: the widest (<= 17 bits: wider measured slower, profiles/r01_wbits_ab4.txt) whose tables fit the budget
-    // (DAPOL_TABLE_GB, default 40 GB), or DAPOL_WBITS (up to 20)
+    // window width: the widest (<= 17 bits: wider measured slower, profiles/r01_wbits_ab4.txt) whose tables fit the budget --
+    // DAPOL_TABLE_GB if set, else 40 GB but never more than 30 % of the memory that is free right now (a second context on
+    // the same GPU, or a smaller device, gets narrower windows instead of an allocation failure) -- or DAPOL_WBITS (up to 20)
     int wbits = WBITS_MIN;
     {
         const char* eb = getenv("DAPOL_TABLE_GB");
-        double budget = (eb ? atof(eb) : 40.0) * 1e9;
+        double budget = 40.0e9;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)free_b * 0.30 < budget) budget = (double)free_b * 0.30;
+        if (eb) budget = atof(eb) * 1e9;
         for (int w = WBITS_MIN; w <= WBITS_AUTO_MAX; w++) {
             TableView t{nullptr, P, w};
             if ((double)t.n_rows() * (double)t.row_words() * 4.0 <= budget) wbits = w;
@@ -336,7 +355,7 @@ int32_t dapol_tree_build(dapol_ctx* ctx, int32_t height, size_t n, const uint64_
     if (enforce_sparsity && height < 64 && ((double)n * 2.0 > (double)(1ull << height) ))
         return fail(DAPOL_ERR_SPARSITY_TOO_SMALL, "2^height < 2 * number of liabilities");
     if (n == 0) return fail(DAPOL_ERR_INVALID_ARGUMENT, "empty leaf set");
-    if (n > (size_t)1 << 24) return fail(DAPOL_ERR_INVALID_ARGUMENT, "at most 2^24 leaves per GPU");
+    if (n > ((size_t)1 << 31)) return fail(DAPOL_ERR_INVALID_ARGUMENT, "at most 2^31 leaves per GPU (32-bit node positions); memory is the practical bound");
     HIPCHK(hipSetDevice(ctx->device));
     dapol_tree_owned* t = new dapol_tree_owned();
     struct Guard { dapol_tree* t; ~Guard() { if (t) dapol_tree_destroy(t); } } guard{t};
@@ -359,7 +378,7 @@ int32_t dapol_tree_build_shard(dapol_ctx* ctx, int32_t total_height, int32_t sha
     *out = nullptr;
     if (total_height < 0 || total_height > 64) return fail(DAPOL_ERR_TREE_HEIGHT_TOO_BIG, "tree height must not exceed 64");
     if (shard_bits < 0 || shard_bits > total_height || shard_bits > 16) return fail(DAPOL_ERR_INVALID_ARGUMENT, "shard_bits out of range");
-    if (n > (size_t)1 << 24) return fail(DAPOL_ERR_INVALID_ARGUMENT, "at most 2^24 leaves per GPU");
+    if (n > ((size_t)1 << 31)) return fail(DAPOL_ERR_INVALID_ARGUMENT, "at most 2^31 leaves per GPU (32-bit node positions); memory is the practical bound");
     HIPCHK(hipSetDevice(ctx->device));
     dapol_tree_owned* t = new dapol_tree_owned();
     struct Guard { dapol_tree* t; ~Guard() { if (t) dapol_tree_destroy(t); } } guard{t};
@@ -420,7 +439,7 @@ int32_t dapol_tree_update(dapol_tree* tree, size_t k, const uint64_t* leaf_idx, 
         }
     }
     const size_t n = ni.size();
-    if (n > (size_t)1 << 24) return fail(DAPOL_ERR_INVALID_ARGUMENT, "at most 2^24 leaves per GPU");
+    if (n > ((size_t)1 << 31)) return fail(DAPOL_ERR_INVALID_ARGUMENT, "at most 2^31 leaves per GPU (32-bit node positions); memory is the practical bound");
     dapol_tree_owned fresh;
     HIPCHK(fresh.leaves.idx.alloc(n)); HIPCHK(fresh.leaves.v.alloc(n)); HIPCHK(fresh.leaves.r.alloc(n * 8));
     HIPCHK(hipMemcpyAsync(fresh.leaves.idx.p, ni.data(), n * 8, hipMemcpyHostToDevice, st));
@@ -647,7 +666,7 @@ static int32_t tree_paths_device(dapol_tree* tree, size_t b, const uint64_t* d_l
     HIPCHK(hipStreamSynchronize(st));
     if (h_missing) return fail(DAPOL_ERR_UNKNOWN_LEAF, "no liability at one of the requested leaves");
     for (int k = 0; k < tree->height; k++) {
-        hipLaunchKernelGGL(k_tree_path_level, dim3(nblk(b, 256)), dim3(256), 0, st, b, d_pos, tree->view(k, nullptr), k, tree->height, n_upper, out);
+        hipLaunchKernelGGL(k_tree_path_level, dim3(nblk(b, 256)), dim3(256), 0, st, b, d_pos, tree->view(k, nullptr), k, tree->height, n_upper, g_wire.siblings_leaf_first, out);
         LAUNCH_CHECK();
     }
     return DAPOL_OK;
@@ -680,3 +699,4 @@ int32_t dapol_tree_paths(dapol_tree* tree, size_t b, const uint64_t* leaf_idx, u
 #include "host_leaf.inc"
 #include "host_wire.inc"
 #include "host_batch.inc"
+#include "host_comm.inc"

@@ -2,6 +2,7 @@
 // and the seed-mode randomness PRF), Keccak-f[1600] with STROBE-128 / Merlin (Transcript::new(&[]) at
 // src/range/mod.rs:51,67,86,105), SHAKE256 (bulletproofs GeneratorsChain) and SHA3-512 (PedersenGens B_blinding).
 #pragma once
+#include "labels.h"
 #include <stdint.h>
 #include "fe.h"
 
@@ -331,8 +332,8 @@ DAPOL_HD void merlin_frame(Strobe& st, const char* label, int label_len, uint32_
     for (int i = 0; i < 4; i++) strobe_absorb_byte(st, (uint8_t)(data_len >> (8 * i)));   // meta_ad(len, more=true)
 }
 DAPOL_HD void merlin_init(Strobe& st, const char* app_label, int n) {  // Transcript::new(label)
-    strobe_init(st, "Merlin v1.0", 11);
-    merlin_frame(st, "dom-sep", 7, (uint32_t)n);
+    strobe_init(st, LBL_STROBE_PROTO);
+    merlin_frame(st, LBL_DOM_SEP, (uint32_t)n);
     strobe_begin_op(st, SF_A);
     for (int i = 0; i < n; i++) strobe_absorb_byte(st, (uint8_t)app_label[i]);
 }

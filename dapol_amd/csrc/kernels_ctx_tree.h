@@ -34,15 +34,17 @@ __device__ __forceinline__ void st_p3(int32_t* dst, const ge_p3& p) {
 // ----------------------------------------------------------------------------- context: generator chains
 // bulletproofs 4.0.0 GeneratorsChain: SHAKE256("GeneratorsChain" || label), label = 'G'|'H' || u32le(party);
 // successive 64-byte reads.  One lane per chain (2 * max_parties chains), 64 reads each.
+__device__ __forceinline__ void absorb_label(Sponge& sp, const char* s, int n) {
+    for (int i = 0; i < n; i++) sponge_absorb_byte(sp, (uint8_t)s[i]);
+}
 __global__ void k_ctx_chains(uint32_t* uniform /*[2P][64][16]*/, int P) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= 2 * P) return;
     int which = c / P, party = c % P;
     Sponge sp;
     sponge_init(sp, 136);
-    const char dom[15] = {'G', 'e', 'n', 'e', 'r', 'a', 't', 'o', 'r', 's', 'C', 'h', 'a', 'i', 'n'};
-    for (int i = 0; i < 15; i++) sponge_absorb_byte(sp, (uint8_t)dom[i]);
-    sponge_absorb_byte(sp, which ? 'H' : 'G');
+    absorb_label(sp, LBL_GENERATORS_CHAIN);
+    sponge_absorb_byte(sp, which ? LBL_GENS_H : LBL_GENS_G);
     for (int i = 0; i < 4; i++) sponge_absorb_byte(sp, (uint8_t)((uint32_t)party >> (8 * i)));
     sponge_finish(sp, 0x1F);
     uint32_t* out = uniform + (size_t)c * 64 * 16;
@@ -285,7 +287,7 @@ __global__ void k_tree_check_leaves(size_t n, const uint64_t* idx, int index_bit
     if (b) atomicOr(bad, 1u);
 }
 
-// Leaf lookup + sibling gather, one lane per (proof, level).  Output party order: root side first.
+// Leaf lookup + sibling gather, one lane per (proof, level).  Output party order: root side first (or leaf first, see k_tree_path_level).
 struct PathOut {
     uint32_t* C;     // [b][height][8] or null
     uint32_t* H;
@@ -305,12 +307,13 @@ __global__ void k_tree_find_leaves(size_t b, const uint64_t* want, size_t n, con
     else { pos[t] = 0xffffffffu; atomicOr(missing, 1u); }
 }
 // Walk one level for all proofs: writes the sibling of each proof's current node and moves to the parent.
-__global__ void k_tree_path_level(size_t b, uint32_t* pos, LevelView lv, int level, int height, int n_upper, PathOut out) {
+__global__ void k_tree_path_level(size_t b, uint32_t* pos, LevelView lv, int level, int height, int n_upper, int leaf_first, PathOut out) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= b) return;
     uint32_t p = pos[t];
     if (p == 0xffffffffu) return;
-    size_t slot = t * (size_t)(height + n_upper) + (size_t)(n_upper + height - 1 - level);
+    // sibling order of a proof (dapol_wire_config.siblings_leaf_first): root side first (slot 0 = the root's child) or leaf first
+    size_t slot = t * (size_t)(height + n_upper) + (size_t)(leaf_first ? level : n_upper + height - 1 - level);
     uint32_t c[8], h[8], r[8];
     uint64_t v = 0;
     if (lv.has_pad[p]) {
@@ -331,13 +334,13 @@ __global__ void k_tree_path_level(size_t b, uint32_t* pos, LevelView lv, int lev
     pos[t] = lv.parent[p];
 }
 // Siblings above a shard root are the same for every leaf of the shard: broadcast them into slots [0, n_upper).
-__global__ void k_tree_path_upper(size_t b, int height, int n_upper, const uint32_t* uC, const uint32_t* uH, const uint64_t* uv,
+__global__ void k_tree_path_upper(size_t b, int height, int n_upper, int leaf_first, const uint32_t* uC, const uint32_t* uH, const uint64_t* uv,
                                   const uint32_t* ur, PathOut out) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= b * (size_t)n_upper) return;
     size_t e = t / n_upper;
     int u = (int)(t - e * n_upper);
-    size_t slot = e * (size_t)(height + n_upper) + u;
+    size_t slot = e * (size_t)(height + n_upper) + (size_t)(leaf_first ? height + (n_upper - 1 - u) : u);     // u = 0: the root's child
     uint32_t w[8];
     if (out.C) { ld8(w, uC + u * 8); st8(out.C + slot * 8, w); }
     if (out.H) { ld8(w, uH + u * 8); st8(out.H + slot * 8, w); }

@@ -427,20 +427,20 @@ __global__ __launch_bounds__(64) void k_rp_finish1(RangeArgs A, TableView tbl) {
     st8(out, Ac);
     st8(out + 8, Sc);
     Strobe s;
-    merlin_init(s, "", 0);                                       // Transcript::new(&[])  (src/range/mod.rs:51,67)
-    merlin_append_bytes(s, "dom-sep", 7, "rangeproof v1", 13);
-    merlin_append_u64(s, "n", 1, (uint64_t)A.n);
-    merlin_append_u64(s, "m", 1, (uint64_t)A.m);
+    merlin_init(s, LBL_APP_TRANSCRIPT);                                       // Transcript::new(&[])  (src/range/mod.rs:51,67)
+    merlin_append_bytes(s, LBL_DOM_SEP, LBL_RANGEPROOF_DOMAIN);
+    merlin_append_u64(s, LBL_N, (uint64_t)A.n);
+    merlin_append_u64(s, LBL_M, (uint64_t)A.m);
     for (int j = 0; j < A.m; j++) {
         uint32_t v[8];
         ld8(v, A.Vc + (b * A.m + j) * 8);
-        merlin_append_words(s, "V", 1, v, 8);
+        merlin_append_words(s, LBL_V, v, 8);
     }
-    merlin_append_words(s, "A", 1, Ac, 8);
-    merlin_append_words(s, "S", 1, Sc, 8);
+    merlin_append_words(s, LBL_A, Ac, 8);
+    merlin_append_words(s, LBL_S, Sc, 8);
     sc y, z, yi;
-    challenge_scalar(y, s, "y", 1);
-    challenge_scalar(z, s, "z", 1);
+    challenge_scalar(y, s, LBL_Y);
+    challenge_scalar(z, s, LBL_Z);
     sc_invert_mont(yi, y);
     ps.y = y; ps.z = z; ps.y_inv = yi; ps.a_bl = a_bl; ps.s_bl = s_bl;
     ps.err = 0;
@@ -524,10 +524,10 @@ __global__ __launch_bounds__(64) void k_rp_finish2(RangeArgs A, TableView tbl) {
     st8(out + 24, T2c);
     Strobe s;
     st_load(s, ps);
-    merlin_append_words(s, "T_1", 3, T1c, 8);
-    merlin_append_words(s, "T_2", 3, T2c, 8);
+    merlin_append_words(s, LBL_T1, T1c, 8);
+    merlin_append_words(s, LBL_T2, T2c, 8);
     sc x;
-    challenge_scalar(x, s, "x", 1);
+    challenge_scalar(x, s, LBL_X);
     if (sc_is_zero(x)) ps.err = 1;                                // ProofError::MaliciousDealer in the crate
     ps.x = x; ps.t1_bl = t1_bl; ps.t2_bl = t2_bl;
     st_store(ps, s);
@@ -601,13 +601,13 @@ __global__ __launch_bounds__(64) void k_rp_finish3(RangeArgs A) {
     st8(out + 48, c_mu);
     Strobe s;
     st_load(s, ps);
-    append_scalar(s, "t_x", 3, c_tx);
-    append_scalar(s, "t_x_blinding", 12, c_tau);
-    append_scalar(s, "e_blinding", 10, c_mu);
+    append_scalar(s, LBL_TX, c_tx);
+    append_scalar(s, LBL_TX_BLINDING, c_tau);
+    append_scalar(s, LBL_E_BLINDING, c_mu);
     sc w;
-    challenge_scalar(w, s, "w", 1);
-    merlin_append_bytes(s, "dom-sep", 7, "ipp v1", 6);
-    merlin_append_u64(s, "n", 1, (uint64_t)A.N);
+    challenge_scalar(w, s, LBL_W);
+    merlin_append_bytes(s, LBL_DOM_SEP, LBL_IPP_DOMAIN);
+    merlin_append_u64(s, LBL_N, (uint64_t)A.N);
     ps.w = w;
     st_store(ps, s);
 }
@@ -678,10 +678,10 @@ __global__ __launch_bounds__(64) void k_rp_round_finish(RangeArgs A, TableView t
     st8(out + 8, Rc);
     Strobe s;
     st_load(s, ps);
-    merlin_append_words(s, "L", 1, Lc, 8);
-    merlin_append_words(s, "R", 1, Rc, 8);
+    merlin_append_words(s, LBL_L, Lc, 8);
+    merlin_append_words(s, LBL_R, Rc, 8);
     sc u, ui;
-    challenge_scalar(u, s, "u", 1);
+    challenge_scalar(u, s, LBL_U);
     sc_invert_mont(ui, u);
     ps.u = u; ps.u_inv = ui;
     st_store(ps, s);

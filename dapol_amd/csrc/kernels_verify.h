@@ -130,10 +130,10 @@ __global__ __launch_bounds__(64) void k_rv_absorb_V(VerifyArgs V) {
     const int l = threadIdx.x;
     // the transcript's head is the same for every proof of the call (it depends on n and m only): each lane replays it
     Strobe s;
-    merlin_init(s, "", 0);
-    merlin_append_bytes(s, "dom-sep", 7, "rangeproof v1", 13);
-    merlin_append_u64(s, "n", 1, (uint64_t)A.n);
-    merlin_append_u64(s, "m", 1, (uint64_t)A.m);
+    merlin_init(s, LBL_APP_TRANSCRIPT);
+    merlin_append_bytes(s, LBL_DOM_SEP, LBL_RANGEPROOF_DOMAIN);
+    merlin_append_u64(s, LBL_N, (uint64_t)A.n);
+    merlin_append_u64(s, LBL_M, (uint64_t)A.m);
     const uint32_t pos0 = s.pos, pb0 = s.pos_begin;
     if (l == 0)
         for (int i = 0; i < 25; i++) sh[i] = s.s[i];
@@ -206,33 +206,33 @@ __global__ __launch_bounds__(64) void k_rv_transcript(VerifyArgs V) {
         s.pos = vs.st_pos;
         s.pos_begin = vs.st_pos_begin;
     } else {
-        merlin_init(s, "", 0);
-        merlin_append_bytes(s, "dom-sep", 7, "rangeproof v1", 13);
-        merlin_append_u64(s, "n", 1, (uint64_t)A.n);
-        merlin_append_u64(s, "m", 1, (uint64_t)A.m);
+        merlin_init(s, LBL_APP_TRANSCRIPT);
+        merlin_append_bytes(s, LBL_DOM_SEP, LBL_RANGEPROOF_DOMAIN);
+        merlin_append_u64(s, LBL_N, (uint64_t)A.n);
+        merlin_append_u64(s, LBL_M, (uint64_t)A.m);
         for (int j = 0; j < A.m; j++) {
             ld8(w8, A.Vc + (b * A.m + j) * 8);
-            merlin_append_words(s, "V", 1, w8, 8);
+            merlin_append_words(s, LBL_V, w8, 8);
         }
     }
-    ld8(w8, pr);      ok &= !words_zero(w8); merlin_append_words(s, "A", 1, w8, 8);      // validate_and_append_point
-    ld8(w8, pr + 8);  ok &= !words_zero(w8); merlin_append_words(s, "S", 1, w8, 8);
-    challenge_scalar(vs.y, s, "y", 1);
-    challenge_scalar(vs.z, s, "z", 1);
-    ld8(w8, pr + 16); ok &= !words_zero(w8); merlin_append_words(s, "T_1", 3, w8, 8);
-    ld8(w8, pr + 24); ok &= !words_zero(w8); merlin_append_words(s, "T_2", 3, w8, 8);
-    challenge_scalar(vs.x, s, "x", 1);
+    ld8(w8, pr);      ok &= !words_zero(w8); merlin_append_words(s, LBL_A, w8, 8);      // validate_and_append_point
+    ld8(w8, pr + 8);  ok &= !words_zero(w8); merlin_append_words(s, LBL_S, w8, 8);
+    challenge_scalar(vs.y, s, LBL_Y);
+    challenge_scalar(vs.z, s, LBL_Z);
+    ld8(w8, pr + 16); ok &= !words_zero(w8); merlin_append_words(s, LBL_T1, w8, 8);
+    ld8(w8, pr + 24); ok &= !words_zero(w8); merlin_append_words(s, LBL_T2, w8, 8);
+    challenge_scalar(vs.x, s, LBL_X);
     uint32_t tx[8], tau[8], mu[8], aw[8], bw[8];
     ld8(tx, pr + 32); ld8(tau, pr + 40); ld8(mu, pr + 48);
     ld8(aw, pr + 56 + 16 * A.lgN); ld8(bw, pr + 64 + 16 * A.lgN);
     ok &= words_canonical_scalar(tx) & words_canonical_scalar(tau) & words_canonical_scalar(mu) & words_canonical_scalar(aw) &
           words_canonical_scalar(bw);                                                   // Scalar::from_canonical_bytes
-    append_scalar(s, "t_x", 3, tx);
-    append_scalar(s, "t_x_blinding", 12, tau);
-    append_scalar(s, "e_blinding", 10, mu);
-    challenge_scalar(vs.w, s, "w", 1);
-    merlin_append_bytes(s, "dom-sep", 7, "ipp v1", 6);
-    merlin_append_u64(s, "n", 1, (uint64_t)A.N);
+    append_scalar(s, LBL_TX, tx);
+    append_scalar(s, LBL_TX_BLINDING, tau);
+    append_scalar(s, LBL_E_BLINDING, mu);
+    challenge_scalar(vs.w, s, LBL_W);
+    merlin_append_bytes(s, LBL_DOM_SEP, LBL_IPP_DOMAIN);
+    merlin_append_u64(s, LBL_N, (uint64_t)A.N);
     // y^-1, (y-1)^-1, (z-1)^-1 and the u_k^-1 by Montgomery's trick: one inversion (~265 products) instead of lgN + 3.  The
     // running products of the u_k wait in the u_inv slots.  A zero among them (probability 2^-250) would zero every inverse,
     // so that case inverts one by one.
@@ -244,10 +244,10 @@ __global__ __launch_bounds__(64) void k_rv_transcript(VerifyArgs V) {
     sc_montmul(run, p_zm1, zm1);
     bool any_zero = sc_is_zero(vs.y) | sc_is_zero(ym1) | sc_is_zero(zm1);
     for (int k = 0; k < A.lgN; k++) {
-        ld8(w8, pr + 56 + 16 * k);     ok &= !words_zero(w8); merlin_append_words(s, "L", 1, w8, 8);
-        ld8(w8, pr + 56 + 16 * k + 8); ok &= !words_zero(w8); merlin_append_words(s, "R", 1, w8, 8);
+        ld8(w8, pr + 56 + 16 * k);     ok &= !words_zero(w8); merlin_append_words(s, LBL_L, w8, 8);
+        ld8(w8, pr + 56 + 16 * k + 8); ok &= !words_zero(w8); merlin_append_words(s, LBL_R, w8, 8);
         sc u;
-        challenge_scalar(u, s, "u", 1);
+        challenge_scalar(u, s, LBL_U);
         vs.u[k] = u;
         any_zero |= sc_is_zero(u);
         vs.u_inv[k] = run;                                       // y (y-1) (z-1) u_0 ... u_(k-1)
@@ -284,9 +284,9 @@ __global__ __launch_bounds__(64) void k_rv_transcript(VerifyArgs V) {
     // they are bound to the data they weigh: soundness-critical, see k_rv_weights.
     {
         uint32_t wide[16];
-        append_scalar(s, "a", 1, aw);
-        append_scalar(s, "b", 1, bw);
-        merlin_challenge_wide(s, "dapol-batch", 11, wide);
+        append_scalar(s, LBL_OWN_A, aw);
+        append_scalar(s, LBL_OWN_B, bw);
+        merlin_challenge_wide(s, LBL_OWN_BATCH, wide);
         for (int i = 0; i < 8; i++) vs.dg[i] = wide[i];
     }
     vs.ok = ok ? 1u : 0u;
@@ -1016,7 +1016,7 @@ __global__ void k_rvb_verdicts(VerifyArgs V) {
 // re-merge the leaf with its siblings (root side first in `pC/pH`) and compare with the root.  One lane per entity.
 __global__ __launch_bounds__(64) void k_verify_paths(int dg, size_t b, int height, const uint64_t* leaf_idx, const uint32_t* leafC, const uint32_t* leafH,
                                                     const uint32_t* pC, const uint32_t* pH, const uint32_t* rootC, const uint32_t* rootH,
-                                                    uint8_t* ok) {
+                                                    int leaf_first, uint8_t* ok) {
     size_t e = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (e >= b) return;
     uint32_t c[8], h[8], sc_[8], sh[8], hn[8];
@@ -1026,7 +1026,7 @@ __global__ __launch_bounds__(64) void k_verify_paths(int dg, size_t b, int heigh
     bool good = ge_decompress(acc, c);
     uint64_t idx = leaf_idx[e];
     for (int k = 0; k < height; k++) {
-        size_t slot = e * (size_t)height + (size_t)(height - 1 - k);
+        size_t slot = e * (size_t)height + (size_t)(leaf_first ? k : height - 1 - k);
         ld8(sc_, pC + slot * 8);
         ld8(sh, pH + slot * 8);
         good &= ge_decompress(sp, sc_);                      // deserialisation rejects non-canonical points (proof/node.rs:88-94)

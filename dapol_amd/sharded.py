@@ -1,7 +1,12 @@
 """Multi-GPU sharding of the proving path: one process per GPU, each owning one top-level
 subtree of the sparse Merkle tree.  The only exchange step is an all-gather of the G subtree-root records
-(C, H, v, r: 104 bytes each) over torch.distributed (RCCL on ROCm); every rank then merges the log2 G replicated
-top levels itself and proves its own entities.  A final all-reduce sums the per-rank proof checksums.
+(C, H, v, r: 104 bytes each); every rank then merges the log2 G replicated top levels itself and proves its own
+entities.  A final all-reduce sums the per-rank proof checksums.
+
+The exchange and the reduce are RCCL calls INSIDE libdapol_hip.so (dapol_shard_exchange / dapol_comm_allreduce_u64,
+include/dapol_hip.h): this module only carries the 128-byte RCCL id from rank 0 to the others (torch.distributed
+broadcast) and calls them.  The torch.distributed all-gather below remains for hosts without RCCL between the ranks
+(gloo: CPU tests, two ranks sharing one GPU) and as the fallback if the library's communicator cannot be created.
 
 Indices stay global everywhere, so padding-node seeds and nonce stream ids -- and therefore every byte -- equal
 the single-GPU result (tests/test_sharded.py emulates G shards on one device and checks exactly that)."""
@@ -69,12 +74,39 @@ class ShardedProver:
         self.w = capi.Workload(ctx, height, leaf_idx, v, r32, shard_bits=self.shard_bits) if len(self.idx) else None
         self.upper = None
         self.root = None
+        self.comm = None
+        self.exchange_path = "none (single GPU)"
+        if world > 1:
+            self.exchange_path = "torch.distributed all_gather (%s)" % ("RCCL" if comm_device == "cuda" else "gloo")
+            if comm_device == "cuda":
+                self._create_comm()
+
+    def _create_comm(self):
+        """RCCL communicator inside the library: rank 0 draws the id, torch.distributed carries it to the other ranks."""
+        t, ok = self.torch, 1
+        try:
+            uid = capi.comm_unique_id() if self.rank == 0 else bytes(capi.COMM_ID_BYTES)
+            buf = t.from_numpy(np.frombuffer(uid, np.uint8).copy()).to(self.comm_device)
+            self.dist.broadcast(buf, src=0)
+            self.comm = capi.Comm(self.ctx, buf.cpu().numpy().tobytes(), self.rank, self.world)
+        except Exception as e:                              # stay on the torch.distributed path, and say so
+            self.comm_error, ok = repr(e), 0
+        flag = t.tensor([ok], dtype=t.int64, device=self.comm_device)
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            self.exchange_path = "dapol_shard_exchange (ncclAllGather inside libdapol_hip.so)"
+        elif self.comm is not None:
+            self.comm.close()
+            self.comm = None
 
     def _exchange(self, root):
         if self.world == 1:
             self.root, self.upper = root, None
             return
-        buf = exchange_records(self.dist, self.torch, pack_record(root), self.world, self.comm_device)   # RCCL over xGMI
+        if self.comm is not None:
+            self.root, self.upper = self.comm.exchange(root)                                             # RCCL over xGMI, in the library
+            return
+        buf = exchange_records(self.dist, self.torch, pack_record(root), self.world, self.comm_device)
         recs = unpack_records(buf, self.world)
         self.root, self.upper = top_levels(self.ctx, recs, self.rank)
 
@@ -87,7 +119,9 @@ class ShardedProver:
             root, st = self.w.build(pad_seed)
             self._exchange(root)
             st = self.w.prove(nonce_seed, n_bits, upper=self.upper, stats=st)
-        if self.world > 1:
+        if self.world > 1 and self.comm is not None:
+            st.checksum = int(self.comm.allreduce([st.checksum], capi.REDUCE_SUM)[0])                    # ncclAllReduce, wrapping sum
+        elif self.world > 1:
             t = self.torch
             # final reduce of the aggregated proof transcript checksum (wrapping 64-bit sum, carried as two 32-bit halves)
             cs = t.tensor([st.checksum & 0xFFFFFFFF, st.checksum >> 32], dtype=t.int64, device=self.comm_device)

@@ -7,6 +7,7 @@
 #pragma once
 #include <array>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <memory>
 #include <map>
@@ -21,6 +22,19 @@
 namespace dapol {
 
 using Bytes32 = std::array<uint8_t, 32>;
+
+// utils::get_secret (src/utils.rs:19-26): 32 bytes from the OS CSPRNG.  Every seed of this API that hides something
+// (padding blindings, prover nonces, verifier weights) is either passed explicitly or drawn here -- never a zero default.
+inline Bytes32 get_secret() {
+    Bytes32 s{};
+    size_t got = 0;
+    if (FILE* f = std::fopen("/dev/urandom", "rb")) {
+        got = std::fread(s.data(), 1, s.size(), f);
+        std::fclose(f);
+    }
+    if (got != s.size()) throw std::runtime_error("dapol: no OS randomness (/dev/urandom)");
+    return s;
+}
 
 struct DapolError : std::runtime_error {      // src/errors.rs:6-17 (+ the ABI's extra codes)
     int32_t code;
@@ -127,7 +141,14 @@ struct DapolBatchProof {
     size_t aggregation_factor = 0;
     int n_bits = 64, height = 0;
     // DapolProof::verify_batch (src/proof/mod.rs:49-54)
+    // Without a seed the library draws the verifier's batching scalars' seed from the OS (the crate uses thread_rng).
+    bool verify_batch(const Context& ctx, const DapolProofNode& root, const std::vector<DapolProofNode>& leaves) const {
+        return verify_batch_impl(ctx, root, leaves, nullptr);
+    }
     bool verify_batch(const Context& ctx, const DapolProofNode& root, const std::vector<DapolProofNode>& leaves, const Bytes32& verify_seed) const {
+        return verify_batch_impl(ctx, root, leaves, verify_seed.data());
+    }
+    bool verify_batch_impl(const Context& ctx, const DapolProofNode& root, const std::vector<DapolProofNode>& leaves, const uint8_t* verify_seed) const {
         if (leaves.size() != leaf_indexes.size()) return false;
         size_t k = leaves.size(), S = merkle_siblings.size();
         std::vector<uint8_t> lC(k * 32), lH(k * 32), sC(S * 32 + 1), sH(S * 32 + 1);
@@ -135,7 +156,7 @@ struct DapolBatchProof {
         for (size_t i = 0; i < S; i++) { std::memcpy(&sC[i * 32], merkle_siblings[i].com.data(), 32); std::memcpy(&sH[i * 32], merkle_siblings[i].hash.data(), 32); }
         uint8_t ok = 0;
         check(dapol_verify_batch(ctx.get(), height, k, leaf_indexes.data(), lC.data(), lH.data(), S, sC.data(), sH.data(), root.com.data(),
-                                 root.hash.data(), (int)policy, (int)aggregation_factor, n_bits, range_proofs.data(), verify_seed.data(), &ok));
+                                 root.hash.data(), (int)policy, (int)aggregation_factor, n_bits, range_proofs.data(), verify_seed, &ok));
         return ok != 0;
     }
 };
@@ -151,7 +172,8 @@ struct DapolOptions {
     std::vector<uint8_t> audit_seed;
     int tree_height = 0;
     size_t aggregation_factor = 0;
-    Bytes32 secret{};                 // smtree Secret: here the seed of the positional padding draws
+    Bytes32 secret = get_secret();    // smtree Secret: here the seed of the positional padding draws.  Random unless the caller
+                                      // sets it: a known seed makes every padding blinding publicly derivable (node.rs:86-88)
 };
 
 // Dapol<D, R> (src/dapol/mod.rs:78-83)
@@ -220,14 +242,19 @@ class Dapol {
         tree_.reset(t, [](dapol_tree* p) { dapol_tree_destroy(p); });
     }
     // Dapol::update (mod.rs:211-213): inserts the liability at idx or replaces the one already there.  On a blank
-    // Dapol the first update creates the tree with pad_seed; later calls ignore pad_seed (a tree has one seed).
-    void update(uint64_t idx, uint64_t value, const Bytes32& blinding, const Bytes32& pad_seed = Bytes32{}) {
+    // Dapol the first update creates the tree with pad_seed; later calls ignore pad_seed (a tree has one seed).  Without a
+    // seed a blank Dapol draws one from the OS (the reference draws every padding blinding from thread_rng, node.rs:87).
+    void update(uint64_t idx, uint64_t value, const Bytes32& blinding) { update(idx, value, blinding, tree_ ? Bytes32{} : get_secret()); }
+    void update(uint64_t idx, uint64_t value, const Bytes32& blinding, const Bytes32& pad_seed) {
         if (!tree_) return build({idx}, {value}, {blinding}, pad_seed);
         check(dapol_tree_update(tree_.get(), 1, &idx, &value, blinding.data()));
     }
     // The batched form: k updates applied in order by one level-parallel rebuild.
+    void update(const std::vector<uint64_t>& idx, const std::vector<uint64_t>& values, const std::vector<Bytes32>& blindings) {
+        update(idx, values, blindings, tree_ ? Bytes32{} : get_secret());
+    }
     void update(const std::vector<uint64_t>& idx, const std::vector<uint64_t>& values, const std::vector<Bytes32>& blindings,
-                const Bytes32& pad_seed = Bytes32{}) {
+                const Bytes32& pad_seed) {
         if (idx.size() != values.size() || idx.size() != blindings.size()) throw DapolError(DAPOL_ERR_INVALID_ARGUMENT);
         if (idx.empty()) return;
         if (!tree_) {

@@ -16,7 +16,12 @@
  *  - a WIDE draw is 64 bytes reduced mod l (== Scalar::random);
  *  - seed mode: draw(domain, a, b) = first 64-byte XOF block of BLAKE3-keyed(seed, LE32 domain|LE64 a|LE64 b);
  *    padding node at (level above leaves, index): domain 1, a = level, b = index;
- *    range-proof nonce: domain 2, a = stream id (the leaf's tree index), b = slot;
+ *    range-proof nonce: domain 2, a = stream id (the leaf's tree index), b = slot, under a key bound to the STATEMENT:
+ *    k1 = draw(seed; 6, stream id, first slot of the proof)[:32], k2 = draw(k1; 7, n_bits, m)[:32], then for every group
+ *    of 31 value commitments k = BLAKE3(k | V_g .. V_g+30); the nonces are draw(k; 2, stream id, slot).  The crate draws
+ *    fresh thread_rng randomness per call; a deterministic stream that ignored the statement would reuse a_blinding,
+ *    s_L, s_R, tau against new challenges whenever a leaf is proved again after its siblings changed (dapol_tree_update,
+ *    another policy / aggregation factor) and leak them.  Same statement => same nonces => same proof bytes;
  *  - slot order of one aggregated proof with m parties of n bits (the crate's draw order): party j draws
  *    a_blinding = j(2n+2), s_blinding = j(2n+2)+1, s_L[i] = j(2n+2)+2+i, s_R[i] = j(2n+2)+2+n+i; then
  *    t1_blinding_j = m(2n+2)+2j, t2_blinding_j = m(2n+2)+2j+1.   m(2n+4) slots in total;
@@ -49,7 +54,8 @@ enum {
     DAPOL_ERR_UNKNOWN_LEAF = 9,          /* the `None` of Dapol::generate_proof* (src/dapol/mod.rs:148-190) */
     DAPOL_ERR_NO_DEVICE = 16,            /* no usable HIP device: the product path never falls back to the CPU */
     DAPOL_ERR_HIP = 17,                  /* a HIP runtime call failed; see dapol_last_error() */
-    DAPOL_ERR_OUT_OF_MEMORY = 18
+    DAPOL_ERR_OUT_OF_MEMORY = 18,
+    DAPOL_ERR_COMM = 19                  /* an RCCL call failed; see dapol_last_error() */
 };
 
 typedef struct dapol_ctx dapol_ctx;
@@ -148,8 +154,12 @@ int32_t dapol_range_prove_batch(dapol_ctx* ctx, int32_t n_bits, int32_t m, size_
 size_t dapol_range_proof_size(int32_t n_bits, int32_t m);
 
 /* verify_aggregated_range_proof / verify_single_range_proof (src/range/mod.rs:83-119 -> verify_multiple), batched:
- * proofs[b][size], V32[b][m][32] -> ok[b] (1 = verifies).  The verifier's batching scalar c (thread_rng in the
- * crate) is derived from verify_seed32 and the proof index. */
+ * proofs[b][size], V32[b][m][32] -> ok[b] (1 = verifies).
+ * verify_seed32 (here and in dapol_verify_entities / dapol_verify_batch) is SOUNDNESS-CRITICAL: it keys the verifier's
+ * random scalars -- c, which combines the two equations of one proof (thread_rng in the crate), and the weights of the
+ * cross-proof batch check.  Pass NULL (recommended): the library draws 32 bytes from the OS CSPRNG per call.  A caller
+ * seed is for reproducible tests; even then every scalar is derived from BLAKE3(seed | digest of every proof and
+ * commitment of the batch), so a weight cannot be predicted before the proofs are fixed (Fiat-Shamir). */
 int32_t dapol_range_verify_batch(dapol_ctx* ctx, int32_t n_bits, int32_t m, size_t b, const uint8_t* proofs, const uint8_t* V32,
                                  const uint8_t verify_seed32[32], uint8_t* ok);
 
@@ -181,6 +191,44 @@ int32_t dapol_range_proofs_serialize(int32_t height, int32_t policy, int32_t agg
                                      uint8_t* wire_out);
 int32_t dapol_range_proofs_deserialize(int32_t policy, int32_t n_bits, const uint8_t* wire, size_t wire_len, uint8_t* blob_out, size_t blob_cap,
                                        uint32_t* n_aggregated, uint64_t* agg_sizes, uint64_t* n_individual, size_t* consumed);
+
+/* What smtree 0.1.2 owns and nothing in the reference repository pins (the crate is not vendored, no golden bytes exist):
+ * one field per assumption, the defaults being the believed values.  Process-wide; set it before proving / serialising.
+ * A maintainer with cargo closes these with tools/replay_tape.rs -> tests/golden/from_reference/ (INTEGRATION.md). */
+typedef struct {
+    int32_t int_big_endian;       /* smtree::utils::usize_to_bytes byte order: 1 = big-endian (default), 0 = little-endian */
+    int32_t batch_num_bytes;      /* MerkleProof::serialize: width of the leaf-count field (default 8) */
+    int32_t sibling_num_bytes;    /* MerkleProof::serialize: width of the sibling-count field (default 8) */
+    int32_t tree_height_bytes;    /* TreeIndex::serialize: width of the height field (default 2) */
+    int32_t path_bytes_full;      /* 0 (default): a path takes ceil(height / 8) bytes; 1: all 32 bytes of TreeIndex.pos */
+    int32_t siblings_leaf_first;  /* order of a proof's siblings = of the range proof's parties: 0 (default) from the root side
+                                     down, 1 from the leaf level up (batched proofs: level by level in that direction) */
+} dapol_wire_config;
+int32_t dapol_wire_config_get(dapol_wire_config* out);
+int32_t dapol_wire_config_set(const dapol_wire_config* cfg);
+
+/* Serializable for DapolProofNode (src/proof/node.rs:74-102), n nodes: wire = (C32 || hash32) per node.  Deserialisation
+ * decompress-validates every commitment in one GPU launch: DAPOL_ERR_BYTES_NOT_ENOUGH / DAPOL_ERR_VALUE_DECODING ("Not the
+ * canonical encoding of a point."). */
+int32_t dapol_proof_nodes_serialize(size_t n, const uint8_t* C32, const uint8_t* H32, uint8_t* wire_out);
+int32_t dapol_proof_nodes_deserialize(dapol_ctx* ctx, size_t n, const uint8_t* wire, size_t wire_len, uint8_t* C32_out, uint8_t* H32_out);
+
+/* DapolProof::serialize / deserialize (src/proof/mod.rs:68-85): R::serialize() || MerkleProof::serialize(), the latter
+ * restated as batch_num || sibling_num || tree_height || path_1..k || (C || hash)_1..S (smtree 0.1.2, from memory: see
+ * dapol_wire_config).  k leaves (k = 1: a proof of dapol_prove_entities with n_siblings = height and the path arrays as
+ * siblings; k > 1: the outputs of dapol_prove_batch); range_blob = the range proofs in dapol_prove_entities' blob layout.
+ * dapol_proof_deserialize: first call with all four output arrays NULL -> height, k, n_siblings, aggregation_factor
+ * (= n_siblings - number of individual proofs, src/range/padding.rs:172) and range_blob_len; second call fills the
+ * arrays.  Errors as the reference: DAPOL_ERR_BYTES_NOT_ENOUGH, DAPOL_ERR_VALUE_DECODING (range-proof framing, non-canonical
+ * scalars, sibling commitments that do not decompress -- validated on the GPU). */
+size_t dapol_proof_wire_size(int32_t height, size_t k, size_t n_siblings, int32_t policy, int32_t aggregation_factor, int32_t n_bits);
+int32_t dapol_proof_serialize(int32_t height, size_t k, const uint64_t* leaf_idx, size_t n_siblings, const uint8_t* sib_C32,
+                              const uint8_t* sib_H32, int32_t policy, int32_t aggregation_factor, int32_t n_bits,
+                              const uint8_t* range_blob, uint8_t* wire_out);
+int32_t dapol_proof_deserialize(dapol_ctx* ctx, int32_t policy, int32_t n_bits, const uint8_t* wire, size_t wire_len, int32_t* height,
+                                size_t* k, size_t* n_siblings, int32_t* aggregation_factor, size_t* range_blob_len,
+                                uint64_t* leaf_idx_out, uint8_t* sib_C32_out, uint8_t* sib_H32_out, uint8_t* range_blob_out,
+                                size_t* consumed);
 
 /* DapolProof::verify (src/proof/mod.rs:41-47 + :89-95) for b single-leaf inclusion proofs as produced by
  * dapol_prove_entities: MerkleProof::verify by re-merging the leaf proof node with its siblings (DapolProofNode::merge,
@@ -214,6 +262,32 @@ int32_t dapol_verify_batch(dapol_ctx* ctx, int32_t height, size_t k, const uint6
                            const uint8_t* leaf_H32, size_t n_siblings, const uint8_t* sib_C32, const uint8_t* sib_H32,
                            const uint8_t root_C32[32], const uint8_t root_H32[32], int32_t policy, int32_t aggregation_factor,
                            int32_t n_bits, const uint8_t* range_proofs, const uint8_t verify_seed32[32], uint8_t* ok);
+
+/* Multi-GPU: one process per GPU, rank g owning the top-level subtree with index prefix g (dapol_tree_build_shard /
+ * dapol_workload_create_shard).  The reference has no communication (single process, single thread); the sharded path has
+ * exactly one exchange step and one final reduce, both RCCL calls inside this library (librccl.so, over xGMI):
+ *   dapol_comm_unique_id   rank 0 makes the 128-byte RCCL id; the host distributes it by whatever means it has
+ *   dapol_comm_create      ncclCommInitRank on the context's GPU; world must be a power of two
+ *   dapol_shard_exchange   ncclAllGather of the G subtree-root records (C | H | v LE64 | r = 104 bytes each; an empty shard
+ *                          sends the padding node of its root position, dapol_padding_nodes), then every rank merges the
+ *                          log2 G replicated top levels on its own GPU (Mergeable::merge) -> the global root record and the
+ *                          upper siblings of this rank, root side first, ready for dapol_prove_entities_upper /
+ *                          dapol_workload_prove.  records_out (may be NULL): the gathered [world][104] records.
+ *   dapol_comm_allreduce_u64  ncclAllReduce over 64-bit words: the final reduce of the per-rank proof checksums (wrapping
+ *                          sum), proof counts, or verdict masks (min = AND of 0/1 verdicts).
+ *   dapol_shard_top_levels the merge half alone, for records gathered by other means (tests, other transports). */
+typedef struct dapol_comm dapol_comm;
+enum { DAPOL_COMM_ID_BYTES = 128, DAPOL_RECORD_BYTES = 104 };
+enum { DAPOL_REDUCE_SUM = 0, DAPOL_REDUCE_MIN = 1, DAPOL_REDUCE_MAX = 2 };
+int32_t dapol_comm_unique_id(uint8_t id_out[DAPOL_COMM_ID_BYTES]);
+int32_t dapol_comm_create(dapol_ctx* ctx, const uint8_t id[DAPOL_COMM_ID_BYTES], int32_t rank, int32_t world, dapol_comm** out);
+int32_t dapol_comm_destroy(dapol_comm* comm);
+int32_t dapol_shard_exchange(dapol_comm* comm, const uint8_t sub_C[32], const uint8_t sub_H[32], uint64_t sub_v, const uint8_t sub_r[32],
+                             uint8_t root_C[32], uint8_t root_H[32], uint64_t* root_v, uint8_t root_r[32], uint8_t* up_C32, uint8_t* up_H32,
+                             uint64_t* up_v, uint8_t* up_r32, uint8_t* records_out);
+int32_t dapol_shard_top_levels(dapol_ctx* ctx, int32_t world, int32_t rank, const uint8_t* records, uint8_t root_C[32], uint8_t root_H[32],
+                               uint64_t* root_v, uint8_t root_r[32], uint8_t* up_C32, uint8_t* up_H32, uint64_t* up_v, uint8_t* up_r32);
+int32_t dapol_comm_allreduce_u64(dapol_comm* comm, int32_t op, uint64_t* inout, size_t n);
 
 /* Bench / roofline support: device-resident variant of build + prove-all used by bench.py so that the timed
  * region starts with inputs already in HBM and nothing is copied back.  Handles are opaque device buffers. */

@@ -563,9 +563,12 @@ def _ip(a, b):
     return sum(x * y for x, y in zip(a, b)) % L
 
 
-def range_prove(values, blindings, n, tape: Tape, label=b""):
+def range_prove(values, blindings, n, tape: Tape, label=b"", commit_values=None, A_offset=0, info=None):
     """RangeProof::prove_multiple_with_rng with Transcript::new(label) (src/range/mod.rs:48-78 uses label=[]).
-    Draw order per party j: a_blinding, s_blinding, s_L[0..n), s_R[0..n); then per party: t1_blinding, t2_blinding."""
+    Draw order per party j: a_blinding, s_blinding, s_L[0..n), s_R[0..n); then per party: t1_blinding, t2_blinding.
+    Adversarial hooks for the soundness tests (never used by the honest paths): commit_values = the values the V_j commit
+    to while the bits still come from `values` (an out-of-range statement with an otherwise honest proof); A_offset = kappa
+    puts A + kappa*B into the transcript and the proof; info (a dict) receives the challenges."""
     m = len(values)
     assert n in (8, 16, 32, 64) and m & (m - 1) == 0 and m > 0 and len(blindings) == m
     G, H = bp_gens(n, m)
@@ -573,7 +576,7 @@ def range_prove(values, blindings, n, tape: Tape, label=b""):
     tr.rangeproof_domain_sep(n, m)
     # Party::new + assign_position_with_rng
     parties = []
-    Vs = [pedersen_commit(v, vb).compress() for v, vb in zip(values, blindings)]
+    Vs = [pedersen_commit(v, vb).compress() for v, vb in zip(commit_values if commit_values is not None else values, blindings)]
     tape.rekey(n, m, Vs)
     for j, (v, vb) in enumerate(zip(values, blindings)):
         V = Vs[j]
@@ -594,11 +597,15 @@ def range_prove(values, blindings, n, tape: Tape, label=b""):
     for p in parties:
         A = A + p["A"]
         S = S + p["S"]
+    if A_offset:
+        A = A + (A_offset % L) * BASEPOINT
     A_c, S_c = A.compress(), S.compress()
     tr.append_point(b"A", A_c)
     tr.append_point(b"S", S_c)
     y = tr.challenge_scalar(b"y")
     z = tr.challenge_scalar(b"z")
+    if info is not None:
+        info.update(y=y, z=z, V=Vs)
     # Party::apply_challenge_with_rng
     T1 = IDENTITY
     T2 = IDENTITY
@@ -834,6 +841,35 @@ def policy_serialize(policy, aggregated, individual):
     for pr in individual:
         out += pr
     return out
+
+
+# smtree 0.1.2 MerkleProof / TreeIndex framing [3P-memory; every width a keyword so a test can move it]:
+#   batch_num || sibling_num || tree_height || path_1 .. path_k || (Com || Hash)_1 .. _S          (UNPINNED)
+WIRE_DEFAULT = dict(big_endian=True, batch_num_bytes=8, sibling_num_bytes=8, tree_height_bytes=2, path_bytes_full=False)
+
+
+def _wi(x, nbytes, cfg):
+    return x.to_bytes(nbytes, "big" if cfg["big_endian"] else "little")
+
+
+def merkle_proof_serialize(height, leaf_idxs, siblings, **kw):
+    """MerkleProof<DapolNode>::serialize: siblings = [(C32, H32)] (DapolProofNode::serialize = Com || Hash, proof/node.rs:74-79);
+    a path = the index bits MSB first, left-aligned (TreeIndex.pos), ceil(height / 8) bytes."""
+    cfg = dict(WIRE_DEFAULT, **kw)
+    out = _wi(len(leaf_idxs), cfg["batch_num_bytes"], cfg) + _wi(len(siblings), cfg["sibling_num_bytes"], cfg)
+    out += _wi(height, cfg["tree_height_bytes"], cfg)
+    pb = 32 if cfg["path_bytes_full"] else (height + 7) // 8
+    for x in leaf_idxs:
+        bits = "".join("1" if (x >> (height - 1 - b)) & 1 else "0" for b in range(height)).ljust(8 * pb, "0")
+        out += bytes(int(bits[8 * i:8 * i + 8], 2) for i in range(pb))
+    for C, Hh in siblings:
+        out += bytes(C) + bytes(Hh)
+    return out
+
+
+def dapol_proof_serialize(policy, aggregated, individual, height, leaf_idxs, siblings, **kw):
+    """DapolProof::serialize (src/proof/mod.rs:68-73): range_proof || merkle_path."""
+    return policy_serialize(policy, aggregated, individual) + merkle_proof_serialize(height, leaf_idxs, siblings, **kw)
 
 
 def policy_deserialize(policy, data, begin=0, single_size=SINGLE_PROOF_BYTE_NUM):

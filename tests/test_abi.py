@@ -100,3 +100,50 @@ def test_batch_sibling_plan_is_host_only_and_matches_oracle(hip_lib, pyref):
         with pytest.raises(hip_lib.DapolError) as e:
             hip_lib.batch_siblings(5, bad)
         assert e.value.code == 8
+
+
+def test_dapol_proof_wire_layout_host_only(hip_lib, pyref):
+    """DapolProof::serialize (src/proof/mod.rs:68-73) = R::serialize() || MerkleProof::serialize(): the C-ABI serialiser (host
+    only) against the Python restatement, for single-leaf and batched shapes, under the default dapol_wire_config and with
+    every switch moved (byte order, field widths, path width)."""
+    import numpy as np
+    rng = np.random.default_rng(3)
+    lib = hip_lib.lib()
+    for c in [x for x in load_golden_cases() if x["policy"] in ("padding", "splitting")][:6]:
+        pol = 0 if c["policy"] == "padding" else 1
+        height, n_bits, agg = c["height"], c["n_bits"], c["agg"]
+        blob = bytes.fromhex("".join(c["aggregated"]) + "".join(c["individual"]))
+        sC = rng.integers(0, 256, size=(height, 32), dtype=np.uint8)           # serialisation does not look inside the nodes
+        sH = rng.integers(0, 256, size=(height, 32), dtype=np.uint8)
+        sibs = [(sC[i].tobytes(), sH[i].tobytes()) for i in range(height)]
+        agg_p = [bytes.fromhex(a) for a in c["aggregated"]]
+        ind_p = [bytes.fromhex(a) for a in c["individual"]]
+        for kw, cfg in [({}, {}),
+                        (dict(big_endian=False), dict(int_big_endian=0)),
+                        (dict(batch_num_bytes=2, sibling_num_bytes=4, tree_height_bytes=1), dict(batch_num_bytes=2, sibling_num_bytes=4, tree_height_bytes=1)),
+                        (dict(path_bytes_full=True), dict(path_bytes_full=1))]:
+            old = hip_lib.wire_config_set(**cfg)
+            try:
+                wire = hip_lib.proof_serialize(height, [c["leaf"]], sC, sH, pol, agg, n_bits, blob)
+                assert len(wire) == lib.dapol_proof_wire_size(height, 1, height, pol, agg, n_bits)
+            finally:
+                hip_lib.wire_config_restore(old)
+            # (the range part keeps its own field widths, src/range/mod.rs:19-21; only the byte order is shared)
+            expect_range = pyref.policy_serialize(c["policy"], agg_p, ind_p)
+            if kw.get("big_endian", True):                                    # (pyref.policy_serialize is the big-endian restatement)
+                assert wire[:len(expect_range)] == expect_range
+            merkle = pyref.merkle_proof_serialize(height, [c["leaf"]], sibs, **kw)
+            assert wire[len(wire) - len(merkle):] == merkle, (kw, wire[-len(merkle):][:24].hex(), merkle[:24].hex())
+            assert len(wire) == len(expect_range) + len(merkle)
+    # shape checks without any golden case: k = 3 leaves, 5 siblings, height 10 -> 2-byte paths
+    old = hip_lib.wire_config_get()
+    assert (old.int_big_endian, old.batch_num_bytes, old.sibling_num_bytes, old.tree_height_bytes, old.path_bytes_full, old.siblings_leaf_first) == (1, 8, 8, 2, 0, 0)
+    m = pyref.merkle_proof_serialize(10, [1, 513, 1023], [(bytes([i]) * 32, bytes([i + 1]) * 32) for i in range(5)])
+    assert len(m) == 8 + 8 + 2 + 3 * 2 + 5 * 64
+    assert m[:18] == (3).to_bytes(8, "big") + (5).to_bytes(8, "big") + (10).to_bytes(2, "big")
+    assert m[18:24] == bytes([0x00, 0x40, 0x80, 0x40, 0xff, 0xc0])                  # 0000000001 | 1000000001 | 1111111111, left-aligned
+
+
+def load_golden_cases():
+    from conftest import load_golden
+    return load_golden("dapol.json")

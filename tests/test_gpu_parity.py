@@ -957,3 +957,309 @@ def test_every_proving_strategy_gives_the_same_bytes(gpu_ctx, n_bits, m):
             for k in env:
                 os.environ.pop(k, None)
         assert got == base, env
+
+
+# ------------------------------------------------------------------------------- soundness of the cross-proof batch check
+def _forged_cancelling_pair(pyref, seed):
+    """Two 8-bit, one-party proofs that are each INVALID but whose residuals cancel in a random linear combination whose
+    weights depend only on (verify seed, position in the batch) -- the round-1 derivation.  Proof 0 is honest except that
+    its commitment holds 300 (out of range; the bits prove 44): residual c_0 z_0^2 * 256 * B.  Proof 1 is honest except that
+    it carries A + kappa*B: residual kappa * B.  kappa = -rho_0 c_0 z_0^2 256 / rho_1."""
+    L = pyref.L
+    w = lambda dom, b: pyref.scalar_from_wide(pyref.seed_wide(seed, dom, b, 0)) or 1
+    rho0, rho1, c0 = w(5, 0), w(5, 1), w(3, 0)
+    i0, i1 = {}, {}
+    p0 = pyref.range_prove([44], [0x1234567], 8, pyref.Tape(seed=seed, stream_id=1), commit_values=[300], info=i0)
+    kappa = (-rho0 * c0 * i0["z"] * i0["z"] * 256 * pyref.inv(rho1)) % L
+    p1 = pyref.range_prove([7], [0x7654321], 8, pyref.Tape(seed=seed, stream_id=2), A_offset=kappa, info=i1)
+    assert not pyref.range_verify(p0, i0["V"], 8) and not pyref.range_verify(p1, i1["V"], 8)
+    proofs = np.frombuffer(p0 + p1, np.uint8).reshape(2, -1).copy()
+    V = np.frombuffer(i0["V"][0] + i1["V"][0], np.uint8).reshape(2, 1, 32).copy()
+    return proofs, V
+
+
+@pytest.mark.gpu
+def test_cancelling_pair_is_rejected(hip_lib, pyref):
+    """batch weights that ignore the proof bytes let a crafted pair of invalid proofs pass the combined check
+    (the round-1 library returns [1, 1] for this pair: profiles/r02_forged_pair_old_vs_new.txt).  The weights are now derived
+    from the digest of every proof and commitment of the batch, so the pair is rejected under the seed it was crafted for,
+    under any other seed, under the library's own OS-random seed, and inside a larger batch of honest proofs."""
+    ctx = hip_lib.Context(0, 1)
+    proofs, V = _forged_cancelling_pair(pyref, SEED)
+    for vs in (SEED, bytes(32), None):
+        assert ctx.range_verify_batch(8, 1, proofs, V, verify_seed=vs).tolist() == [0, 0]
+    rng = np.random.default_rng(11)
+    b = 70
+    v = rng.integers(0, 256, size=(b, 1), dtype=np.uint64)
+    r = rng.integers(0, 256, size=(b, 1, 32), dtype=np.uint8)
+    r[:, :, 31] &= 0x0F
+    honest = ctx.range_prove_batch(8, 1, v, r, nonce_seed=SEED, stream_id=np.arange(b, dtype=np.uint64))
+    C, _ = ctx.commit_hash_batch(v.reshape(-1), r.reshape(-1, 32))
+    allp = np.concatenate([proofs, honest])
+    allV = np.concatenate([V, C.reshape(b, 1, 32)])
+    for vs in (SEED, None):
+        ok = ctx.range_verify_batch(8, 1, allp, allV, verify_seed=vs)
+        assert ok[:2].tolist() == [0, 0] and ok[2:].all()
+
+
+@pytest.mark.gpu
+def test_nonces_are_bound_to_the_statement(gpu_ctx):
+    """the same seed and stream id with a different witness, a different party count or a different
+    first slot must not reuse a single nonce: A and S (bytes 0..64, functions of a_blinding, s_blinding, s_L, s_R only
+    through the nonce stream and the bits) and T1, T2 change; the same statement twice gives the same bytes."""
+    n, m = 16, 2
+    v = np.array([[5, 9]], np.uint64)
+    r = np.arange(64, dtype=np.uint8).reshape(1, 2, 32) & 0x7F
+    base = gpu_ctx.range_prove_batch(n, m, v, r, nonce_seed=SEED, stream_id=[77])
+    again = gpu_ctx.range_prove_batch(n, m, v, r, nonce_seed=SEED, stream_id=[77])
+    assert base.tobytes() == again.tobytes()
+    r2 = r.copy()
+    r2[0, 1, 0] ^= 1                                              # another blinding of party 1: same bits, another statement
+    other = gpu_ctx.range_prove_batch(n, m, v, r2, nonce_seed=SEED, stream_id=[77])
+    assert other[0, 32:64].tobytes() != base[0, 32:64].tobytes()         # S = s_bl*B~ + <s_L,G> + <s_R,H>: nonces only
+    shifted = gpu_ctx.range_prove_batch(n, m, v, r, nonce_seed=SEED, stream_id=[77], slot_base=1000)
+    assert shifted[0, 32:64].tobytes() != base[0, 32:64].tobytes()
+    # duplicate stream ids inside one call with different witnesses: no shared S either
+    v2 = np.array([[5, 9], [5, 10]], np.uint64)
+    rr = np.concatenate([r, r])
+    two = gpu_ctx.range_prove_batch(n, m, v2, rr, nonce_seed=SEED, stream_id=[77, 77])
+    assert two[0].tobytes() == base[0].tobytes() and two[1, 32:64].tobytes() != two[0, 32:64].tobytes()
+
+
+# --------------------------------------------------------------------------------------- f2: DapolProof wire format
+@pytest.mark.gpu
+def test_dapol_proof_serialization_round_trip(gpu_ctx, hip_lib, pyref):
+    """src/proof/tests.rs:6-35 (height 8, 20 leaves, a batch of 10, Splitting, aggregation factor 1): generate_proof_batch ->
+    serialize -> deserialize -> verify_batch; and src/tests.rs:50-93's single-leaf flavour (both policies).  The wire bytes
+    equal the Python restatement's; decoding errors mirror DecodingError (truncation -> 6, a sibling commitment that does not
+    decompress -> 7, validated on the GPU)."""
+    height, n_bits = 8, 8
+    rng = np.random.default_rng(20)
+    idx, v, r = _rand_leaves(rng, height, 20, vmax=12)          # every sibling value (a subtree sum) stays below 2^8
+    tree = hip_lib.Tree(gpu_ctx, height, idx, v, r, SEED)
+    rC, rH, _, _ = tree.root()
+    lC, lH = gpu_ctx.commit_hash_batch(v, r)
+    batch = idx[:10]
+    level, index, sC, sH, blob = tree.prove_batch(batch, hip_lib.POLICY_SPLITTING, 1, n_bits, SEED)
+    S = len(level)
+    wire = hip_lib.proof_serialize(height, batch, sC, sH, hip_lib.POLICY_SPLITTING, 1, n_bits, blob)
+    ps1 = hip_lib.lib().dapol_range_proof_size(n_bits, 1)
+    agg_p, ind_p = [blob[:ps1]], [blob[ps1 * (1 + i):ps1 * (2 + i)] for i in range(S - 1)]
+    assert wire == pyref.dapol_proof_serialize("splitting", agg_p, ind_p, height, [int(x) for x in batch],
+                                               [(sC[i].tobytes(), sH[i].tobytes()) for i in range(S)])
+    d = gpu_ctx.proof_deserialize(hip_lib.POLICY_SPLITTING, n_bits, wire + b"tail")
+    assert d["consumed"] == len(wire) and d["height"] == height and d["aggregation_factor"] == 1
+    assert d["leaf_idx"].tolist() == batch.tolist() and d["sib_C"].tobytes() == sC.tobytes() and d["sib_H"].tobytes() == sH.tobytes()
+    assert d["range_blob"] == blob
+    assert gpu_ctx.verify_batch(d["height"], d["leaf_idx"], lC[:10], lH[:10], d["sib_C"], d["sib_H"], rC, rH, hip_lib.POLICY_SPLITTING,
+                                d["aggregation_factor"], n_bits, d["range_blob"])
+    with pytest.raises(hip_lib.DapolError) as e:
+        gpu_ctx.proof_deserialize(hip_lib.POLICY_SPLITTING, n_bits, wire[:-1])
+    assert e.value.code == 6
+    bad = bytearray(wire)
+    off = len(wire) - 64 * S + 64 * 2                                     # commitment of sibling 2 := an s with no point behind it
+    bad[off:off + 32] = (2).to_bytes(32, "little")
+    assert pyref.decompress(bytes(bad[off:off + 32])) is None
+    with pytest.raises(hip_lib.DapolError) as e:
+        gpu_ctx.proof_deserialize(hip_lib.POLICY_SPLITTING, n_bits, bytes(bad))
+    assert e.value.code == 7
+    # single-leaf proofs, both policies, agg < height: serialize -> deserialize -> DapolProof::verify
+    for pol, name, agg in ((hip_lib.POLICY_PADDING, "padding", 5), (hip_lib.POLICY_SPLITTING, "splitting", 6)):
+        pC, pH, out = tree.prove_entities(idx[:4], pol, agg, n_bits, SEED)
+        for e_ in range(4):
+            w = hip_lib.proof_serialize(height, [idx[e_]], pC[e_], pH[e_], pol, agg, n_bits, out[e_].tobytes())
+            d = gpu_ctx.proof_deserialize(pol, n_bits, w)
+            assert (d["height"], d["aggregation_factor"], d["leaf_idx"].tolist()) == (height, agg, [int(idx[e_])])
+            ok = gpu_ctx.verify_entities(height, d["leaf_idx"], lC[e_:e_ + 1], lH[e_:e_ + 1], d["sib_C"][None], d["sib_H"][None], rC, rH, pol,
+                                         d["aggregation_factor"], n_bits, np.frombuffer(d["range_blob"], np.uint8)[None])
+            assert ok.tolist() == [1]
+    # DapolProofNode on its own (proof/node.rs:74-102)
+    nodes = np.concatenate([sC, sH], axis=1).tobytes()
+    C2, H2 = gpu_ctx.proof_nodes_deserialize(nodes, S)
+    assert C2.tobytes() == sC.tobytes() and H2.tobytes() == sH.tobytes()
+    with pytest.raises(hip_lib.DapolError) as e:
+        gpu_ctx.proof_nodes_deserialize(nodes[:-1], S)
+    assert e.value.code == 6
+
+
+@pytest.mark.gpu
+def test_sibling_order_switch(gpu_ctx, hip_lib, ref):
+    """dapol_wire_config.siblings_leaf_first (smtree's sibling order is not pinned by the reference repository): with the
+    switch on, paths come leaf side first, the range proof's parties follow that order (bytes = the C oracle's proof over the
+    reversed parties), single-leaf and batched proofs still verify; with the switch back, the default bytes return."""
+    height, n_bits = 6, 8
+    rng = np.random.default_rng(6)
+    idx, v, r = _rand_leaves(rng, height, 9, vmax=25)            # subtree sums stay below 2^8
+    tree = hip_lib.Tree(gpu_ctx, height, idx, v, r, SEED)
+    rC, rH, _, _ = tree.root()
+    lC, lH = gpu_ctx.commit_hash_batch(v, r)
+    C0, H0, v0, r0 = tree.paths(idx)
+    _, _, out0 = tree.prove_entities(idx, hip_lib.POLICY_PADDING, height, n_bits, SEED)
+    old = hip_lib.wire_config_set(siblings_leaf_first=1)
+    try:
+        C1, H1, v1, r1 = tree.paths(idx)
+        assert C1.tobytes() == C0[:, ::-1].tobytes() and v1.tolist() == v0[:, ::-1].tolist()
+        pC, pH, out1 = tree.prove_entities(idx, hip_lib.POLICY_PADDING, height, n_bits, SEED)
+        for e in range(len(idx)):
+            assert out1[e].tobytes() == _oracle_padding_proof(ref, n_bits, height, v1[e], r1[e], idx[e])
+        assert gpu_ctx.verify_entities(height, idx, lC, lH, pC, pH, rC, rH, hip_lib.POLICY_PADDING, height, n_bits, out1).all()
+        level, index, sC, sH, blob = tree.prove_batch(idx[:4], hip_lib.POLICY_SPLITTING, 2, n_bits, SEED)
+        assert list(level) == sorted(level)                                   # leaf level first
+        assert gpu_ctx.verify_batch(height, idx[:4], lC[:4], lH[:4], sC, sH, rC, rH, hip_lib.POLICY_SPLITTING, 2, n_bits, blob)
+    finally:
+        hip_lib.wire_config_restore(old)
+    _, _, out2 = tree.prove_entities(idx, hip_lib.POLICY_PADDING, height, n_bits, SEED)
+    assert out2.tobytes() == out0.tobytes() and out1.tobytes() != out0.tobytes()
+
+
+# ------------------------------------------------------------------------- BASELINE configs as workloads (VERDICT r1 #2)
+@pytest.mark.gpu
+def test_config2_workload_strided_layout_vs_oracle(gpu_ctx, hip_lib, ref):
+    """configs[2] shape through the bench path (Workload on the strided layout of benches/dapol.rs:160-175, height 32, 64-bit
+    proofs, padding policy, aggregation_factor = height) at 2^13 entities: root vs the C oracle's tree, 8 sampled proofs byte
+    for byte, their inclusion proofs through DapolProof::verify."""
+    import bench
+    height, n_bits, n = 32, 64, 1 << 13
+    idx, v, r = bench.synth_inputs(n, height, 0, n)
+    w = hip_lib.Workload(gpu_ctx, height, idx, v, r)
+    root, st = w.build(bench.PAD_SEED)
+    st = w.prove(bench.NONCE_SEED, n_bits, stats=st)
+    t = _ref_tree(ref, height, idx, v, r, seed=bench.PAD_SEED)
+    assert _ref_root(ref, t) == root
+    assert root[2] == int(v.sum())
+    ref.ref_tree_free(t)
+    sample = idx[:: n // 8][:8]
+    sv, sr, sC, sH = w.paths(sample, with_nodes=True)
+    ps = hip_lib.lib().dapol_range_proof_size(n_bits, 32)
+    got = np.stack([w.proofs(int(p), 1, ps)[0] for p in np.searchsorted(idx, sample)])
+    for k in range(8):
+        assert got[k].tobytes() == _oracle_padding_proof(ref, n_bits, height, sv[k], sr[k], sample[k], seed=bench.NONCE_SEED)
+    pos = np.searchsorted(idx, sample)
+    lC, lH = gpu_ctx.commit_hash_batch(v[pos], r[pos])
+    assert gpu_ctx.verify_entities(height, sample, lC, lH, sC, sH, root[0], root[1], hip_lib.POLICY_PADDING, height, n_bits, got).all()
+    assert st.proofs == n and st.proof_bytes == n * 992 and st.msm_launches > 0
+
+
+@pytest.mark.gpu
+def test_config2_full_size_properties(gpu_ctx, hip_lib):
+    """configs[2] at FULL size (2^20 entities, height 32, 64-bit proofs), one pass of the bench workload, through
+    size-independent properties: root value = sum of the liabilities, node counts of the strided layout (13.63 M
+    merges -> 14,680,063 real + 12,582,912 padding nodes), a second build gives the same root (determinism), and 2,048
+    sampled inclusion proofs verify against that root on the GPU."""
+    import bench
+    height, n_bits, n = 32, 64, 1 << 20
+    idx, v, r = bench.synth_inputs(n, height, 0, n)
+    w = hip_lib.Workload(gpu_ctx, height, idx, v, r)
+    root, st = w.build(bench.PAD_SEED)
+    assert root[2] == int(v.sum())
+    root2, _ = w.build(bench.PAD_SEED)
+    assert root2 == root
+    st = w.prove(bench.NONCE_SEED, n_bits, stats=st)
+    assert st.proofs == n and st.proof_bytes == n * 992
+    sample = idx[:: n // 2048][:2048]
+    pos = np.searchsorted(idx, sample)
+    _, _, sC, sH = w.paths(sample, with_nodes=True)
+    got = np.stack([w.proofs(int(p), 1, 992)[0] for p in pos])
+    lC, lH = gpu_ctx.commit_hash_batch(v[pos], r[pos])
+    assert gpu_ctx.verify_entities(height, sample, lC, lH, sC, sH, root[0], root[1], hip_lib.POLICY_PADDING, height, n_bits, got).all()
+    tampered = got.copy()
+    tampered[7, 40] ^= 1
+    ok = gpu_ctx.verify_entities(height, sample, lC, lH, sC, sH, root[0], root[1], hip_lib.POLICY_PADDING, height, n_bits, tampered)
+    assert ok[7] == 0 and ok.sum() == 2047
+
+
+@pytest.mark.gpu
+def test_config3_eight_shards_height32_64bit(gpu_ctx, hip_lib):
+    """configs[3] shape: 8 top-level shards, height 32, 64-bit proofs, 2^13 entities (strided layout): root, paths and proof
+    bytes of every shard equal the unsharded build's."""
+    import bench
+    from dapol_amd import sharded
+    height, n_bits, n, sb = 32, 64, 1 << 13, 3
+    idx, v, r = bench.synth_inputs(n, height, 0, n)
+    full = hip_lib.Workload(gpu_ctx, height, idx, v, r)
+    froot, fst = full.build(bench.PAD_SEED)
+    full.prove(bench.NONCE_SEED, n_bits, stats=fst)
+    fproofs = full.proofs(0, n, 992)
+    shards, recs = [], []
+    for s in range(8):
+        sel = (idx >> np.uint64(height - sb)) == s
+        w = hip_lib.Workload(gpu_ctx, height, idx[sel], v[sel], r[sel], shard_bits=sb)
+        root, st = w.build(bench.PAD_SEED)
+        shards.append((sel, w, st))
+        recs.append(sharded.pack_record(root))
+    records = sharded.unpack_records(np.stack(recs), 8)
+    csum = 0
+    for s, (sel, w, st) in enumerate(shards):
+        root, upper = sharded.top_levels(gpu_ctx, records, s)
+        assert root == froot
+        st = w.prove(bench.NONCE_SEED, n_bits, upper=upper, stats=st)
+        assert w.proofs(0, int(sel.sum()), 992).tobytes() == fproofs[sel].tobytes()
+        probe = idx[sel][[0, -1]]
+        a = w.paths(probe, upper=upper, with_nodes=True)
+        b = full.paths(probe, with_nodes=True)
+        assert all(x.tobytes() == y.tobytes() for x, y in zip(a, b))
+
+
+@pytest.mark.gpu
+def test_config4_1024_proofs_of_1024_parties_with_oracle_verdict(hip_lib, ref):
+    """configs[4] at its full shape on one GPU: 1,024 aggregated proofs x 1,024 commitments (2^20 entities), verification
+    only.  All verify; one flipped byte is found; and the C oracle's verify_multiple gives the same verdicts on the first
+    proof, honest and tampered (ref_range_verify, single thread)."""
+    ctx = hip_lib.Context(0, 1024)
+    b, m = 1024, 1024
+    rng = np.random.default_rng(4)
+    v = rng.integers(0, 2**32, size=(b, m), dtype=np.uint64)
+    r = rng.integers(0, 256, size=(b, m, 32), dtype=np.uint8)
+    r[:, :, 31] &= 0x0F
+    proofs = ctx.range_prove_batch(64, m, v, r, nonce_seed=SEED, stream_id=np.arange(b, dtype=np.uint64))
+    C, _ = ctx.commit_hash_batch(v.reshape(-1), r.reshape(-1, 32))
+    V = C.reshape(b, m, 32)
+    assert ctx.range_verify_batch(64, m, proofs, V).all()
+    bad = proofs.copy()
+    bad[0, 700] ^= 4
+    bad[513, 64] ^= 1
+    ok = ctx.range_verify_batch(64, m, bad, V)
+    assert ok[0] == 0 and ok[513] == 0 and ok.sum() == b - 2
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    c32 = bytes(range(1, 33))
+    V0 = np.ascontiguousarray(V[0])
+    assert ref.ref_range_verify(64, m, proofs[0].tobytes(), ctypes.c_size_t(proofs.shape[1]), p(V0), c32, 0) == 1
+    assert ref.ref_range_verify(64, m, bad[0].tobytes(), ctypes.c_size_t(proofs.shape[1]), p(V0), c32, 0) == 0
+
+
+# ----------------------------------------------------------------------------------- RCCL exchange inside the library
+@pytest.mark.gpu
+def test_rccl_exchange_one_rank_and_top_levels(gpu_ctx, hip_lib):
+    """dapol_comm_* / dapol_shard_exchange with the one rank a 1-GPU box has: ncclCommInitRank, ncclAllGather and
+    ncclAllReduce really run (librccl.so); with G = 1 the global root is the subtree root and there are no upper siblings.
+    The merge half (dapol_shard_top_levels) is checked for 8 shards against the Python-side merge of the same records and
+    against the unsharded tree."""
+    from dapol_amd import sharded
+    height, sb = 9, 3
+    rng = np.random.default_rng(8)
+    idx, v, r = _rand_leaves(rng, height, 40, vmax=1000)
+    full = hip_lib.Tree(gpu_ctx, height, idx, v, r, SEED)
+    comm = hip_lib.Comm(gpu_ctx, hip_lib.comm_unique_id(), 0, 1)
+    root, upper, rec = comm.exchange(full.root(), with_records=True)
+    assert root == full.root() and len(upper[2]) == 0
+    assert rec.tobytes() == sharded.pack_record(full.root()).tobytes()
+    assert comm.allreduce([5, 2**64 - 1]).tolist() == [5, 2**64 - 1]
+    assert comm.allreduce([7], hip_lib.REDUCE_MIN).tolist() == [7]
+    comm.close()
+    recs = []
+    for s in range(8):
+        sel = (idx >> np.uint64(height - sb)) == s
+        if sel.any():
+            recs.append(sharded.pack_record(hip_lib.Tree(gpu_ctx, height, idx[sel], v[sel], r[sel], SEED, shard_bits=sb).root()))
+        else:
+            C, H, rr = gpu_ctx.padding_nodes(SEED, [height - sb], [s])
+            recs.append(sharded.pack_record((C[0].tobytes(), H[0].tobytes(), 0, rr[0].tobytes())))
+    records = np.stack(recs)
+    for s in range(8):
+        root, upper = hip_lib.shard_top_levels(gpu_ctx, records, s)
+        proot, pupper = sharded.top_levels(gpu_ctx, sharded.unpack_records(records, 8), s)
+        assert root == proot == full.root()
+        assert all(np.asarray(a).tobytes() == np.asarray(b).tobytes() for a, b in zip(upper, pupper))
+    with pytest.raises(hip_lib.DapolError) as e:
+        hip_lib.Comm(gpu_ctx, bytes(128), 0, 3)
+    assert e.value.code == 8
