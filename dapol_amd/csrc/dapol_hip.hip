@@ -58,6 +58,7 @@ struct DevBuf {
 };
 
 static inline unsigned nblk(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // The assumptions about smtree 0.1.2 that nothing in the reference repository pins (include/dapol_hip.h, dapol_wire_config):
 // byte order and widths of the wire integers, path width, and the order of a proof's siblings.  One field each; the
@@ -72,9 +73,10 @@ struct dapol_ctx {
     int device = 0;
     int max_parties = 0;
     int n_cu = 256;                                      // hipDeviceProp_t::multiProcessorCount (MI355X: 256)
-    // wavefronts the MSM kernels keep resident: CUs x 4 SIMDs x DAPOL_MSM_OCC (launch bound of k_rp_msm); launches are sized
-    // in whole rounds of this many wavefronts
-    size_t resident_waves() const { return (size_t)n_cu * 4 * DAPOL_MSM_OCC; }
+    int msm_waves_per_cu = 4 * DAPOL_MSM_OCC;            // resident wavefronts of k_rp_msm per CU (occupancy API, dapol_ctx_create)
+    unsigned msm_dyn_lds = 0;                            // dynamic LDS bytes of the MSM launches: caps the residency (DAPOL_MSM_OCC_CAP)
+    // wavefronts the dominant kernel keeps resident on the chip: launches are sized in whole rounds of this many
+    size_t resident_waves() const { return (size_t)n_cu * (size_t)msm_waves_per_cu; }
     hipStream_t stream = nullptr;
     hipStream_t side[3] = {nullptr, nullptr, nullptr};   // further pipelines of the range prover (several chunks in flight)
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
@@ -123,6 +125,21 @@ int32_t dapol_ctx_create(int32_t device, int32_t max_parties, int32_t digest_id,
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, device));
         if (prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
+        // Residency of the dominant kernel (one wavefront per block): what its registers and LDS allow -- asked of the runtime,
+        // not assumed.  DAPOL_MSM_OCC_CAP=<waves per SIMD> lowers it by padding the launch's LDS (A/B knob: at the socket power
+        // cap more resident wavefronts are not automatically faster, profiles/r01_madchain_ab.txt).
+        if (const char* e = getenv("DAPOL_MSM_OCC_CAP")) {
+            int cap = atoi(e);
+            const size_t lds_cu = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 163840, stat = sizeof(int32_t) * 4 * FE_NL * 64;
+            if (cap >= 1 && cap <= 8) {
+                size_t per_block = lds_cu / (size_t)(4 * cap) / 512 * 512;          // LDS is granted in 512-byte granules
+                if (per_block > stat) c->msm_dyn_lds = (unsigned)(per_block - stat);
+            }
+        }
+        int blocks = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_rp_msm<MSM_PLAIN, 4>, 64, c->msm_dyn_lds) == hipSuccess && blocks > 0)
+            c->msm_waves_per_cu = blocks;
+        else (void)hipGetLastError();
     }
     struct Guard { dapol_ctx* c; ~Guard() { if (c) dapol_ctx_destroy(c); } } guard{c};
     HIPCHK(hipStreamCreate(&c->stream));
@@ -228,34 +245,20 @@ int32_t dapol_commit_hash_batch(dapol_ctx* ctx, size_t n, const uint64_t* v, con
 }
 
 // --------------------------------------------------------------------------------------------------- tree
+template <typename T>
+struct Span { T* p = nullptr; };             // a view into the tree's arena (same `.p` spelling as DevBuf)
 struct LevelBuf {
-    size_t n = 0;
-    DevBuf<uint64_t> idx, v;
-    DevBuf<uint32_t> C, H, r, padC, padH, padr, parent;
-    DevBuf<uint8_t> has_pad;
-    hipError_t alloc(size_t count, bool own_leaf_arrays) {
-        n = count;
-        hipError_t e;
-        if (own_leaf_arrays) {
-            if ((e = idx.alloc(count)) != hipSuccess) return e;
-            if ((e = v.alloc(count)) != hipSuccess) return e;
-            if ((e = r.alloc(count * 8)) != hipSuccess) return e;
-        }
-        if ((e = C.alloc(count * 8)) != hipSuccess) return e;
-        if ((e = H.alloc(count * 8)) != hipSuccess) return e;
-        if ((e = padC.alloc(count * 8)) != hipSuccess) return e;
-        if ((e = padH.alloc(count * 8)) != hipSuccess) return e;
-        if ((e = padr.alloc(count * 8)) != hipSuccess) return e;
-        if ((e = parent.alloc(count)) != hipSuccess) return e;
-        if ((e = has_pad.alloc(count)) != hipSuccess) return e;
-        return hipMemset(has_pad.p, 0, count);
-    }
+    size_t n = 0;                            // real nodes of the level (the host-side bound while the build is in flight)
+    Span<uint64_t> idx, v;
+    Span<uint32_t> C, H, r, padC, padH, padr, parent;
+    Span<uint8_t> has_pad;
 };
 
 struct dapol_tree {
     dapol_ctx* ctx = nullptr;
     int height = 0;
     std::vector<LevelBuf> levels;      // 0 = leaves .. height = root
+    DevBuf<uint8_t> arena;             // every level's arrays: ONE allocation per build
     // level 0 may borrow caller-resident device arrays (workload path)
     uint64_t* leaf_idx = nullptr;
     uint64_t* leaf_v = nullptr;
@@ -291,50 +294,85 @@ static int32_t tree_build_device(dapol_ctx* ctx, int index_bits, int shard_bits,
     t->levels.resize((size_t)height + 1);
     t->n_pad = 0;
     t->n_real = 0;
-    DevBuf<uint32_t> bad, seed, flag, pos, head, bsums, total;
-    HIPCHK(bad.alloc(1)); HIPCHK(seed.alloc(8)); HIPCHK(total.alloc(1));
+    DevBuf<uint32_t> bad, seed, flag, pos, head, bsums, cnt;
+    HIPCHK(bad.alloc(1)); HIPCHK(seed.alloc(8)); HIPCHK(cnt.alloc((size_t)height + 2));
     HIPCHK(hipMemsetAsync(bad.p, 0, 4, st));
     HIPCHK(hipMemcpyAsync(seed.p, pad_seed32, 32, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_tree_check_leaves, dim3(nblk(n, 256)), dim3(256), 0, st, n, d_idx, index_bits, height, bad.p);
     LAUNCH_CHECK();
     uint32_t h_bad = 0;
     HIPCHK(hipMemcpyAsync(&h_bad, bad.p, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipStreamSynchronize(st));          // the one early wait: malformed input must not reach the level kernels
     if (h_bad) return fail(DAPOL_ERR_INVALID_ARGUMENT, "leaf indexes must be strictly increasing, below 2^height, and (shard build) share their top shard_bits bits");
+    // Upper bound of every level's size, known on the host: a level has at most as many nodes as the one below and at most
+    // 2^(levels above it) positions.  The actual sizes are computed on the device (cnt) and read back once, at the end.
+    std::vector<size_t> bound((size_t)height + 1);
+    bound[0] = n;
+    for (int k = 0; k < height; k++) {
+        const int bits_above = height - (k + 1);
+        bound[k + 1] = bound[k];
+        if (bits_above < 40 && ((size_t)1 << bits_above) < bound[k + 1]) bound[k + 1] = (size_t)1 << bits_above;
+    }
+    {   // one arena for all levels
+        size_t need = 0, pad_total = 0;
+        auto take = [&](size_t bytes) { size_t o = need; need += align_up(bytes, 256); return o; };
+        std::vector<size_t> off((size_t)(height + 1) * 10);
+        for (int k = 0; k <= height; k++) {
+            const size_t c = bound[k];
+            size_t* o = &off[(size_t)k * 10];
+            o[0] = k ? take(c * 8) : 0; o[1] = k ? take(c * 8) : 0; o[2] = k ? take(c * 32) : 0;      // idx, v, r (level 0 borrows the caller's)
+            o[3] = take(c * 32); o[4] = take(c * 32); o[5] = take(c * 32); o[6] = take(c * 32); o[7] = take(c * 32); o[8] = take(c * 4);
+            pad_total += align_up(c, 256);
+        }
+        const size_t pad_at = need;
+        need += pad_total;
+        HIPCHK(t->arena.alloc(need));
+        HIPCHK(hipMemsetAsync(t->arena.p + pad_at, 0, pad_total, st));
+        size_t pad_off = pad_at;
+        for (int k = 0; k <= height; k++) {
+            LevelBuf& L = t->levels[k];
+            const size_t* o = &off[(size_t)k * 10];
+            uint8_t* a = t->arena.p;
+            L.n = bound[k];
+            if (k) { L.idx.p = (uint64_t*)(a + o[0]); L.v.p = (uint64_t*)(a + o[1]); L.r.p = (uint32_t*)(a + o[2]); }
+            L.C.p = (uint32_t*)(a + o[3]); L.H.p = (uint32_t*)(a + o[4]); L.padC.p = (uint32_t*)(a + o[5]); L.padH.p = (uint32_t*)(a + o[6]);
+            L.padr.p = (uint32_t*)(a + o[7]); L.parent.p = (uint32_t*)(a + o[8]);
+            L.has_pad.p = a + pad_off;
+            pad_off += align_up(bound[k], 256);
+        }
+    }
     HIPCHK(flag.alloc(n)); HIPCHK(pos.alloc(n)); HIPCHK(head.alloc(n)); HIPCHK(bsums.alloc(nblk(n, 1024) + 1));
     DevBuf<int32_t> ext_a, ext_b;
     HIPCHK(ext_a.alloc(n * 40)); HIPCHK(ext_b.alloc(n * 40));
-    HIPCHK(t->levels[0].alloc(n, false));
+    const uint32_t n32 = (uint32_t)n;
+    HIPCHK(hipMemcpyAsync(cnt.p, &n32, 4, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_commit_hash, dim3(nblk(n, 256)), dim3(256), 0, st, ctx->tv, n, d_v, d_r, t->levels[0].C.p, t->levels[0].H.p, ext_a.p);
     LAUNCH_CHECK();
     int32_t* ext_cur = ext_a.p;
     int32_t* ext_nxt = ext_b.p;
-    size_t cur_n = n;
-    for (int k = 0; k < height; k++) {
+    for (int k = 0; k < height; k++) {                    // launches only: nothing here waits for the device
         LevelView cur = t->view(k, ext_cur);
-        hipLaunchKernelGGL(k_tree_flags, dim3(nblk(cur_n, 256)), dim3(256), 0, st, cur_n, cur.idx, flag.p);
+        hipLaunchKernelGGL(k_tree_flags, dim3(nblk(bound[k], 256)), dim3(256), 0, st, cnt.p + k, cur.idx, flag.p);
         LAUNCH_CHECK();
-        size_t nb = nblk(cur_n, 1024);
-        hipLaunchKernelGGL(k_scan_block, dim3((unsigned)nb), dim3(256), 0, st, cur_n, flag.p, pos.p, bsums.p);
+        hipLaunchKernelGGL(k_scan_block, dim3(nblk(bound[k], 1024)), dim3(256), 0, st, cnt.p + k, flag.p, pos.p, bsums.p);
         LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(64), 0, st, nb, bsums.p, total.p);
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, st, cnt.p + k, bsums.p, cnt.p + k + 1);
         LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_scan_finish, dim3(nblk(cur_n, 256)), dim3(256), 0, st, cur_n, flag.p, pos.p, bsums.p, head.p);
+        hipLaunchKernelGGL(k_scan_finish, dim3(nblk(bound[k], 256)), dim3(256), 0, st, cnt.p + k, flag.p, pos.p, bsums.p, head.p);
         LAUNCH_CHECK();
-        uint32_t next_n = 0;
-        HIPCHK(hipMemcpyAsync(&next_n, total.p, 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        HIPCHK(t->levels[k + 1].alloc(next_n, true));
         LevelView nxt = t->view(k + 1, k + 1 < height ? ext_nxt : nullptr);
-        hipLaunchKernelGGL(k_tree_merge, dim3(nblk(next_n, 256)), dim3(256), 0, st, ctx->tv, cur, nxt, head.p, k, seed.p);
+        hipLaunchKernelGGL(k_tree_merge, dim3(nblk(bound[k + 1], 256)), dim3(256), 0, st, ctx->tv, cur, nxt, head.p, k, seed.p, cnt.p);
         LAUNCH_CHECK();
-        t->n_real += cur_n;
-        t->n_pad += 2 * (uint64_t)next_n - cur_n;
-        cur_n = next_n;
         std::swap(ext_cur, ext_nxt);
     }
-    t->n_real += cur_n;
+    std::vector<uint32_t> h_cnt((size_t)height + 1);
+    HIPCHK(hipMemcpyAsync(h_cnt.data(), cnt.p, ((size_t)height + 1) * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    for (int k = 0; k <= height; k++) {
+        t->levels[k].n = h_cnt[k];
+        t->n_real += h_cnt[k];
+        if (k < height) t->n_pad += 2 * (uint64_t)h_cnt[k + 1] - h_cnt[k];
+    }
     return DAPOL_OK;
 }
 

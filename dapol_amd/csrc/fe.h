@@ -1,19 +1,21 @@
-// GF(2^255-19) arithmetic for gfx950: ten signed limbs, radix 2^25.5 (limb i holds ceil(25.5 i) .. bits).
+// GF(2^255-19) arithmetic for gfx950: nine signed limbs, radix 2^29 (limb i has weight 2^(29 i); 9 x 29 = 261 bits, so
+// a reduced value keeps 23 bits in limb 8 and 2^261 = 2^6 * 2^255 wraps to 1216).
 //
-// Why this form (measured, tools/ubench_valu.hip on MI355X): v_mad_{u,i}64_{u,i}32 issues at ~4.2-5 cycles
-// per wave, the same as v_fma_f64 and every other VOP3 op, while carry-producing adds (v_add_co/v_addc) cost
-// as much as a multiply.  So the cheapest 255-bit multiply is the one with the fewest *instructions*: an
-// unsaturated radix whose column sums fit the MAD's 64-bit addend (no carry instructions inside a column),
-// with the 2^255 = 19 wrap folded into pre-multiplied operands that still fit 32 bits.  That is the classic
-// 10 x 25.5-bit signed representation: 100 MADs + ~35 shift/mask/pre-multiply instructions per product.
+// Why this form (measured, tools/ubench_valu.hip on MI355X): v_mad_{u,i}64_{u,i}32 issues at ~4.2-5 cycles per wave, every
+// other VOP3 op at ~3.6-4.3, plain VOP2 logic at ~2: a 255-bit product costs what its MULTIPLY-ADDs cost, so the cheapest
+// representation is the one with the fewest of them whose column sums still ride the MAD's 64-bit addend.  Round 1 used
+// the classic 10 x 25.5-bit limbs: 100 MADs + 9 multiplies by 19 + 10 carries.  Nine 29-bit limbs need 81 MADs; the high
+// columns 9..16 cannot be pre-multiplied by the wrap factor (1216 * 2^29 does not fit 32 bits), so they are carried into
+// limbs first and re-enter through 9 more MADs by 1216: 90 MADs + 17 carries, ~8 % fewer issue cycles per product
+// (profiles/r02_fe29_ab.txt), and a point is 36 registers instead of 40.  fe_sq: 45 + 9 MADs.
 //
-// Bounds (floor carries, so "reduced" limbs are non-negative: even limbs in [0,2^26), odd limbs in [0,2^25+2^16)):
-//   TIGHT  = |even limb| <= 1.68*2^26 and |odd limb| <= 1.68*2^25  (a reduced value, its negation, or the
-//            DIFFERENCE of two reduced values);   LOOSE = up to 8x a reduced value (sums of a few terms).
-//   fe_mul(h, f, g): f may be LOOSE, g must be TIGHT (19*g_i must fit int32; column sums < 2^63 need A*B < 16).
-//   fe_sq(h, f):     f must be TIGHT (38*f_odd, 19*f_even must fit int32).
-//   Outputs of fe_mul / fe_sq / fe_carry are reduced.  A SUM of two reduced values is loose: carry it before
-//   it is squared or used as g.
+// Bounds (floor carries, so "reduced" limbs are non-negative: limbs 0..7 in [0, 2^29 + 2^17), limb 8 in [0, 2^23]):
+//   TIGHT  = |limb| <= 2^29 + 2^17  (a reduced value, its negation, or the DIFFERENCE of two reduced values);
+//   LOOSE  = up to 3x a reduced value in magnitude (2Z - C, B + A, ...).
+//   fe_mul(h, f, g): f may be LOOSE, g must be TIGHT: a column is at most 9 products of 3*2^29 * 2^29 = 27 * 2^58 < 2^63.
+//   fe_sq(h, f):     f must be TIGHT (the doubled limbs 2 f_i must fit int32; columns <= 9 * 2^59).
+//   Outputs of fe_mul / fe_sq / fe_carry are reduced.  A SUM of two reduced values is loose: carry it before it is squared
+//   or used as g.
 #pragma once
 #include <stdint.h>
 
@@ -27,133 +29,99 @@
 
 namespace dapol {
 
+enum { FE_NL = 9, FE_M29 = 0x1fffffff, FE_M23 = 0x7fffff };
+
 struct fe {
-    int32_t v[10];
+    int32_t v[FE_NL];
 };
 
 DAPOL_HD void fe_0(fe& h) {
-    for (int i = 0; i < 10; i++) h.v[i] = 0;
+    for (int i = 0; i < FE_NL; i++) h.v[i] = 0;
 }
 DAPOL_HD void fe_1(fe& h) {
     fe_0(h);
     h.v[0] = 1;
 }
 DAPOL_HD void fe_add(fe& h, const fe& f, const fe& g) {
-    for (int i = 0; i < 10; i++) h.v[i] = f.v[i] + g.v[i];
+    for (int i = 0; i < FE_NL; i++) h.v[i] = f.v[i] + g.v[i];
 }
 DAPOL_HD void fe_sub(fe& h, const fe& f, const fe& g) {
-    for (int i = 0; i < 10; i++) h.v[i] = f.v[i] - g.v[i];
+    for (int i = 0; i < FE_NL; i++) h.v[i] = f.v[i] - g.v[i];
 }
 DAPOL_HD void fe_neg(fe& h, const fe& f) {
-    for (int i = 0; i < 10; i++) h.v[i] = -f.v[i];
+    for (int i = 0; i < FE_NL; i++) h.v[i] = -f.v[i];
 }
 // h = c ? g : h  (branch-free select)
 DAPOL_HD void fe_cmov(fe& h, const fe& g, bool c) {
-    for (int i = 0; i < 10; i++) h.v[i] = c ? g.v[i] : h.v[i];
+    for (int i = 0; i < FE_NL; i++) h.v[i] = c ? g.v[i] : h.v[i];
 }
 DAPOL_HD void fe_cswap(fe& f, fe& g, bool c) {
-    for (int i = 0; i < 10; i++) {
+    for (int i = 0; i < FE_NL; i++) {
         int32_t a = f.v[i], b = g.v[i];
         f.v[i] = c ? b : a;
         g.v[i] = c ? a : b;
     }
 }
 
-// Sequential floor carry of ten 64-bit column sums into limbs; the 2^255 wrap re-enters limb 0 times 19.
-DAPOL_HD void fe_reduce_cols(fe& h, int64_t c0, int64_t c1, int64_t c2, int64_t c3, int64_t c4, int64_t c5, int64_t c6,
-                             int64_t c7, int64_t c8, int64_t c9) {
-    c1 += c0 >> 26; int32_t h0 = (int32_t)c0 & 0x3ffffff;
-    c2 += c1 >> 25; int32_t h1 = (int32_t)c1 & 0x1ffffff;
-    c3 += c2 >> 26; int32_t h2 = (int32_t)c2 & 0x3ffffff;
-    c4 += c3 >> 25; int32_t h3 = (int32_t)c3 & 0x1ffffff;
-    c5 += c4 >> 26; int32_t h4 = (int32_t)c4 & 0x3ffffff;
-    c6 += c5 >> 25; int32_t h5 = (int32_t)c5 & 0x1ffffff;
-    c7 += c6 >> 26; int32_t h6 = (int32_t)c6 & 0x3ffffff;
-    c8 += c7 >> 25; int32_t h7 = (int32_t)c7 & 0x1ffffff;
-    c9 += c8 >> 26; int32_t h8 = (int32_t)c8 & 0x3ffffff;
-    int64_t t = (c9 >> 25) * 19 + h0; int32_t h9 = (int32_t)c9 & 0x1ffffff;
-    h.v[0] = (int32_t)t & 0x3ffffff;
-    h.v[1] = h1 + (int32_t)(t >> 26);
-    h.v[2] = h2; h.v[3] = h3; h.v[4] = h4; h.v[5] = h5; h.v[6] = h6; h.v[7] = h7; h.v[8] = h8; h.v[9] = h9;
+// Limbs from the nine low columns whose carries are already chained (c_k includes c_(k-1) >> 29): limbs 0..7 are the low 29
+// bits; column 8 keeps 23 bits and everything above bit 255 re-enters limb 0 times 19.
+DAPOL_HD void fe_limbs_from_cols(fe& h, int64_t c0, int64_t c1, int64_t c2, int64_t c3, int64_t c4, int64_t c5, int64_t c6, int64_t c7,
+                                 int64_t c8) {
+    const int64_t t = (c8 >> 23) * 19 + (int64_t)((int32_t)c0 & FE_M29);
+    h.v[0] = (int32_t)t & FE_M29;
+    h.v[1] = ((int32_t)c1 & FE_M29) + (int32_t)(t >> 29);
+    h.v[2] = (int32_t)c2 & FE_M29; h.v[3] = (int32_t)c3 & FE_M29; h.v[4] = (int32_t)c4 & FE_M29; h.v[5] = (int32_t)c5 & FE_M29;
+    h.v[6] = (int32_t)c6 & FE_M29; h.v[7] = (int32_t)c7 & FE_M29;
+    h.v[8] = (int32_t)c8 & FE_M23;
 }
 
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(DAPOL_NO_MAD_CHAIN)
-// Device form of the column sums.  Every column is ONE chain of v_mad_i64_i32 whose first addend is the carry out of
-// the column below, so the 64-bit carry additions of fe_reduce_cols disappear into MADs that are issued anyway
-// (per product: 100 MAD + 10 shift + 10 mask, without the 9 v_lshl_add_u64; same values, same limbs).  Written as
-// inline assembly, one statement per column, because LLVM re-associates a C sum so that the carry is added last, as
-// a separate instruction; one statement per column (not per MAD) keeps the hazard recogniser from padding the
-// dependent MADs with s_nop.
+// Device form of the column sums.  Every column is ONE chain of v_mad_i64_i32 whose first addend is the carry out of the
+// column below, so no 64-bit carry addition is ever issued on its own.  Inline assembly, one statement per column, because
+// LLVM re-associates a C sum so that the carry is added last, as a separate instruction; one statement per column (not per
+// MAD) keeps the hazard recogniser from padding the dependent MADs with s_nop.  madNc: N products added to a carry;
+// madNz: N products from zero.  (Generated once; the second destination is VOP3b's unused scalar carry-out.)
 #define DAPOL_MAD_CHAIN 1
-__device__ __forceinline__ int64_t mad_col10z(int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2,
-        int32_t a3, int32_t b3, int32_t a4, int32_t b4, int32_t a5, int32_t b5, int32_t a6, int32_t b6, int32_t a7,
-        int32_t b7, int32_t a8, int32_t b8, int32_t a9, int32_t b9) {
-    int64_t d;
-    uint64_t sdst;               // VOP3b scalar destination (carry out), unused
-    asm("v_mad_i64_i32 %0, %1, %2, %3, 0\n\t"
-        "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %10, %11, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %12, %13, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %14, %15, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %16, %17, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %18, %19, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %20, %21, %0"
-        : "=&v"(d), "=s"(sdst)
-        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5),
-          "v"(a6), "v"(b6), "v"(a7), "v"(b7), "v"(a8), "v"(b8), "v"(a9), "v"(b9));
+__device__ __forceinline__ int64_t mad1c(int64_t d, int32_t a0, int32_t b0) {
+    uint64_t sdst;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
+        : "+v"(d), "=s"(sdst)
+        : "v"(a0), "v"(b0));
     return d;
 }
-__device__ __forceinline__ int64_t mad_col10c(int64_t d, int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2,
-        int32_t b2, int32_t a3, int32_t b3, int32_t a4, int32_t b4, int32_t a5, int32_t b5, int32_t a6, int32_t b6,
-        int32_t a7, int32_t b7, int32_t a8, int32_t b8, int32_t a9, int32_t b9) {
-    uint64_t sdst;               // VOP3b scalar destination (carry out), unused
+
+__device__ __forceinline__ int64_t mad2c(int64_t d, int32_t a0, int32_t b0, int32_t a1, int32_t b1) {
+    uint64_t sdst;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %4, %5, %0"
+        : "+v"(d), "=s"(sdst)
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1));
+    return d;
+}
+
+__device__ __forceinline__ int64_t mad3c(int64_t d, int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2) {
+    uint64_t sdst;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %6, %7, %0"
+        : "+v"(d), "=s"(sdst)
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2));
+    return d;
+}
+
+__device__ __forceinline__ int64_t mad4c(int64_t d, int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2, int32_t a3, int32_t b3) {
+    uint64_t sdst;
     asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t"
         "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
         "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %10, %11, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %12, %13, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %14, %15, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %16, %17, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %18, %19, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %20, %21, %0"
+        "v_mad_i64_i32 %0, %1, %8, %9, %0"
         : "+v"(d), "=s"(sdst)
-        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5),
-          "v"(a6), "v"(b6), "v"(a7), "v"(b7), "v"(a8), "v"(b8), "v"(a9), "v"(b9));
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3));
     return d;
 }
-__device__ __forceinline__ int64_t mad_col6z(int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2,
-        int32_t a3, int32_t b3, int32_t a4, int32_t b4, int32_t a5, int32_t b5) {
-    int64_t d;
-    uint64_t sdst;               // VOP3b scalar destination (carry out), unused
-    asm("v_mad_i64_i32 %0, %1, %2, %3, 0\n\t"
-        "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %10, %11, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %12, %13, %0"
-        : "=&v"(d), "=s"(sdst)
-        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5));
-    return d;
-}
-__device__ __forceinline__ int64_t mad_col6c(int64_t d, int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2,
-        int32_t b2, int32_t a3, int32_t b3, int32_t a4, int32_t b4, int32_t a5, int32_t b5) {
-    uint64_t sdst;               // VOP3b scalar destination (carry out), unused
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %10, %11, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %12, %13, %0"
-        : "+v"(d), "=s"(sdst)
-        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5));
-    return d;
-}
-__device__ __forceinline__ int64_t mad_col5c(int64_t d, int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2,
-        int32_t b2, int32_t a3, int32_t b3, int32_t a4, int32_t b4) {
-    uint64_t sdst;               // VOP3b scalar destination (carry out), unused
+
+__device__ __forceinline__ int64_t mad5c(int64_t d, int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2, int32_t a3, int32_t b3, int32_t a4, int32_t b4) {
+    uint64_t sdst;
     asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t"
         "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
         "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t"
@@ -163,131 +131,263 @@ __device__ __forceinline__ int64_t mad_col5c(int64_t d, int32_t a0, int32_t b0, 
         : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4));
     return d;
 }
-// Limbs from columns whose carries are already chained (c_k includes c_{k-1} >> shift).
-__device__ __forceinline__ void fe_reduce_chained(fe& h, int64_t c0, int64_t c1, int64_t c2, int64_t c3, int64_t c4, int64_t c5,
-                                                  int64_t c6, int64_t c7, int64_t c8, int64_t c9) {
-    int32_t h0 = (int32_t)c0 & 0x3ffffff, h1 = (int32_t)c1 & 0x1ffffff;
-    int64_t t = (c9 >> 25) * 19 + h0;
-    h.v[0] = (int32_t)t & 0x3ffffff;
-    h.v[1] = h1 + (int32_t)(t >> 26);
-    h.v[2] = (int32_t)c2 & 0x3ffffff; h.v[3] = (int32_t)c3 & 0x1ffffff; h.v[4] = (int32_t)c4 & 0x3ffffff;
-    h.v[5] = (int32_t)c5 & 0x1ffffff; h.v[6] = (int32_t)c6 & 0x3ffffff; h.v[7] = (int32_t)c7 & 0x1ffffff;
-    h.v[8] = (int32_t)c8 & 0x3ffffff; h.v[9] = (int32_t)c9 & 0x1ffffff;
+
+__device__ __forceinline__ int64_t mad6c(int64_t d, int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2, int32_t a3, int32_t b3, int32_t a4, int32_t b4, int32_t a5, int32_t b5) {
+    uint64_t sdst;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %10, %11, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %12, %13, %0"
+        : "+v"(d), "=s"(sdst)
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5));
+    return d;
+}
+
+__device__ __forceinline__ int64_t mad7c(int64_t d, int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2, int32_t a3, int32_t b3, int32_t a4, int32_t b4, int32_t a5, int32_t b5, int32_t a6, int32_t b6) {
+    uint64_t sdst;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %10, %11, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %12, %13, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %14, %15, %0"
+        : "+v"(d), "=s"(sdst)
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), "v"(a6), "v"(b6));
+    return d;
+}
+
+__device__ __forceinline__ int64_t mad8c(int64_t d, int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2, int32_t a3, int32_t b3, int32_t a4, int32_t b4, int32_t a5, int32_t b5, int32_t a6, int32_t b6, int32_t a7, int32_t b7) {
+    uint64_t sdst;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %10, %11, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %12, %13, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %14, %15, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %16, %17, %0"
+        : "+v"(d), "=s"(sdst)
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), "v"(a6), "v"(b6), "v"(a7), "v"(b7));
+    return d;
+}
+
+__device__ __forceinline__ int64_t mad9c(int64_t d, int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2, int32_t a3, int32_t b3, int32_t a4, int32_t b4, int32_t a5, int32_t b5, int32_t a6, int32_t b6, int32_t a7, int32_t b7, int32_t a8, int32_t b8) {
+    uint64_t sdst;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %10, %11, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %12, %13, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %14, %15, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %16, %17, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %18, %19, %0"
+        : "+v"(d), "=s"(sdst)
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), "v"(a6), "v"(b6), "v"(a7), "v"(b7), "v"(a8), "v"(b8));
+    return d;
+}
+
+__device__ __forceinline__ int64_t mad10c(int64_t d, int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2, int32_t a3, int32_t b3, int32_t a4, int32_t b4, int32_t a5, int32_t b5, int32_t a6, int32_t b6, int32_t a7, int32_t b7, int32_t a8, int32_t b8, int32_t a9, int32_t b9) {
+    uint64_t sdst;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %10, %11, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %12, %13, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %14, %15, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %16, %17, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %18, %19, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %20, %21, %0"
+        : "+v"(d), "=s"(sdst)
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), "v"(a6), "v"(b6), "v"(a7), "v"(b7), "v"(a8), "v"(b8), "v"(a9), "v"(b9));
+    return d;
+}
+
+__device__ __forceinline__ int64_t mad2z(int32_t a0, int32_t b0, int32_t a1, int32_t b1) {
+    int64_t d;
+    uint64_t sdst;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, 0\n\t"
+        "v_mad_i64_i32 %0, %1, %4, %5, %0"
+        : "=&v"(d), "=s"(sdst)
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1));
+    return d;
+}
+
+__device__ __forceinline__ int64_t mad8z(int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2, int32_t a3, int32_t b3, int32_t a4, int32_t b4, int32_t a5, int32_t b5, int32_t a6, int32_t b6, int32_t a7, int32_t b7) {
+    int64_t d;
+    uint64_t sdst;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, 0\n\t"
+        "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %10, %11, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %12, %13, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %14, %15, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %16, %17, %0"
+        : "=&v"(d), "=s"(sdst)
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), "v"(a6), "v"(b6), "v"(a7), "v"(b7));
+    return d;
+}
+
+__device__ __forceinline__ int64_t mad4z(int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2, int32_t a3, int32_t b3) {
+    int64_t d;
+    uint64_t sdst;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, 0\n\t"
+        "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "=&v"(d), "=s"(sdst)
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3));
+    return d;
 }
 #endif
 
 #define M64(a, b) ((int64_t)(a) * (int64_t)(b))
 
 DAPOL_HD void fe_mul(fe& h, const fe& f, const fe& g) {
-    const int32_t f0 = f.v[0], f1 = f.v[1], f2 = f.v[2], f3 = f.v[3], f4 = f.v[4], f5 = f.v[5], f6 = f.v[6], f7 = f.v[7],
-                  f8 = f.v[8], f9 = f.v[9];
-    const int32_t g0 = g.v[0], g1 = g.v[1], g2 = g.v[2], g3 = g.v[3], g4 = g.v[4], g5 = g.v[5], g6 = g.v[6], g7 = g.v[7],
-                  g8 = g.v[8], g9 = g.v[9];
-    const int32_t g1_19 = 19 * g1, g2_19 = 19 * g2, g3_19 = 19 * g3, g4_19 = 19 * g4, g5_19 = 19 * g5, g6_19 = 19 * g6,
-                  g7_19 = 19 * g7, g8_19 = 19 * g8, g9_19 = 19 * g9;
-    const int32_t f1_2 = 2 * f1, f3_2 = 2 * f3, f5_2 = 2 * f5, f7_2 = 2 * f7, f9_2 = 2 * f9;
+    const int32_t f0 = f.v[0], f1 = f.v[1], f2 = f.v[2], f3 = f.v[3], f4 = f.v[4], f5 = f.v[5], f6 = f.v[6], f7 = f.v[7], f8 = f.v[8];
+    const int32_t g0 = g.v[0], g1 = g.v[1], g2 = g.v[2], g3 = g.v[3], g4 = g.v[4], g5 = g.v[5], g6 = g.v[6], g7 = g.v[7], g8 = g.v[8];
 #if defined(DAPOL_MAD_CHAIN)
-    const int64_t c0 = mad_col10z(f0, g0, f1_2, g9_19, f2, g8_19, f3_2, g7_19, f4, g6_19, f5_2, g5_19, f6, g4_19, f7_2,
-        g3_19, f8, g2_19, f9_2, g1_19);
-    const int64_t c1 = mad_col10c(c0 >> 26, f0, g1, f1, g0, f2, g9_19, f3, g8_19, f4, g7_19, f5, g6_19, f6, g5_19, f7,
-        g4_19, f8, g3_19, f9, g2_19);
-    const int64_t c2 = mad_col10c(c1 >> 25, f0, g2, f1_2, g1, f2, g0, f3_2, g9_19, f4, g8_19, f5_2, g7_19, f6, g6_19, f7_2,
-        g5_19, f8, g4_19, f9_2, g3_19);
-    const int64_t c3 = mad_col10c(c2 >> 26, f0, g3, f1, g2, f2, g1, f3, g0, f4, g9_19, f5, g8_19, f6, g7_19, f7, g6_19, f8,
-        g5_19, f9, g4_19);
-    const int64_t c4 = mad_col10c(c3 >> 25, f0, g4, f1_2, g3, f2, g2, f3_2, g1, f4, g0, f5_2, g9_19, f6, g8_19, f7_2,
-        g7_19, f8, g6_19, f9_2, g5_19);
-    const int64_t c5 = mad_col10c(c4 >> 26, f0, g5, f1, g4, f2, g3, f3, g2, f4, g1, f5, g0, f6, g9_19, f7, g8_19, f8,
-        g7_19, f9, g6_19);
-    const int64_t c6 = mad_col10c(c5 >> 25, f0, g6, f1_2, g5, f2, g4, f3_2, g3, f4, g2, f5_2, g1, f6, g0, f7_2, g9_19, f8,
-        g8_19, f9_2, g7_19);
-    const int64_t c7 = mad_col10c(c6 >> 26, f0, g7, f1, g6, f2, g5, f3, g4, f4, g3, f5, g2, f6, g1, f7, g0, f8, g9_19, f9,
-        g8_19);
-    const int64_t c8 = mad_col10c(c7 >> 25, f0, g8, f1_2, g7, f2, g6, f3_2, g5, f4, g4, f5_2, g3, f6, g2, f7_2, g1, f8, g0,
-        f9_2, g9_19);
-    const int64_t c9 = mad_col10c(c8 >> 26, f0, g9, f1, g8, f2, g7, f3, g6, f4, g5, f5, g4, f6, g3, f7, g2, f8, g1, f9, g0);
-    fe_reduce_chained(h, c0, c1, c2, c3, c4, c5, c6, c7, c8, c9);
+    const int32_t k1216 = 1216;
+    const int64_t c9 = mad8z(f1, g8, f2, g7, f3, g6, f4, g5, f5, g4, f6, g3, f7, g2, f8, g1);
+    const int64_t c10 = mad7c(c9 >> 29, f2, g8, f3, g7, f4, g6, f5, g5, f6, g4, f7, g3, f8, g2);
+    const int64_t c11 = mad6c(c10 >> 29, f3, g8, f4, g7, f5, g6, f6, g5, f7, g4, f8, g3);
+    const int64_t c12 = mad5c(c11 >> 29, f4, g8, f5, g7, f6, g6, f7, g5, f8, g4);
+    const int64_t c13 = mad4c(c12 >> 29, f5, g8, f6, g7, f7, g6, f8, g5);
+    const int64_t c14 = mad3c(c13 >> 29, f6, g8, f7, g7, f8, g6);
+    const int64_t c15 = mad2c(c14 >> 29, f7, g8, f8, g7);
+    const int64_t c16 = mad1c(c15 >> 29, f8, g8);
+    // the high half as limbs h9..h16 (+ the last carry h17): column k wraps to column k - 9 times 2^261 mod p = 1216
+    const int32_t h9 = (int32_t)c9 & FE_M29;
+    const int32_t h10 = (int32_t)c10 & FE_M29;
+    const int32_t h11 = (int32_t)c11 & FE_M29;
+    const int32_t h12 = (int32_t)c12 & FE_M29;
+    const int32_t h13 = (int32_t)c13 & FE_M29;
+    const int32_t h14 = (int32_t)c14 & FE_M29;
+    const int32_t h15 = (int32_t)c15 & FE_M29;
+    const int32_t h16 = (int32_t)c16 & FE_M29;
+    const int32_t h17 = (int32_t)(c16 >> 29);
+    const int64_t c0 = mad2z(f0, g0, h9, k1216);
+    const int64_t c1 = mad3c(c0 >> 29, f0, g1, f1, g0, h10, k1216);
+    const int64_t c2 = mad4c(c1 >> 29, f0, g2, f1, g1, f2, g0, h11, k1216);
+    const int64_t c3 = mad5c(c2 >> 29, f0, g3, f1, g2, f2, g1, f3, g0, h12, k1216);
+    const int64_t c4 = mad6c(c3 >> 29, f0, g4, f1, g3, f2, g2, f3, g1, f4, g0, h13, k1216);
+    const int64_t c5 = mad7c(c4 >> 29, f0, g5, f1, g4, f2, g3, f3, g2, f4, g1, f5, g0, h14, k1216);
+    const int64_t c6 = mad8c(c5 >> 29, f0, g6, f1, g5, f2, g4, f3, g3, f4, g2, f5, g1, f6, g0, h15, k1216);
+    const int64_t c7 = mad9c(c6 >> 29, f0, g7, f1, g6, f2, g5, f3, g4, f4, g3, f5, g2, f6, g1, f7, g0, h16, k1216);
+    const int64_t c8 = mad10c(c7 >> 29, f0, g8, f1, g7, f2, g6, f3, g5, f4, g4, f5, g3, f6, g2, f7, g1, f8, g0, h17, k1216);
 #else
-    int64_t c0 = M64(f0, g0) + M64(f1_2, g9_19) + M64(f2, g8_19) + M64(f3_2, g7_19) + M64(f4, g6_19) + M64(f5_2, g5_19) +
-                 M64(f6, g4_19) + M64(f7_2, g3_19) + M64(f8, g2_19) + M64(f9_2, g1_19);
-    int64_t c1 = M64(f0, g1) + M64(f1, g0) + M64(f2, g9_19) + M64(f3, g8_19) + M64(f4, g7_19) + M64(f5, g6_19) +
-                 M64(f6, g5_19) + M64(f7, g4_19) + M64(f8, g3_19) + M64(f9, g2_19);
-    int64_t c2 = M64(f0, g2) + M64(f1_2, g1) + M64(f2, g0) + M64(f3_2, g9_19) + M64(f4, g8_19) + M64(f5_2, g7_19) +
-                 M64(f6, g6_19) + M64(f7_2, g5_19) + M64(f8, g4_19) + M64(f9_2, g3_19);
-    int64_t c3 = M64(f0, g3) + M64(f1, g2) + M64(f2, g1) + M64(f3, g0) + M64(f4, g9_19) + M64(f5, g8_19) + M64(f6, g7_19) +
-                 M64(f7, g6_19) + M64(f8, g5_19) + M64(f9, g4_19);
-    int64_t c4 = M64(f0, g4) + M64(f1_2, g3) + M64(f2, g2) + M64(f3_2, g1) + M64(f4, g0) + M64(f5_2, g9_19) + M64(f6, g8_19) +
-                 M64(f7_2, g7_19) + M64(f8, g6_19) + M64(f9_2, g5_19);
-    int64_t c5 = M64(f0, g5) + M64(f1, g4) + M64(f2, g3) + M64(f3, g2) + M64(f4, g1) + M64(f5, g0) + M64(f6, g9_19) +
-                 M64(f7, g8_19) + M64(f8, g7_19) + M64(f9, g6_19);
-    int64_t c6 = M64(f0, g6) + M64(f1_2, g5) + M64(f2, g4) + M64(f3_2, g3) + M64(f4, g2) + M64(f5_2, g1) + M64(f6, g0) +
-                 M64(f7_2, g9_19) + M64(f8, g8_19) + M64(f9_2, g7_19);
-    int64_t c7 = M64(f0, g7) + M64(f1, g6) + M64(f2, g5) + M64(f3, g4) + M64(f4, g3) + M64(f5, g2) + M64(f6, g1) + M64(f7, g0) +
-                 M64(f8, g9_19) + M64(f9, g8_19);
-    int64_t c8 = M64(f0, g8) + M64(f1_2, g7) + M64(f2, g6) + M64(f3_2, g5) + M64(f4, g4) + M64(f5_2, g3) + M64(f6, g2) +
-                 M64(f7_2, g1) + M64(f8, g0) + M64(f9_2, g9_19);
-    int64_t c9 = M64(f0, g9) + M64(f1, g8) + M64(f2, g7) + M64(f3, g6) + M64(f4, g5) + M64(f5, g4) + M64(f6, g3) + M64(f7, g2) +
-                 M64(f8, g1) + M64(f9, g0);
-    fe_reduce_cols(h, c0, c1, c2, c3, c4, c5, c6, c7, c8, c9);
+    const int64_t c9 = M64(f1, g8) + M64(f2, g7) + M64(f3, g6) + M64(f4, g5) + M64(f5, g4) + M64(f6, g3) + M64(f7, g2) + M64(f8, g1);
+    const int64_t c10 = (c9 >> 29) + M64(f2, g8) + M64(f3, g7) + M64(f4, g6) + M64(f5, g5) + M64(f6, g4) + M64(f7, g3) + M64(f8, g2);
+    const int64_t c11 = (c10 >> 29) + M64(f3, g8) + M64(f4, g7) + M64(f5, g6) + M64(f6, g5) + M64(f7, g4) + M64(f8, g3);
+    const int64_t c12 = (c11 >> 29) + M64(f4, g8) + M64(f5, g7) + M64(f6, g6) + M64(f7, g5) + M64(f8, g4);
+    const int64_t c13 = (c12 >> 29) + M64(f5, g8) + M64(f6, g7) + M64(f7, g6) + M64(f8, g5);
+    const int64_t c14 = (c13 >> 29) + M64(f6, g8) + M64(f7, g7) + M64(f8, g6);
+    const int64_t c15 = (c14 >> 29) + M64(f7, g8) + M64(f8, g7);
+    const int64_t c16 = (c15 >> 29) + M64(f8, g8);
+    const int32_t h9 = (int32_t)c9 & FE_M29;
+    const int32_t h10 = (int32_t)c10 & FE_M29;
+    const int32_t h11 = (int32_t)c11 & FE_M29;
+    const int32_t h12 = (int32_t)c12 & FE_M29;
+    const int32_t h13 = (int32_t)c13 & FE_M29;
+    const int32_t h14 = (int32_t)c14 & FE_M29;
+    const int32_t h15 = (int32_t)c15 & FE_M29;
+    const int32_t h16 = (int32_t)c16 & FE_M29;
+    const int32_t h17 = (int32_t)(c16 >> 29);
+    const int64_t c0 = M64(f0, g0) + M64(h9, 1216);
+    const int64_t c1 = (c0 >> 29) + M64(f0, g1) + M64(f1, g0) + M64(h10, 1216);
+    const int64_t c2 = (c1 >> 29) + M64(f0, g2) + M64(f1, g1) + M64(f2, g0) + M64(h11, 1216);
+    const int64_t c3 = (c2 >> 29) + M64(f0, g3) + M64(f1, g2) + M64(f2, g1) + M64(f3, g0) + M64(h12, 1216);
+    const int64_t c4 = (c3 >> 29) + M64(f0, g4) + M64(f1, g3) + M64(f2, g2) + M64(f3, g1) + M64(f4, g0) + M64(h13, 1216);
+    const int64_t c5 = (c4 >> 29) + M64(f0, g5) + M64(f1, g4) + M64(f2, g3) + M64(f3, g2) + M64(f4, g1) + M64(f5, g0) + M64(h14, 1216);
+    const int64_t c6 = (c5 >> 29) + M64(f0, g6) + M64(f1, g5) + M64(f2, g4) + M64(f3, g3) + M64(f4, g2) + M64(f5, g1) + M64(f6, g0) + M64(h15, 1216);
+    const int64_t c7 = (c6 >> 29) + M64(f0, g7) + M64(f1, g6) + M64(f2, g5) + M64(f3, g4) + M64(f4, g3) + M64(f5, g2) + M64(f6, g1) + M64(f7, g0) + M64(h16, 1216);
+    const int64_t c8 = (c7 >> 29) + M64(f0, g8) + M64(f1, g7) + M64(f2, g6) + M64(f3, g5) + M64(f4, g4) + M64(f5, g3) + M64(f6, g2) + M64(f7, g1) + M64(f8, g0) + M64(h17, 1216);
 #endif
+    fe_limbs_from_cols(h, c0, c1, c2, c3, c4, c5, c6, c7, c8);
 }
 
 DAPOL_HD void fe_sq(fe& h, const fe& f) {
-    const int32_t f0 = f.v[0], f1 = f.v[1], f2 = f.v[2], f3 = f.v[3], f4 = f.v[4], f5 = f.v[5], f6 = f.v[6], f7 = f.v[7],
-                  f8 = f.v[8], f9 = f.v[9];
-    const int32_t f0_2 = 2 * f0, f1_2 = 2 * f1, f2_2 = 2 * f2, f3_2 = 2 * f3, f4_2 = 2 * f4, f5_2 = 2 * f5, f6_2 = 2 * f6,
-                  f7_2 = 2 * f7;
-    const int32_t f5_38 = 38 * f5, f6_19 = 19 * f6, f7_38 = 38 * f7, f8_19 = 19 * f8, f9_38 = 38 * f9;
+    const int32_t f0 = f.v[0], f1 = f.v[1], f2 = f.v[2], f3 = f.v[3], f4 = f.v[4], f5 = f.v[5], f6 = f.v[6], f7 = f.v[7], f8 = f.v[8];
+    const int32_t f0_2 = 2 * f0, f1_2 = 2 * f1, f2_2 = 2 * f2, f3_2 = 2 * f3, f4_2 = 2 * f4, f5_2 = 2 * f5, f6_2 = 2 * f6, f7_2 = 2 * f7;
 #if defined(DAPOL_MAD_CHAIN)
-    const int64_t c0 = mad_col6z(f0, f0, f1_2, f9_38, f2_2, f8_19, f3_2, f7_38, f4_2, f6_19, f5, f5_38);
-    const int64_t c1 = mad_col5c(c0 >> 26, f0_2, f1, f2, f9_38, f3_2, f8_19, f4, f7_38, f5_2, f6_19);
-    const int64_t c2 = mad_col6c(c1 >> 25, f0_2, f2, f1_2, f1, f3_2, f9_38, f4_2, f8_19, f5_2, f7_38, f6, f6_19);
-    const int64_t c3 = mad_col5c(c2 >> 26, f0_2, f3, f1_2, f2, f4, f9_38, f5_2, f8_19, f6, f7_38);
-    const int64_t c4 = mad_col6c(c3 >> 25, f0_2, f4, f1_2, f3_2, f2, f2, f5_2, f9_38, f6_2, f8_19, f7, f7_38);
-    const int64_t c5 = mad_col5c(c4 >> 26, f0_2, f5, f1_2, f4, f2_2, f3, f6, f9_38, f7_2, f8_19);
-    const int64_t c6 = mad_col6c(c5 >> 25, f0_2, f6, f1_2, f5_2, f2_2, f4, f3_2, f3, f7_2, f9_38, f8, f8_19);
-    const int64_t c7 = mad_col5c(c6 >> 26, f0_2, f7, f1_2, f6, f2_2, f5, f3_2, f4, f8, f9_38);
-    const int64_t c8 = mad_col6c(c7 >> 25, f0_2, f8, f1_2, f7_2, f2_2, f6, f3_2, f5_2, f4, f4, f9, f9_38);
-    const int64_t c9 = mad_col5c(c8 >> 26, f0_2, f9, f1_2, f8, f2_2, f7, f3_2, f6, f4_2, f5);
-    fe_reduce_chained(h, c0, c1, c2, c3, c4, c5, c6, c7, c8, c9);
+    const int32_t k1216 = 1216;
+    const int64_t c9 = mad4z(f1_2, f8, f2_2, f7, f3_2, f6, f4_2, f5);
+    const int64_t c10 = mad4c(c9 >> 29, f2_2, f8, f3_2, f7, f4_2, f6, f5, f5);
+    const int64_t c11 = mad3c(c10 >> 29, f3_2, f8, f4_2, f7, f5_2, f6);
+    const int64_t c12 = mad3c(c11 >> 29, f4_2, f8, f5_2, f7, f6, f6);
+    const int64_t c13 = mad2c(c12 >> 29, f5_2, f8, f6_2, f7);
+    const int64_t c14 = mad2c(c13 >> 29, f6_2, f8, f7, f7);
+    const int64_t c15 = mad1c(c14 >> 29, f7_2, f8);
+    const int64_t c16 = mad1c(c15 >> 29, f8, f8);
+    const int32_t h9 = (int32_t)c9 & FE_M29;
+    const int32_t h10 = (int32_t)c10 & FE_M29;
+    const int32_t h11 = (int32_t)c11 & FE_M29;
+    const int32_t h12 = (int32_t)c12 & FE_M29;
+    const int32_t h13 = (int32_t)c13 & FE_M29;
+    const int32_t h14 = (int32_t)c14 & FE_M29;
+    const int32_t h15 = (int32_t)c15 & FE_M29;
+    const int32_t h16 = (int32_t)c16 & FE_M29;
+    const int32_t h17 = (int32_t)(c16 >> 29);
+    const int64_t c0 = mad2z(f0, f0, h9, k1216);
+    const int64_t c1 = mad2c(c0 >> 29, f0_2, f1, h10, k1216);
+    const int64_t c2 = mad3c(c1 >> 29, f0_2, f2, f1, f1, h11, k1216);
+    const int64_t c3 = mad3c(c2 >> 29, f0_2, f3, f1_2, f2, h12, k1216);
+    const int64_t c4 = mad4c(c3 >> 29, f0_2, f4, f1_2, f3, f2, f2, h13, k1216);
+    const int64_t c5 = mad4c(c4 >> 29, f0_2, f5, f1_2, f4, f2_2, f3, h14, k1216);
+    const int64_t c6 = mad5c(c5 >> 29, f0_2, f6, f1_2, f5, f2_2, f4, f3, f3, h15, k1216);
+    const int64_t c7 = mad5c(c6 >> 29, f0_2, f7, f1_2, f6, f2_2, f5, f3_2, f4, h16, k1216);
+    const int64_t c8 = mad6c(c7 >> 29, f0_2, f8, f1_2, f7, f2_2, f6, f3_2, f5, f4, f4, h17, k1216);
 #else
-    int64_t c0 = M64(f0, f0) + M64(f1_2, f9_38) + M64(f2_2, f8_19) + M64(f3_2, f7_38) + M64(f4_2, f6_19) + M64(f5, f5_38);
-    int64_t c1 = M64(f0_2, f1) + M64(f2, f9_38) + M64(f3_2, f8_19) + M64(f4, f7_38) + M64(f5_2, f6_19);
-    int64_t c2 = M64(f0_2, f2) + M64(f1_2, f1) + M64(f3_2, f9_38) + M64(f4_2, f8_19) + M64(f5_2, f7_38) + M64(f6, f6_19);
-    int64_t c3 = M64(f0_2, f3) + M64(f1_2, f2) + M64(f4, f9_38) + M64(f5_2, f8_19) + M64(f6, f7_38);
-    int64_t c4 = M64(f0_2, f4) + M64(f1_2, f3_2) + M64(f2, f2) + M64(f5_2, f9_38) + M64(f6_2, f8_19) + M64(f7, f7_38);
-    int64_t c5 = M64(f0_2, f5) + M64(f1_2, f4) + M64(f2_2, f3) + M64(f6, f9_38) + M64(f7_2, f8_19);
-    int64_t c6 = M64(f0_2, f6) + M64(f1_2, f5_2) + M64(f2_2, f4) + M64(f3_2, f3) + M64(f7_2, f9_38) + M64(f8, f8_19);
-    int64_t c7 = M64(f0_2, f7) + M64(f1_2, f6) + M64(f2_2, f5) + M64(f3_2, f4) + M64(f8, f9_38);
-    int64_t c8 = M64(f0_2, f8) + M64(f1_2, f7_2) + M64(f2_2, f6) + M64(f3_2, f5_2) + M64(f4, f4) + M64(f9, f9_38);
-    int64_t c9 = M64(f0_2, f9) + M64(f1_2, f8) + M64(f2_2, f7) + M64(f3_2, f6) + M64(f4_2, f5);
-    fe_reduce_cols(h, c0, c1, c2, c3, c4, c5, c6, c7, c8, c9);
+    const int64_t c9 = M64(f1_2, f8) + M64(f2_2, f7) + M64(f3_2, f6) + M64(f4_2, f5);
+    const int64_t c10 = (c9 >> 29) + M64(f2_2, f8) + M64(f3_2, f7) + M64(f4_2, f6) + M64(f5, f5);
+    const int64_t c11 = (c10 >> 29) + M64(f3_2, f8) + M64(f4_2, f7) + M64(f5_2, f6);
+    const int64_t c12 = (c11 >> 29) + M64(f4_2, f8) + M64(f5_2, f7) + M64(f6, f6);
+    const int64_t c13 = (c12 >> 29) + M64(f5_2, f8) + M64(f6_2, f7);
+    const int64_t c14 = (c13 >> 29) + M64(f6_2, f8) + M64(f7, f7);
+    const int64_t c15 = (c14 >> 29) + M64(f7_2, f8);
+    const int64_t c16 = (c15 >> 29) + M64(f8, f8);
+    const int32_t h9 = (int32_t)c9 & FE_M29;
+    const int32_t h10 = (int32_t)c10 & FE_M29;
+    const int32_t h11 = (int32_t)c11 & FE_M29;
+    const int32_t h12 = (int32_t)c12 & FE_M29;
+    const int32_t h13 = (int32_t)c13 & FE_M29;
+    const int32_t h14 = (int32_t)c14 & FE_M29;
+    const int32_t h15 = (int32_t)c15 & FE_M29;
+    const int32_t h16 = (int32_t)c16 & FE_M29;
+    const int32_t h17 = (int32_t)(c16 >> 29);
+    const int64_t c0 = M64(f0, f0) + M64(h9, 1216);
+    const int64_t c1 = (c0 >> 29) + M64(f0_2, f1) + M64(h10, 1216);
+    const int64_t c2 = (c1 >> 29) + M64(f0_2, f2) + M64(f1, f1) + M64(h11, 1216);
+    const int64_t c3 = (c2 >> 29) + M64(f0_2, f3) + M64(f1_2, f2) + M64(h12, 1216);
+    const int64_t c4 = (c3 >> 29) + M64(f0_2, f4) + M64(f1_2, f3) + M64(f2, f2) + M64(h13, 1216);
+    const int64_t c5 = (c4 >> 29) + M64(f0_2, f5) + M64(f1_2, f4) + M64(f2_2, f3) + M64(h14, 1216);
+    const int64_t c6 = (c5 >> 29) + M64(f0_2, f6) + M64(f1_2, f5) + M64(f2_2, f4) + M64(f3, f3) + M64(h15, 1216);
+    const int64_t c7 = (c6 >> 29) + M64(f0_2, f7) + M64(f1_2, f6) + M64(f2_2, f5) + M64(f3_2, f4) + M64(h16, 1216);
+    const int64_t c8 = (c7 >> 29) + M64(f0_2, f8) + M64(f1_2, f7) + M64(f2_2, f6) + M64(f3_2, f5) + M64(f4, f4) + M64(h17, 1216);
 #endif
+    fe_limbs_from_cols(h, c0, c1, c2, c3, c4, c5, c6, c7, c8);
 }
 #undef M64
 
-// h = f * small constant (|c| < 2^20), carried
-DAPOL_HD void fe_mul_small(fe& h, const fe& f, int32_t c) {
-    fe_reduce_cols(h, (int64_t)f.v[0] * c, (int64_t)f.v[1] * c, (int64_t)f.v[2] * c, (int64_t)f.v[3] * c, (int64_t)f.v[4] * c,
-                   (int64_t)f.v[5] * c, (int64_t)f.v[6] * c, (int64_t)f.v[7] * c, (int64_t)f.v[8] * c, (int64_t)f.v[9] * c);
-}
-
-// Weak carry of a LOOSE value (|limb| < 2^30) back to reduced form, all in 32-bit VOP2 ops.
+// Weak carry of a LOOSE value (|limb| < 2^31 / 20) back to reduced form, all in 32-bit ops.
 DAPOL_HD void fe_carry(fe& h, const fe& f) {
-    int32_t h0 = f.v[0], h1 = f.v[1], h2 = f.v[2], h3 = f.v[3], h4 = f.v[4], h5 = f.v[5], h6 = f.v[6], h7 = f.v[7], h8 = f.v[8],
-            h9 = f.v[9];
-    h1 += h0 >> 26; h0 &= 0x3ffffff;
-    h2 += h1 >> 25; h1 &= 0x1ffffff;
-    h3 += h2 >> 26; h2 &= 0x3ffffff;
-    h4 += h3 >> 25; h3 &= 0x1ffffff;
-    h5 += h4 >> 26; h4 &= 0x3ffffff;
-    h6 += h5 >> 25; h5 &= 0x1ffffff;
-    h7 += h6 >> 26; h6 &= 0x3ffffff;
-    h8 += h7 >> 25; h7 &= 0x1ffffff;
-    h9 += h8 >> 26; h8 &= 0x3ffffff;
-    h0 += 19 * (h9 >> 25); h9 &= 0x1ffffff;
-    h1 += h0 >> 26; h0 &= 0x3ffffff;
-    h.v[0] = h0; h.v[1] = h1; h.v[2] = h2; h.v[3] = h3; h.v[4] = h4; h.v[5] = h5; h.v[6] = h6; h.v[7] = h7; h.v[8] = h8; h.v[9] = h9;
+    int32_t h0 = f.v[0], h1 = f.v[1], h2 = f.v[2], h3 = f.v[3], h4 = f.v[4], h5 = f.v[5], h6 = f.v[6], h7 = f.v[7], h8 = f.v[8];
+    h1 += h0 >> 29; h0 &= FE_M29;
+    h2 += h1 >> 29; h1 &= FE_M29;
+    h3 += h2 >> 29; h2 &= FE_M29;
+    h4 += h3 >> 29; h3 &= FE_M29;
+    h5 += h4 >> 29; h4 &= FE_M29;
+    h6 += h5 >> 29; h5 &= FE_M29;
+    h7 += h6 >> 29; h6 &= FE_M29;
+    h8 += h7 >> 29; h7 &= FE_M29;
+    h0 += 19 * (h8 >> 23); h8 &= FE_M23;
+    h1 += h0 >> 29; h0 &= FE_M29;
+    h.v[0] = h0; h.v[1] = h1; h.v[2] = h2; h.v[3] = h3; h.v[4] = h4; h.v[5] = h5; h.v[6] = h6; h.v[7] = h7; h.v[8] = h8;
 }
 // carried sum: reduced output from two reduced (or tight) inputs
 DAPOL_HD void fe_addc(fe& h, const fe& f, const fe& g) {
@@ -338,34 +438,39 @@ DAPOL_HD_NOINLINE void fe_invert(fe& out, const fe& z) {
     fe_mul(out, t, z3);      // z^(2^255-21)
 }
 
+// Eight little-endian words of the canonical (fully reduced) value.  Accepts any tight / loose input, negative limbs
+// included: two signed carry passes bring the value into [0, 2^255 + 19], the last step subtracts p when it is >= p.
+DAPOL_HD void fe_towords(uint32_t* w, const fe& f) {
+    int32_t l[FE_NL];
+    for (int i = 0; i < FE_NL; i++) l[i] = f.v[i];
+    for (int pass = 0; pass < 3; pass++) {
+        for (int i = 0; i < 8; i++) { l[i + 1] += l[i] >> 29; l[i] &= FE_M29; }
+        l[0] += 19 * (l[8] >> 23);
+        l[8] &= FE_M23;
+    }
+    // now limbs 1..8 are canonical-width, l0 in [0, 2^29 + 19]; value in [0, 2^255 + 19).  q = 1 iff value >= p.
+    int32_t q = (l[0] + 19) >> 29;
+    for (int i = 1; i < 8; i++) q = (l[i] + q) >> 29;
+    q = (l[8] + q) >> 23;
+    l[0] += 19 * q;
+    for (int i = 0; i < 8; i++) { l[i + 1] += l[i] >> 29; l[i] &= FE_M29; }
+    l[8] &= FE_M23;                                             // drops q * 2^255
+    const uint32_t u0 = (uint32_t)l[0], u1 = (uint32_t)l[1], u2 = (uint32_t)l[2], u3 = (uint32_t)l[3], u4 = (uint32_t)l[4],
+                   u5 = (uint32_t)l[5], u6 = (uint32_t)l[6], u7 = (uint32_t)l[7], u8 = (uint32_t)l[8];
+    w[0] = u0 | (u1 << 29);                  // bits   0.. 31: limb 0 (29) + 3 of limb 1
+    w[1] = (u1 >> 3) | (u2 << 26);           // bits  32.. 63: 26 of limb 1 + 6 of limb 2
+    w[2] = (u2 >> 6) | (u3 << 23);           // bits  64.. 95: 23 + 9
+    w[3] = (u3 >> 9) | (u4 << 20);           // bits  96..127: 20 + 12
+    w[4] = (u4 >> 12) | (u5 << 17);          // bits 128..159: 17 + 15
+    w[5] = (u5 >> 15) | (u6 << 14);          // bits 160..191: 14 + 18
+    w[6] = (u6 >> 18) | (u7 << 11);          // bits 192..223: 11 + 21
+    w[7] = (u7 >> 21) | (u8 << 8);           // bits 224..255:  8 + 23 (+ bit 255 = 0)
+}
+
 // Canonical little-endian 32-byte encoding (fully reduced).
 DAPOL_HD void fe_tobytes(uint8_t* s, const fe& f) {
-    int32_t h0 = f.v[0], h1 = f.v[1], h2 = f.v[2], h3 = f.v[3], h4 = f.v[4], h5 = f.v[5], h6 = f.v[6], h7 = f.v[7], h8 = f.v[8],
-            h9 = f.v[9];
-    int32_t q = (19 * h9 + (1 << 24)) >> 25;
-    q = (h0 + q) >> 26; q = (h1 + q) >> 25; q = (h2 + q) >> 26; q = (h3 + q) >> 25; q = (h4 + q) >> 26;
-    q = (h5 + q) >> 25; q = (h6 + q) >> 26; q = (h7 + q) >> 25; q = (h8 + q) >> 26; q = (h9 + q) >> 25;
-    h0 += 19 * q;
-    int32_t c;
-    c = h0 >> 26; h1 += c; h0 -= c * (1 << 26);
-    c = h1 >> 25; h2 += c; h1 -= c * (1 << 25);
-    c = h2 >> 26; h3 += c; h2 -= c * (1 << 26);
-    c = h3 >> 25; h4 += c; h3 -= c * (1 << 25);
-    c = h4 >> 26; h5 += c; h4 -= c * (1 << 26);
-    c = h5 >> 25; h6 += c; h5 -= c * (1 << 25);
-    c = h6 >> 26; h7 += c; h6 -= c * (1 << 26);
-    c = h7 >> 25; h8 += c; h7 -= c * (1 << 25);
-    c = h8 >> 26; h9 += c; h8 -= c * (1 << 26);
-    c = h9 >> 25; h9 -= c * (1 << 25);
     uint32_t w[8];
-    w[0] = (uint32_t)h0 | ((uint32_t)h1 << 26);
-    w[1] = ((uint32_t)h1 >> 6) | ((uint32_t)h2 << 19);
-    w[2] = ((uint32_t)h2 >> 13) | ((uint32_t)h3 << 13);
-    w[3] = ((uint32_t)h3 >> 19) | ((uint32_t)h4 << 6);
-    w[4] = (uint32_t)h5 | ((uint32_t)h6 << 25);
-    w[5] = ((uint32_t)h6 >> 7) | ((uint32_t)h7 << 19);
-    w[6] = ((uint32_t)h7 >> 13) | ((uint32_t)h8 << 12);
-    w[7] = ((uint32_t)h8 >> 20) | ((uint32_t)h9 << 6);
+    fe_towords(w, f);
     for (int i = 0; i < 8; i++) {
         s[4 * i] = (uint8_t)w[i];
         s[4 * i + 1] = (uint8_t)(w[i] >> 8);
@@ -374,26 +479,17 @@ DAPOL_HD void fe_tobytes(uint8_t* s, const fe& f) {
     }
 }
 
-// Same as fe_tobytes but into eight little-endian words (device-friendly: no byte stores).
-DAPOL_HD void fe_towords(uint32_t* w, const fe& f) {
-    uint8_t s[32];
-    fe_tobytes(s, f);
-    for (int i = 0; i < 8; i++)
-        w[i] = (uint32_t)s[4 * i] | ((uint32_t)s[4 * i + 1] << 8) | ((uint32_t)s[4 * i + 2] << 16) | ((uint32_t)s[4 * i + 3] << 24);
-}
-
 // Load from eight little-endian words; bit 255 is ignored (dalek FieldElement::from_bytes semantics).
 DAPOL_HD void fe_fromwords(fe& h, const uint32_t* w) {
-    h.v[0] = (int32_t)(w[0] & 0x3ffffff);
-    h.v[1] = (int32_t)(((w[0] >> 26) | (w[1] << 6)) & 0x1ffffff);
-    h.v[2] = (int32_t)(((w[1] >> 19) | (w[2] << 13)) & 0x3ffffff);
-    h.v[3] = (int32_t)(((w[2] >> 13) | (w[3] << 19)) & 0x1ffffff);
-    h.v[4] = (int32_t)((w[3] >> 6) & 0x3ffffff);
-    h.v[5] = (int32_t)(w[4] & 0x1ffffff);
-    h.v[6] = (int32_t)(((w[4] >> 25) | (w[5] << 7)) & 0x3ffffff);
-    h.v[7] = (int32_t)(((w[5] >> 19) | (w[6] << 13)) & 0x1ffffff);
-    h.v[8] = (int32_t)(((w[6] >> 12) | (w[7] << 20)) & 0x3ffffff);
-    h.v[9] = (int32_t)((w[7] >> 6) & 0x1ffffff);
+    h.v[0] = (int32_t)(w[0] & FE_M29);
+    h.v[1] = (int32_t)(((w[0] >> 29) | (w[1] << 3)) & FE_M29);
+    h.v[2] = (int32_t)(((w[1] >> 26) | (w[2] << 6)) & FE_M29);
+    h.v[3] = (int32_t)(((w[2] >> 23) | (w[3] << 9)) & FE_M29);
+    h.v[4] = (int32_t)(((w[3] >> 20) | (w[4] << 12)) & FE_M29);
+    h.v[5] = (int32_t)(((w[4] >> 17) | (w[5] << 15)) & FE_M29);
+    h.v[6] = (int32_t)(((w[5] >> 14) | (w[6] << 18)) & FE_M29);
+    h.v[7] = (int32_t)(((w[6] >> 11) | (w[7] << 21)) & FE_M29);
+    h.v[8] = (int32_t)((w[7] >> 8) & FE_M23);
 }
 
 DAPOL_HD void fe_frombytes(fe& h, const uint8_t* s) {

@@ -18,17 +18,20 @@ __device__ __forceinline__ void st8(uint32_t* p, const uint32_t* w) {
     q[0] = make_uint4(w[0], w[1], w[2], w[3]);
     q[1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
-__device__ __forceinline__ void ld_p3(ge_p3& p, const int32_t* src) {  // 40 words
+// An extended point in memory: a record of P3_WORDS = 40 words (160 bytes, the stride every buffer uses) holding
+// X | Y | Z | T as 4 x FE_NL = 36 limbs; the last four words are unused.
+enum { P3_WORDS = 40 };
+__device__ __forceinline__ void ld_p3(ge_p3& p, const int32_t* src) {
     const int4* q = reinterpret_cast<const int4*>(src);
-    int32_t w[40];
-    for (int i = 0; i < 10; i++) { int4 a = q[i]; w[4 * i] = a.x; w[4 * i + 1] = a.y; w[4 * i + 2] = a.z; w[4 * i + 3] = a.w; }
-    for (int i = 0; i < 10; i++) { p.X.v[i] = w[i]; p.Y.v[i] = w[10 + i]; p.Z.v[i] = w[20 + i]; p.T.v[i] = w[30 + i]; }
+    int32_t w[4 * FE_NL];
+    for (int i = 0; i < FE_NL; i++) { int4 a = q[i]; w[4 * i] = a.x; w[4 * i + 1] = a.y; w[4 * i + 2] = a.z; w[4 * i + 3] = a.w; }
+    for (int i = 0; i < FE_NL; i++) { p.X.v[i] = w[i]; p.Y.v[i] = w[FE_NL + i]; p.Z.v[i] = w[2 * FE_NL + i]; p.T.v[i] = w[3 * FE_NL + i]; }
 }
 __device__ __forceinline__ void st_p3(int32_t* dst, const ge_p3& p) {
-    int32_t w[40];
-    for (int i = 0; i < 10; i++) { w[i] = p.X.v[i]; w[10 + i] = p.Y.v[i]; w[20 + i] = p.Z.v[i]; w[30 + i] = p.T.v[i]; }
+    int32_t w[4 * FE_NL];
+    for (int i = 0; i < FE_NL; i++) { w[i] = p.X.v[i]; w[FE_NL + i] = p.Y.v[i]; w[2 * FE_NL + i] = p.Z.v[i]; w[3 * FE_NL + i] = p.T.v[i]; }
     int4* q = reinterpret_cast<int4*>(dst);
-    for (int i = 0; i < 10; i++) q[i] = make_int4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+    for (int i = 0; i < FE_NL; i++) q[i] = make_int4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
 }
 
 // ----------------------------------------------------------------------------- context: generator chains
@@ -116,8 +119,7 @@ __global__ void k_ctx_table(int32_t* table, const int32_t* base_pts, int n_rows,
         ge_to_niels(q, x, y);
     }
     int32_t* e = table + ((size_t)row * entries + (size_t)k) * TBL_ENTRY_WORDS;
-    for (int i = 0; i < 10; i++) { e[i] = q.ypx.v[i]; e[10 + i] = q.ymx.v[i]; e[20 + i] = q.xy2d.v[i]; }
-    e[30] = 0; e[31] = 0;
+    niels_store_entry(e, q);
 }
 __global__ void k_ctx_compress(uint32_t* comp /*[rows][8]*/, const int32_t* base_pts, int n_rows) {
     int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -155,20 +157,16 @@ __global__ __launch_bounds__(256) void k_commit_hash(TableView tbl, size_t n, co
 }
 
 // --------------------------------------------------------------------------------------------------- scan
+// The level sizes live on the DEVICE (cnt[k] = real nodes of level k): every kernel of the build reads its bound from there
+// and is launched over the host-side upper bound, so the host never waits for a level (no per-level synchronisation).
 // flag[i] = 1 if node i starts a new parent (its index >> 1 differs from its predecessor's).
-__global__ void k_tree_flags(size_t n, const uint64_t* idx, uint32_t* flag) {
+__global__ void k_tree_flags(const uint32_t* n_ptr, const uint64_t* idx, uint32_t* flag) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= *n_ptr) return;
     flag[i] = (i == 0 || (idx[i] >> 1) != (idx[i - 1] >> 1)) ? 1u : 0u;
 }
-// Block-local inclusive scan of 1024 elements per 256-thread block.
-__global__ __launch_bounds__(256) void k_scan_block(size_t n, const uint32_t* in, uint32_t* out, uint32_t* block_sums) {
-    __shared__ uint32_t wave_tot[4];
-    size_t base = (size_t)blockIdx.x * 1024 + (size_t)threadIdx.x * 4;
-    uint32_t a[4];
-    for (int k = 0; k < 4; k++) a[k] = (base + k < n) ? in[base + k] : 0u;
-    a[1] += a[0]; a[2] += a[1]; a[3] += a[2];
-    uint32_t x = a[3];
+// Inclusive scan of 256 values held one per thread; returns the inclusive value, *total = sum over the block.
+__device__ __forceinline__ uint32_t block_scan256(uint32_t x, uint32_t* wave_tot /*[4] shared*/, uint32_t* total) {
     int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int off = 1; off < 64; off <<= 1) {
         uint32_t y = __shfl_up(x, off);
@@ -176,23 +174,45 @@ __global__ __launch_bounds__(256) void k_scan_block(size_t n, const uint32_t* in
     }
     if (lane == 63) wave_tot[wv] = x;
     __syncthreads();
-    uint32_t add = 0;
-    for (int k = 0; k < wv; k++) add += wave_tot[k];
-    uint32_t excl = x - a[3] + add;
+    uint32_t add = 0, all = 0;
+    for (int k = 0; k < 4; k++) { if (k < wv) add += wave_tot[k]; all += wave_tot[k]; }
+    __syncthreads();
+    *total = all;
+    return x + add;
+}
+// Block-local inclusive scan of 1024 elements per 256-thread block.
+__global__ __launch_bounds__(256) void k_scan_block(const uint32_t* n_ptr, const uint32_t* in, uint32_t* out, uint32_t* block_sums) {
+    __shared__ uint32_t wave_tot[4];
+    const size_t n = *n_ptr;
+    size_t base = (size_t)blockIdx.x * 1024 + (size_t)threadIdx.x * 4;
+    if ((size_t)blockIdx.x * 1024 >= n) return;                      // (whole block: the launch covers the host-side bound)
+    uint32_t a[4];
+    for (int k = 0; k < 4; k++) a[k] = (base + k < n) ? in[base + k] : 0u;
+    a[1] += a[0]; a[2] += a[1]; a[3] += a[2];
+    uint32_t tot, incl = block_scan256(a[3], wave_tot, &tot);
+    uint32_t excl = incl - a[3];
     for (int k = 0; k < 4; k++)
         if (base + k < n) out[base + k] = a[k] + excl;
-    if (threadIdx.x == 255) block_sums[blockIdx.x] = x + add;
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
 }
-__global__ void k_scan_sums(size_t nb, uint32_t* block_sums, uint32_t* total) {  // single thread: nb <= 16384
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    uint32_t run = 0;
-    for (size_t b = 0; b < nb; b++) { uint32_t t = block_sums[b]; block_sums[b] = run; run += t; }
-    *total = run;
+// Exclusive scan of the block sums by ONE block of 256 threads (256 sums per trip); the grand total = size of the next level.
+__global__ __launch_bounds__(256) void k_scan_sums(const uint32_t* n_ptr, uint32_t* block_sums, uint32_t* total) {
+    __shared__ uint32_t wave_tot[4];
+    const size_t nb = ((size_t)*n_ptr + 1023) / 1024;
+    uint32_t carry = 0;
+    for (size_t base = 0; base < nb; base += 256) {
+        size_t i = base + threadIdx.x;
+        uint32_t t = i < nb ? block_sums[i] : 0u, tot;
+        uint32_t incl = block_scan256(t, wave_tot, &tot);
+        if (i < nb) block_sums[i] = carry + incl - t;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) *total = carry;
 }
 // pos[i] = parent slot of node i; head[q] = first child of parent q.
-__global__ void k_scan_finish(size_t n, const uint32_t* flag, uint32_t* pos, const uint32_t* block_offs, uint32_t* head) {
+__global__ void k_scan_finish(const uint32_t* n_ptr, const uint32_t* flag, uint32_t* pos, const uint32_t* block_offs, uint32_t* head) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= *n_ptr) return;
     uint32_t p = pos[i] + block_offs[i >> 10] - 1;
     pos[i] = p;
     if (flag[i]) head[p] = (uint32_t)i;
@@ -218,12 +238,13 @@ struct LevelView {
 // the adjacent real node or a padding node made on the spot (Paddable::padding, src/dapol/node.rs:86-88, with the
 // positional seed-mode blinding); parent = Mergeable::merge (node.rs:64-80).
 __global__ __launch_bounds__(256) void k_tree_merge(TableView tbl, LevelView cur, LevelView nxt, const uint32_t* head, int level,
-                                                    const uint32_t* pad_seed /*8 words*/) {
+                                                    const uint32_t* pad_seed /*8 words*/, const uint32_t* cnt /*[levels + 1], device*/) {
     size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nxt.n) return;
+    const size_t cur_n = cnt[level], nxt_n = cnt[level + 1];           // (cur.n / nxt.n are only host-side bounds during the build)
+    if (q >= nxt_n) return;
     size_t i = head[q];
     uint64_t my_idx = cur.idx[i];
-    bool pair = (i + 1 < cur.n) && (cur.idx[i + 1] == (my_idx ^ 1ull));
+    bool pair = (i + 1 < cur_n) && (cur.idx[i + 1] == (my_idx ^ 1ull));
     uint32_t cA[8], hA[8], rA[8], cB[8], hB[8], rB[8];
     uint64_t vA = cur.v[i], vB = 0;
     ge_p3 pA, pB;

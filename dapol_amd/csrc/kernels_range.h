@@ -149,22 +149,22 @@ __device__ __forceinline__ int gen_row(const TableView& t, int n, int j, bool is
 }
 
 // ----------------------------------------------------------------------------------------- wave reductions
-__device__ __forceinline__ void wave_reduce_point(ge_p3& acc, int32_t* lds /*[40][64]*/, int lane, int width) {
+__device__ __forceinline__ void wave_reduce_point(ge_p3& acc, int32_t* lds /*[4 * FE_NL][64]*/, int lane, int width) {
     for (int off = width >> 1; off >= 1; off >>= 1) {
-        for (int i = 0; i < 10; i++) {
+        for (int i = 0; i < FE_NL; i++) {
             lds[(i)*64 + lane] = acc.X.v[i];
-            lds[(10 + i) * 64 + lane] = acc.Y.v[i];
-            lds[(20 + i) * 64 + lane] = acc.Z.v[i];
-            lds[(30 + i) * 64 + lane] = acc.T.v[i];
+            lds[(FE_NL + i) * 64 + lane] = acc.Y.v[i];
+            lds[(2 * FE_NL + i) * 64 + lane] = acc.Z.v[i];
+            lds[(3 * FE_NL + i) * 64 + lane] = acc.T.v[i];
         }
         __syncthreads();
         if ((lane & (width - 1)) < off) {
             ge_p3 o, r;
-            for (int i = 0; i < 10; i++) {
+            for (int i = 0; i < FE_NL; i++) {
                 o.X.v[i] = lds[(i)*64 + lane + off];
-                o.Y.v[i] = lds[(10 + i) * 64 + lane + off];
-                o.Z.v[i] = lds[(20 + i) * 64 + lane + off];
-                o.T.v[i] = lds[(30 + i) * 64 + lane + off];
+                o.Y.v[i] = lds[(FE_NL + i) * 64 + lane + off];
+                o.Z.v[i] = lds[(2 * FE_NL + i) * 64 + lane + off];
+                o.T.v[i] = lds[(3 * FE_NL + i) * 64 + lane + off];
             }
             ge_add(r, acc, o);
             acc = r;
@@ -172,17 +172,14 @@ __device__ __forceinline__ void wave_reduce_point(ge_p3& acc, int32_t* lds /*[40
         __syncthreads();
     }
 }
-__device__ __forceinline__ void wave_reduce_sc(sc& acc, uint32_t* lds /*[8][64]*/, int lane) {
+// Sum of one scalar per lane over the wavefront, by wavefront shuffles (DPP / ds_bpermute; no LDS round trip, no barrier):
+// the inner products <l, r>, c_L = <a_L, b_R>, c_R = <a_R, b_L> of the inner-product argument.  Lane 0 ends with the total.
+__device__ __forceinline__ void wave_reduce_sc(sc& acc) {
     for (int off = 32; off >= 1; off >>= 1) {
-        for (int i = 0; i < 8; i++) lds[i * 64 + lane] = acc.v[i];
-        __syncthreads();
-        if (lane < off) {
-            sc o, r;
-            for (int i = 0; i < 8; i++) o.v[i] = lds[i * 64 + lane + off];
-            sc_add(r, acc, o);
-            acc = r;
-        }
-        __syncthreads();
+        sc o, r;
+        for (int i = 0; i < 8; i++) o.v[i] = (uint32_t)__shfl_down((int)acc.v[i], off, 64);
+        sc_add(r, acc, o);
+        acc = r;
     }
 }
 
@@ -204,7 +201,7 @@ __global__ __launch_bounds__(64) void k_rp_nonces(RangeArgs A) {
 
 // ------------------------------------------------------------------------- K1: A = sum_i (bit ? G_i : -H_i)
 __global__ __launch_bounds__(64) void k_rp_A(RangeArgs A, TableView tbl) {
-    __shared__ int32_t lds[40 * 64];
+    __shared__ int32_t lds[4 * FE_NL * 64];
     size_t b = blockIdx.x;
     int l = threadIdx.x;
     ge_p3 acc;
@@ -233,7 +230,7 @@ __global__ __launch_bounds__(64, DAPOL_MSM_OCC) void k_rp_msm(RangeArgs A, Table
     // at LPL = 32) over more mixed adds.  The digit layout is the same for every LPL.
     // MODE: MSM_PLAIN -> P0 / P1;  MSM_MATERIALIZE -> the 64 per-lane sums are kept (folded generators; T / 32 blocks
     // per proof, block c taking every (T/32)-th term);  MSM_TAIL -> the table is the PROOF's own (2N rows).
-    __shared__ int32_t lds[40 * 64];
+    __shared__ int32_t lds[4 * FE_NL * 64];
     constexpr int PPW = 32 / LPL;
     int l = threadIdx.x;
     int sub = l / (2 * LPL), ll = l % (2 * LPL), side = ll / LPL, ql = ll % LPL;
@@ -324,7 +321,7 @@ __device__ __forceinline__ void build_niels_row(int32_t* row) {
     for (int e = 1; e < ENTRIES; e++) {
         if (e > 1) { ge_p3 t; ge_add(t, mul, base); mul = t; }
         int32_t* slot = row + e * 32;
-        for (int i = 0; i < 10; i++) { slot[i] = mul.X.v[i]; slot[10 + i] = mul.Y.v[i]; slot[20 + i] = mul.Z.v[i]; }
+        for (int i = 0; i < FE_NL; i++) { slot[i] = mul.X.v[i]; slot[FE_NL + i] = mul.Y.v[i]; slot[2 * FE_NL + i] = mul.Z.v[i]; }
         if (e == 1) pre[0] = mul.Z;
         else fe_mul(pre[e - 1], pre[e - 2], mul.Z);
     }
@@ -334,20 +331,18 @@ __device__ __forceinline__ void build_niels_row(int32_t* row) {
     for (int e = ENTRIES - 1; e >= 1; e--) {
         int32_t* slot = row + e * 32;
         fe X, Y, Z, zi, x, y;
-        for (int i = 0; i < 10; i++) { X.v[i] = slot[i]; Y.v[i] = slot[10 + i]; Z.v[i] = slot[20 + i]; }
+        for (int i = 0; i < FE_NL; i++) { X.v[i] = slot[i]; Y.v[i] = slot[FE_NL + i]; Z.v[i] = slot[2 * FE_NL + i]; }
         if (e > 1) { fe_mul(zi, inv, pre[e - 2]); fe t; fe_mul(t, inv, Z); inv = t; }
         else zi = inv;
         fe_mul(x, X, zi);
         fe_mul(y, Y, zi);
         ge_niels q;
         ge_to_niels(q, x, y);
-        for (int i = 0; i < 10; i++) { slot[i] = q.ypx.v[i]; slot[10 + i] = q.ymx.v[i]; slot[20 + i] = q.xy2d.v[i]; }
-        slot[30] = 0; slot[31] = 0;
+        niels_store_entry(slot, q);
     }
     ge_niels id;
     ge_niels_identity(id);
-    for (int i = 0; i < 10; i++) { row[i] = id.ypx.v[i]; row[10 + i] = id.ymx.v[i]; row[20 + i] = id.xy2d.v[i]; }
-    row[30] = 0; row[31] = 0;
+    niels_store_entry(row, id);
 }
 
 // One lane per materialised generator: its table row, and the tail argument's vectors: a, b = the first T entries of the
@@ -450,7 +445,6 @@ __global__ __launch_bounds__(64) void k_rp_finish1(RangeArgs A, TableView tbl) {
 // ------------------------------------------------- K3: l0, l1, r0, r1 and t1, t2 (wave per proof)
 // Party::apply_challenge_with_rng restated over the concatenated vectors: position i = (party j, bit ii).
 __global__ __launch_bounds__(64) void k_rp_poly(RangeArgs A) {
-    __shared__ uint32_t lds[8 * 64];
     size_t b = blockIdx.x;
     int l = threadIdx.x;
     const ProofState& ps = A.st[b];
@@ -485,8 +479,8 @@ __global__ __launch_bounds__(64) void k_rp_poly(RangeArgs A) {
         st_sc(A.s2 + b * A.N + i, r1);
         sc_montmul(yi, yi, y64);
     }
-    wave_reduce_sc(t1, lds, l);
-    wave_reduce_sc(t2, lds, l);
+    wave_reduce_sc(t1);
+    wave_reduce_sc(t2);
     if (l == 0) { A.st[b].t1 = t1; A.st[b].t2 = t2; }
 }
 
@@ -535,7 +529,6 @@ __global__ __launch_bounds__(64) void k_rp_finish2(RangeArgs A, TableView tbl) {
 
 // ------------------------------------- K4: l = l0 + l1 x, r = r0 + r1 x, t_x = <l, r>, s-vector init (wave/proof)
 __global__ __launch_bounds__(64) void k_rp_lr(RangeArgs A) {
-    __shared__ uint32_t lds[8 * 64];
     size_t b = blockIdx.x;
     int l = threadIdx.x;
     const ProofState& ps = A.st[b];
@@ -564,7 +557,7 @@ __global__ __launch_bounds__(64) void k_rp_lr(RangeArgs A) {
         st_sc(A.s2 + b * A.N + i, yi);           // s_H[i] = y^-i   (H' = y^-i H, folded into the scalar)
         sc_montmul(yi, yi, y64);
     }
-    wave_reduce_sc(tx, lds, l);
+    wave_reduce_sc(tx);
     if (l == 0) A.st[b].t_x = tx;
 }
 
@@ -633,7 +626,6 @@ __global__ __launch_bounds__(64) void k_rp_round_prep(RangeArgs A, int round) {
 }
 // c_L = <a_L, b_R>, c_R = <a_R, b_L>  (wave per proof)
 __global__ __launch_bounds__(64) void k_rp_round_ip(RangeArgs A, int round) {
-    __shared__ uint32_t lds[8 * 64];
     size_t b = blockIdx.x;
     int l = threadIdx.x, half = 1 << (A.lgN - 1 - round);
     sc cL, cR;
@@ -650,8 +642,8 @@ __global__ __launch_bounds__(64) void k_rp_round_ip(RangeArgs A, int round) {
         sc_montmul(t, aR, bL);
         sc_add(cR, cR, t);
     }
-    wave_reduce_sc(cL, lds, l);
-    wave_reduce_sc(cR, lds, l);
+    wave_reduce_sc(cL);
+    wave_reduce_sc(cR);
     if (l == 0) { A.st[b].cL = cL; A.st[b].cR = cR; }
 }
 

@@ -464,7 +464,7 @@ __device__ __forceinline__ void ge_scalarmul_vartime(ge_p3& out, const ge_p3& p,
     out = acc;
 }
 __global__ __launch_bounds__(64) void k_rv_varpoints(VerifyArgs V) {
-    __shared__ int32_t lds[40 * 64];
+    __shared__ int32_t lds[4 * FE_NL * 64];
     const RangeArgs& A = V.R;
     size_t b = blockIdx.x;
     int l = threadIdx.x;
@@ -663,7 +663,6 @@ __global__ __launch_bounds__(64) void k_rvb_tables2(RlcArgs R) {
 }
 // Sum of rho z over the proofs of a group (one wavefront per group) -- the constant term of every generator scalar.
 __global__ __launch_bounds__(64) void k_rvb_rzsum(RlcArgs R) {
-    __shared__ uint32_t lw[8 * 64];
     const VerifyArgs& V = R.V;
     const RangeArgs& A = V.R;
     const int g = blockIdx.x, l = threadIdx.x;
@@ -674,7 +673,7 @@ __global__ __launch_bounds__(64) void k_rvb_rzsum(RlcArgs R) {
         ld_sc(x, V.tabs + p * (size_t)V.tab_stride + o_rz);
         sc_add(acc, acc, x);
     }
-    wave_reduce_sc(acc, lw, l);
+    wave_reduce_sc(acc);
     if (l == 0) st_sc(R.rzg + g, acc);
 }
 // The sums of k_rvb_gh_partial with the reduction taken out of the loop: the operands wait as 29-bit limbs, a trip is the
@@ -855,7 +854,9 @@ __global__ __launch_bounds__(64) void k_rvp_decode(RlcArgs R) {
     fe_carry(b2, b2);
     fe_mul(c2, pt.T, FE_D2);
     int32_t* o = R.pN + t * 32;
-    for (int i = 0; i < 10; i++) { o[i] = a.v[i]; o[10 + i] = b2.v[i]; o[20 + i] = c2.v[i]; }
+    ge_niels qn;
+    qn.ypx = a; qn.ymx = b2; qn.xy2d = c2;
+    niels_store_entry(o, qn);
     o[30] = good ? 0 : 1;
 }
 // Scalars -> digits + histogram (lane per point), after the replay.  A point that did not decode sends the chunk to the
@@ -913,7 +914,7 @@ __global__ __launch_bounds__(64) void k_rvp_scatter(RlcArgs R) {
 }
 // Bucket sums: RVP_S adjacent lanes share a bucket (every RVP_S-th point each), then a tree reduction.  grid = NW * NB * S / 64.
 __global__ __launch_bounds__(64) void k_rvp_buckets(RlcArgs R) {
-    __shared__ int32_t lds[40 * 64];
+    __shared__ int32_t lds[4 * FE_NL * 64];
     const int l = threadIdx.x;
     const size_t gid = (size_t)blockIdx.x * 64 + l;
     const int s = (int)(gid % RVP_S), bidx = (int)((gid / RVP_S) % RVP_NB), w = (int)(gid / ((size_t)RVP_S * RVP_NB));
@@ -923,16 +924,8 @@ __global__ __launch_bounds__(64) void k_rvp_buckets(RlcArgs R) {
     ge_identity(acc);
     for (uint32_t i = s; i < n; i += RVP_S) {
         uint32_t e = srt[i];
-        const int4* q4 = reinterpret_cast<const int4*>(R.pN + (size_t)(e & 0x7fffffffu) * 32);
-        int4 a0 = q4[0], a1 = q4[1], a2 = q4[2], a3 = q4[3], a4 = q4[4], a5 = q4[5], a6 = q4[6], a7 = q4[7];
-        ge_niels q;                                               // stored as ypx[10] ymx[10] xy2d[10]
-        q.ypx.v[0] = a0.x; q.ypx.v[1] = a0.y; q.ypx.v[2] = a0.z; q.ypx.v[3] = a0.w; q.ypx.v[4] = a1.x; q.ypx.v[5] = a1.y;
-        q.ypx.v[6] = a1.z; q.ypx.v[7] = a1.w; q.ypx.v[8] = a2.x; q.ypx.v[9] = a2.y;
-        q.ymx.v[0] = a2.z; q.ymx.v[1] = a2.w; q.ymx.v[2] = a3.x; q.ymx.v[3] = a3.y; q.ymx.v[4] = a3.z; q.ymx.v[5] = a3.w;
-        q.ymx.v[6] = a4.x; q.ymx.v[7] = a4.y; q.ymx.v[8] = a4.z; q.ymx.v[9] = a4.w;
-        q.xy2d.v[0] = a5.x; q.xy2d.v[1] = a5.y; q.xy2d.v[2] = a5.z; q.xy2d.v[3] = a5.w; q.xy2d.v[4] = a6.x; q.xy2d.v[5] = a6.y;
-        q.xy2d.v[6] = a6.z; q.xy2d.v[7] = a6.w; q.xy2d.v[8] = a7.x; q.xy2d.v[9] = a7.y;
-        (void)a7;
+        ge_niels q;
+        niels_load_entry(q, R.pN + (size_t)(e & 0x7fffffffu) * 32);
         ge_madd(acc, acc, q, (e >> 31) != 0);
     }
     wave_reduce_point(acc, lds, l, RVP_S);
@@ -941,7 +934,7 @@ __global__ __launch_bounds__(64) void k_rvp_buckets(RlcArgs R) {
 // Window sums: W_w = sum_k k B_k, scaled by 2^(C w), into Q0[w] (Q1[w] = identity) for k_rvb_finish.  One wavefront per
 // window: lane l owns the L = NB / 64 buckets of weights l L + 1 .. l L + L.
 __global__ __launch_bounds__(64) void k_rvp_window(RlcArgs R) {
-    __shared__ int32_t lds[40 * 64];
+    __shared__ int32_t lds[4 * FE_NL * 64];
     const int w = blockIdx.x, l = threadIdx.x, L = RVP_NB / 64;
     ge_p3 run, aseg, b, t;
     ge_identity(run);
@@ -973,7 +966,7 @@ __global__ __launch_bounds__(64) void k_rvp_window(RlcArgs R) {
 }
 // Sums everything and tests for the identity (one wavefront).
 __global__ __launch_bounds__(64) void k_rvb_finish(RlcArgs R, TableView tbl) {
-    __shared__ int32_t lds[40 * 64];
+    __shared__ int32_t lds[4 * FE_NL * 64];
     const RangeArgs& A = R.V.R;
     int l = threadIdx.x;
     const int ns1 = A.nsplit > 1 ? A.nsplit : 1;
@@ -993,9 +986,8 @@ __global__ __launch_bounds__(64) void k_rvb_finish(RlcArgs R, TableView tbl) {
         ld_sc(x, R.bsum + 2 * i); sc_add(bb, bb, x);
         ld_sc(x, R.bsum + 2 * i + 1); sc_add(bs, bs, x);
     }
-    uint32_t* lw = reinterpret_cast<uint32_t*>(lds);
-    wave_reduce_sc(bb, lw, l);
-    wave_reduce_sc(bs, lw, l);
+    wave_reduce_sc(bb);
+    wave_reduce_sc(bs);
     if (l == 0) {
         uint32_t k8[8], c8[8];
         sc_from_mont(k8, bb);

@@ -2,7 +2,7 @@
 //
 // Layout (W-bit signed windows): a ROW holds the 2^(W-1)+1 multiples k*P, k = 0..2^(W-1), of one
 // base point P as 128-byte entries
-// (affine niels form: y+x, y-x, 2dxy as 3 x 10 int32 limbs, 2 words of padding -> eight 16-byte loads per lookup,
+// (affine niels form: y+x, y-x, 2dxy as 3 x 9 int32 limbs, 5 words of padding -> seven 16-byte loads per lookup,
 // one cache line).  Entry 0 is the identity so a zero digit needs no branch; digits are signed (-128..128).
 //   rows [0, 64*P)            G[party][bit]      (P = max_parties)       bulletproofs BulletproofGens G chain
 //   rows [64*P, 128*P)        H[party][bit]                              ... H chain
@@ -45,20 +45,29 @@ struct TableView {
 };
 
 #if defined(__HIPCC__)
+// A 128-byte entry holds ypx | ymx | xy2d as 3 x FE_NL = 27 limbs (words 0..26); words 27..31 are padding (word 30 doubles
+// as a flag in the verifier's decoded-point arrays).  Seven 16-byte loads fetch it.
+__host__ __device__ __forceinline__ void niels_store_entry(int32_t* e, const ge_niels& q) {
+    for (int i = 0; i < FE_NL; i++) { e[i] = q.ypx.v[i]; e[FE_NL + i] = q.ymx.v[i]; e[2 * FE_NL + i] = q.xy2d.v[i]; }
+    for (int i = 3 * FE_NL; i < TBL_ENTRY_WORDS; i++) e[i] = 0;
+}
+__device__ __forceinline__ void niels_load_entry(ge_niels& q, const int32_t* e) {
+    const int4* p = reinterpret_cast<const int4*>(e);
+    int4 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3], a4 = p[4], a5 = p[5], a6 = p[6];
+    q.ypx.v[0] = a0.x; q.ypx.v[1] = a0.y; q.ypx.v[2] = a0.z; q.ypx.v[3] = a0.w;
+    q.ypx.v[4] = a1.x; q.ypx.v[5] = a1.y; q.ypx.v[6] = a1.z; q.ypx.v[7] = a1.w;
+    q.ypx.v[8] = a2.x;
+    q.ymx.v[0] = a2.y; q.ymx.v[1] = a2.z; q.ymx.v[2] = a2.w;
+    q.ymx.v[3] = a3.x; q.ymx.v[4] = a3.y; q.ymx.v[5] = a3.z; q.ymx.v[6] = a3.w;
+    q.ymx.v[7] = a4.x; q.ymx.v[8] = a4.y;
+    q.xy2d.v[0] = a4.z; q.xy2d.v[1] = a4.w;
+    q.xy2d.v[2] = a5.x; q.xy2d.v[3] = a5.y; q.xy2d.v[4] = a5.z; q.xy2d.v[5] = a5.w;
+    q.xy2d.v[6] = a6.x; q.xy2d.v[7] = a6.y; q.xy2d.v[8] = a6.z;
+}
 // Load entry |d| of `row`; the sign is applied by ge_madd.
 __device__ __forceinline__ void tbl_load(ge_niels& q, const TableView& t, int row, int absd) {
     // one 64-bit multiply-add for the entry's word offset (row and |d| are non-negative; the offset stays below 2^40)
-    const int4* p = reinterpret_cast<const int4*>(t.base + ((uint64_t)(uint32_t)row * (uint32_t)t.row_words() + (uint32_t)(absd * TBL_ENTRY_WORDS)));
-    int4 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3], a4 = p[4], a5 = p[5], a6 = p[6], a7 = p[7];
-    q.ypx.v[0] = a0.x; q.ypx.v[1] = a0.y; q.ypx.v[2] = a0.z; q.ypx.v[3] = a0.w;
-    q.ypx.v[4] = a1.x; q.ypx.v[5] = a1.y; q.ypx.v[6] = a1.z; q.ypx.v[7] = a1.w;
-    q.ypx.v[8] = a2.x; q.ypx.v[9] = a2.y;
-    q.ymx.v[0] = a2.z; q.ymx.v[1] = a2.w;
-    q.ymx.v[2] = a3.x; q.ymx.v[3] = a3.y; q.ymx.v[4] = a3.z; q.ymx.v[5] = a3.w;
-    q.ymx.v[6] = a4.x; q.ymx.v[7] = a4.y; q.ymx.v[8] = a4.z; q.ymx.v[9] = a4.w;
-    q.xy2d.v[0] = a5.x; q.xy2d.v[1] = a5.y; q.xy2d.v[2] = a5.z; q.xy2d.v[3] = a5.w;
-    q.xy2d.v[4] = a6.x; q.xy2d.v[5] = a6.y; q.xy2d.v[6] = a6.z; q.xy2d.v[7] = a6.w;
-    q.xy2d.v[8] = a7.x; q.xy2d.v[9] = a7.y;
+    niels_load_entry(q, t.base + ((uint64_t)(uint32_t)row * (uint32_t)t.row_words() + (uint32_t)(absd * TBL_ENTRY_WORDS)));
 }
 
 // acc += d * (row's base point), d in [-128, 128]

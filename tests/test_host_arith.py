@@ -12,7 +12,8 @@ def buf(n):
 def test_field_ops(host_shim, pyref):
     P = pyref.P
     rnd = random.Random(1)
-    edge = [0, 1, 2, P - 1, P - 2, 2**255 - 20, 2**254, 19, 2**26 - 1, 2**255 - 19 - 2**26]
+    edge = [0, 1, 2, P - 1, P - 2, 2**255 - 20, 2**254, 19, 2**26 - 1, 2**255 - 19 - 2**26, 2**29 - 1, 2**29, 2**232 - 1, 2**232,
+            2**255 - 19 - 2**29, sum((2**29 - 1) << (29 * i) for i in range(8)) + ((2**23 - 1) << 232) - 19, 2**255 - 1 - 19, 2**58 - 1, 2**261 % P]
 
     def op(k, a, b):
         o = buf(32)

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(64, 3) void k(int32_t* out, const int32_t* in, int 
     ge_p3 acc;
     ge_niels q;
     const int32_t* p = in + threadIdx.x * 70;
-    for (int i = 0; i < 10; i++) {
+    for (int i = 0; i < FE_NL; i++) {
         acc.X.v[i] = p[i]; acc.Y.v[i] = p[10 + i]; acc.Z.v[i] = p[20 + i]; acc.T.v[i] = p[30 + i];
         q.ypx.v[i] = p[40 + i]; q.ymx.v[i] = p[50 + i]; q.xy2d.v[i] = p[60 + i];
     }
@@ -30,7 +30,7 @@ __global__ __launch_bounds__(64, 3) void k(int32_t* out, const int32_t* in, int 
     }
     if (blockIdx.x == 100 && threadIdx.x == 0) { clk[0] = clock64() - c0; clk[1] = wall_clock64() - w0; }   // shader clocks vs 100 MHz ticks
     int32_t* o = out + ((size_t)blockIdx.x * 64 + threadIdx.x) * 40;
-    for (int i = 0; i < 10; i++) { o[i] = acc.X.v[i]; o[10 + i] = acc.Y.v[i]; o[20 + i] = acc.Z.v[i]; o[30 + i] = acc.T.v[i]; }
+    for (int i = 0; i < FE_NL; i++) { o[i] = acc.X.v[i]; o[10 + i] = acc.Y.v[i]; o[20 + i] = acc.Z.v[i]; o[30 + i] = acc.T.v[i]; }
 }
 
 template <int OP> int run(const char* name, int32_t* d_out, const int32_t* d_in, int blocks, int iters) {
@@ -58,7 +58,7 @@ int main() {
     int32_t h_in[64 * 70];
     // the basepoint in extended form and its niels form would do; any reduced limbs exercise the same instructions
     for (int t = 0; t < 64; t++)
-        for (int i = 0; i < 70; i++) h_in[t * 70 + i] = (int32_t)(((uint32_t)(t * 2654435761u + i * 40503u + 12345u)) & ((i & 1) ? 0x1ffffff : 0x3ffffff));
+        for (int i = 0; i < 70; i++) h_in[t * 70 + i] = (int32_t)(((uint32_t)(t * 2654435761u + i * 40503u + 12345u)) & ((i % 10) == 8 ? 0x7fffff : 0x1fffffff));     // reduced 29-bit limbs (23 bits in limb 8)
     int32_t *d_in, *d_out;
     CHECK(hipMalloc(&d_in, sizeof(h_in))); CHECK(hipMemcpy(d_in, h_in, sizeof(h_in), hipMemcpyHostToDevice));
     CHECK(hipMalloc(&d_out, (size_t)blocks * 64 * 40 * 4));
