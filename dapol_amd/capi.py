@@ -73,6 +73,11 @@ _SIG = {
     "dapol_workload_destroy": (ctypes.c_int32, [_P]),
     "dapol_workload_run": (ctypes.c_int32, [_P, _P, _P, ctypes.c_int32, ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(WorkloadStats)]),
     "dapol_workload_proofs": (ctypes.c_int32, [_P, ctypes.c_size_t, ctypes.c_size_t, _P]),
+    "dapol_tree_node_records": (ctypes.c_int32, [_P, ctypes.c_size_t, _P, _P, _P, _P, _P, _P, _P]),
+    "dapol_shard_top_node_records": (ctypes.c_int32, [_P, ctypes.c_int32, _P, ctypes.c_size_t, _P, _P, _P, _P, _P, _P]),
+    "dapol_prove_batch_records": (ctypes.c_int32, [_P, ctypes.c_size_t, _P, ctypes.c_size_t, _P, _P, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                                   _P, _P]),
+    "dapol_workload_tree": (ctypes.c_int32, [_P, ctypes.POINTER(_P)]),
     "dapol_comm_unique_id": (ctypes.c_int32, [_P]),
     "dapol_comm_create": (ctypes.c_int32, [_P, _P, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(_P)]),
     "dapol_comm_destroy": (ctypes.c_int32, [_P]),
@@ -413,6 +418,41 @@ class Comm:
         return w
 
 
+def tree_node_records(tree_handle, level, index):
+    """Records (C, H, v, r, found) of the nodes a (shard) tree stores at the given (level above the leaves, index) positions."""
+    level, index = _u8(level), _u64(index)
+    n = index.shape[0]
+    C, H, r = (np.zeros((max(n, 1), 32), np.uint8) for _ in range(3))
+    v, found = np.zeros(max(n, 1), np.uint64), np.zeros(max(n, 1), np.uint8)
+    _chk(lib().dapol_tree_node_records(tree_handle, n, _ptr(level), _ptr(index), _ptr(C), _ptr(H), _ptr(v), _ptr(r), _ptr(found)))
+    return C[:n], H[:n], v[:n], r[:n], found[:n]
+
+
+def shard_top_node_records(ctx, records, level_above, index):
+    rec = _u8(records).reshape(-1, RECORD_BYTES)
+    level_above, index = _u8(level_above), _u64(index)
+    n = index.shape[0]
+    C, H, r = (np.zeros((max(n, 1), 32), np.uint8) for _ in range(3))
+    v = np.zeros(max(n, 1), np.uint64)
+    _chk(lib().dapol_shard_top_node_records(ctx.h, rec.shape[0], _ptr(rec), n, _ptr(level_above), _ptr(index), _ptr(C), _ptr(H), _ptr(v), _ptr(r)))
+    return C[:n], H[:n], v[:n], r[:n]
+
+
+def prove_batch_records(ctx, leaf_idx, sib_C, sib_v, sib_r, policy, aggregation_factor, n_bits, nonce_seed):
+    """R::generate_proof over assembled sibling records (dapol_batch_siblings order): the range-proof blob."""
+    leaf_idx = _u64(leaf_idx)
+    sC, sr, sv = _u8(sib_C).reshape(-1, 32), _u8(sib_r).reshape(-1, 32), _u64(sib_v)
+    S = sC.shape[0]
+    es = lib().dapol_entity_proof_size(S, policy, aggregation_factor, n_bits)
+    if es == 0:
+        raise DapolError(8, "bad policy / aggregation_factor / n_bits")
+    out = np.zeros(es, np.uint8)
+    seed = _u8(np.frombuffer(nonce_seed, np.uint8))
+    _chk(lib().dapol_prove_batch_records(ctx.h, leaf_idx.shape[0], _ptr(leaf_idx), S, _ptr(sC), _ptr(sv), _ptr(sr), policy, aggregation_factor, n_bits,
+                                         _ptr(seed), _ptr(out)))
+    return out.tobytes()
+
+
 def shard_top_levels(ctx, records, rank):
     """The merge half of the exchange for records gathered by other means: records [world][104]."""
     rec = _u8(records).reshape(-1, RECORD_BYTES)
@@ -563,6 +603,12 @@ class Workload:
     def run(self, pad_seed, nonce_seed, n_bits=64, first=0, count=None):
         _, st = self.build(pad_seed)
         return self.prove(nonce_seed, n_bits, first, count, stats=st)
+
+    def tree_handle(self):
+        """The (sub)tree of the last build, borrowed (for tree_node_records)."""
+        h = _P()
+        _chk(lib().dapol_workload_tree(self.h, ctypes.byref(h)))
+        return h
 
     def paths(self, leaf_idx, upper=None, with_nodes=False):
         """Siblings of sampled leaves of the last build: (v, r) and, with_nodes, also the proof nodes (C, H)."""

@@ -143,3 +143,28 @@ class ShardedProver:
         for k, p in enumerate(pos):
             out[k] = self.w.proofs(int(p), 1, proof_size)[0]
         return out
+
+
+def assemble_batch_records(height, shard_bits, leaves, shard_lookups, records, ctx):
+    """Sibling records of a batched proof over a sharded tree, in dapol_batch_siblings order.
+    shard_lookups[g](level, index) -> (C, H, v, r, found) for the positions inside shard g (dapol_tree_node_records on that
+    rank's tree; on a real multi-GPU run the rows come back through an all-gather); records = the exchanged [G][104]
+    subtree-root records, used for the positions at and above the shard roots (dapol_shard_top_node_records)."""
+    level, index = capi.batch_siblings(height, leaves)
+    S = len(level)
+    C, H, r = (np.zeros((S, 32), np.uint8) for _ in range(3))
+    v = np.zeros(S, np.uint64)
+    local_h = height - shard_bits
+    top = np.nonzero(level >= local_h)[0]
+    if len(top):
+        tC, tH, tv, tr = capi.shard_top_node_records(ctx, records, level[top] - local_h, index[top])
+        C[top], H[top], v[top], r[top] = tC, tH, tv, tr
+    low = np.nonzero(level < local_h)[0]
+    owner = (index[low] >> (local_h - level[low]).astype(np.uint64)).astype(np.int64)
+    for g in sorted(set(owner.tolist())):
+        sel = low[owner == g]
+        gC, gH, gv, gr, found = shard_lookups[g](level[sel], index[sel])
+        if not found.all():
+            raise capi.DapolError(9, "shard %d does not hold a sibling of the batch" % g)
+        C[sel], H[sel], v[sel], r[sel] = gC, gH, gv, gr
+    return level, index, C, H, v, r

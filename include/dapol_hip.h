@@ -289,6 +289,25 @@ int32_t dapol_shard_top_levels(dapol_ctx* ctx, int32_t world, int32_t rank, cons
                                uint64_t* root_v, uint8_t root_r[32], uint8_t* up_C32, uint8_t* up_H32, uint64_t* up_v, uint8_t* up_r32);
 int32_t dapol_comm_allreduce_u64(dapol_comm* comm, int32_t op, uint64_t* inout, size_t n);
 
+/* generate_proof_batch (src/dapol/mod.rs:172-190) on a SHARDED tree.  The siblings of a batch lie in several shards and in
+ * the replicated top levels, so the proof is assembled from node RECORDS (C, H, v, r):
+ *   dapol_batch_siblings            the positions (level above the leaves, index) of the proof's siblings;
+ *   dapol_tree_node_records         this rank's records among them: the real or padding node a (shard) tree stores at each
+ *                                   position, found[i] = 0 where the tree holds none (another shard's, or above the shard root);
+ *   dapol_shard_top_node_records    the nodes at and above the shard roots (level_above = 0 .. log2 G), from the G exchanged
+ *                                   subtree-root records;
+ *   dapol_prove_batch_records       R::generate_proof over the assembled siblings, in dapol_batch_siblings' order.
+ * Between the second and the last step the ranks exchange their 104-byte rows by any transport.  The result equals
+ * dapol_prove_batch on the unsharded tree byte for byte.  dapol_workload_tree lends a workload's current (sub)tree to these
+ * calls (valid until the workload's next build / destroy; do not destroy it). */
+int32_t dapol_tree_node_records(dapol_tree* tree, size_t n, const uint8_t* level, const uint64_t* index, uint8_t* C32, uint8_t* H32,
+                                uint64_t* v, uint8_t* r32, uint8_t* found);
+int32_t dapol_shard_top_node_records(dapol_ctx* ctx, int32_t world, const uint8_t* records, size_t n, const uint8_t* level_above,
+                                     const uint64_t* index, uint8_t* C32, uint8_t* H32, uint64_t* v, uint8_t* r32);
+int32_t dapol_prove_batch_records(dapol_ctx* ctx, size_t k, const uint64_t* leaf_idx, size_t n_siblings, const uint8_t* sib_C32,
+                                  const uint64_t* sib_v, const uint8_t* sib_r32, int32_t policy, int32_t aggregation_factor,
+                                  int32_t n_bits, const uint8_t nonce_seed32[32], uint8_t* range_out);
+
 /* Bench / roofline support: device-resident variant of build + prove-all used by bench.py so that the timed
  * region starts with inputs already in HBM and nothing is copied back.  Handles are opaque device buffers. */
 typedef struct dapol_workload dapol_workload;
@@ -298,6 +317,7 @@ int32_t dapol_workload_create(dapol_ctx* ctx, int32_t height, size_t n, const ui
 int32_t dapol_workload_create_shard(dapol_ctx* ctx, int32_t total_height, int32_t shard_bits, size_t n, const uint64_t* leaf_idx,
                                     const uint64_t* v, const uint8_t* r32, dapol_workload** out);
 int32_t dapol_workload_destroy(dapol_workload* w);
+int32_t dapol_workload_tree(dapol_workload* w, dapol_tree** out);    /* borrowed: the tree of the last dapol_workload_build */
 /* One pass: tree build + one padding-policy inclusion range proof per entity (aggregation_factor = height).
  * Returns device time of the two phases in milliseconds (HIP events on the ctx stream), the time and launch
  * count of the dominant kernel (the fixed-base MSM), and a 64-bit checksum of all proof bytes + the root. */

@@ -947,7 +947,7 @@ def test_every_proving_strategy_gives_the_same_bytes(gpu_ctx, n_bits, m):
     sid = np.arange(b, dtype=np.uint64)
     base = gpu_ctx.range_prove_batch(n_bits, m, v, r, nonce_seed=SEED, stream_id=sid).tobytes()
     for env in ({"DAPOL_NO_TAIL": "1"}, {"DAPOL_TAIL_N": "32"}, {"DAPOL_TAIL_N": "128"}, {"DAPOL_TAIL_LPL": "4"}, {"DAPOL_TAIL_LPL": "1"},
-                {"DAPOL_LPL": "32"}, {"DAPOL_LPL": "4"}, {"DAPOL_CHUNK": "64"}, {"DAPOL_TAIL_N": "256", "DAPOL_LPL": "16"},
+                {"DAPOL_LPL": "32"}, {"DAPOL_LPL": "4"}, {"DAPOL_LPL": "2"}, {"DAPOL_LPL": "2", "DAPOL_MSM_OCC_CAP": "3"}, {"DAPOL_CHUNK": "64"}, {"DAPOL_TAIL_N": "256", "DAPOL_LPL": "16"},
                 {"DAPOL_CHUNK": "8"}, {"DAPOL_CHUNK": "5", "DAPOL_STREAMS": "4"}, {"DAPOL_CHUNK": "16", "DAPOL_STREAMS": "1"},
                 {"DAPOL_CHUNK": "36", "DAPOL_STREAMS": "3"}, {"DAPOL_NO_SPLIT": "1"}, {"DAPOL_NO_SPLIT": "1", "DAPOL_TAIL_LPL": "32"}):
         os.environ.update(env)
@@ -1263,3 +1263,47 @@ def test_rccl_exchange_one_rank_and_top_levels(gpu_ctx, hip_lib):
     with pytest.raises(hip_lib.DapolError) as e:
         hip_lib.Comm(gpu_ctx, bytes(128), 0, 3)
     assert e.value.code == 8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("policy,agg", [(0, None), (1, 3), (0, 0)])
+def test_batch_proof_on_a_sharded_tree(gpu_ctx, hip_lib, policy, agg):
+    """generate_proof_batch (src/dapol/mod.rs:172-190) over a tree split into 4 top-level shards (one of them empty): sibling
+    records gathered per shard (dapol_tree_node_records), top nodes from the exchanged root records
+    (dapol_shard_top_node_records), proof by dapol_prove_batch_records -- siblings and range-proof bytes equal
+    dapol_prove_batch on the unsharded tree, and the batch verifies."""
+    from dapol_amd import sharded
+    height, sb, n_bits = 8, 2, 16
+    rng = np.random.default_rng(42)
+    local = 1 << (height - sb)
+    idx = np.sort(np.concatenate([rng.choice(local, size=5, replace=False).astype(np.uint64) + np.uint64(s * local) for s in (0, 1, 3)]))
+    v = rng.integers(0, 1000, size=len(idx), dtype=np.uint64)
+    r = rng.integers(0, 256, size=(len(idx), 32), dtype=np.uint8)
+    r[:, 31] &= 0x0F
+    full = hip_lib.Tree(gpu_ctx, height, idx, v, r, SEED)
+    leaves = idx[[0, 3, 6, 7, 12]]                                   # leaves of shards 0, 1 and 3
+    flevel, findex, fC, fH, fblob = full.prove_batch(leaves, policy, len(hip_lib.batch_siblings(height, leaves)[0]) if agg is None else agg, n_bits, SEED)
+    trees, recs = {}, []
+    for s in range(4):
+        sel = (idx >> np.uint64(height - sb)) == s
+        if sel.any():
+            trees[s] = hip_lib.Tree(gpu_ctx, height, idx[sel], v[sel], r[sel], SEED, shard_bits=sb)
+            recs.append(sharded.pack_record(trees[s].root()))
+        else:
+            C, H, rr = gpu_ctx.padding_nodes(SEED, [height - sb], [s])
+            recs.append(sharded.pack_record((C[0].tobytes(), H[0].tobytes(), 0, rr[0].tobytes())))
+    records = np.stack(recs)
+    lookups = {s: (lambda lv, ix, t=t: hip_lib.tree_node_records(t.h, lv, ix)) for s, t in trees.items()}
+    level, index, C, H, sv, sr = sharded.assemble_batch_records(height, sb, leaves, lookups, records, gpu_ctx)
+    assert level.tolist() == flevel.tolist() and index.tolist() == findex.tolist()
+    assert C.tobytes() == fC.tobytes() and H.tobytes() == fH.tobytes()
+    a = len(level) if agg is None else agg
+    blob = hip_lib.prove_batch_records(gpu_ctx, leaves, C, sv, sr, policy, a, n_bits, SEED)
+    assert blob == fblob
+    pos = np.searchsorted(idx, leaves)
+    lC, lH = gpu_ctx.commit_hash_batch(v[pos], r[pos])
+    rC, rH, _, _ = full.root()
+    assert gpu_ctx.verify_batch(height, leaves, lC, lH, C, H, rC, rH, policy, a, n_bits, blob)
+    # a position no shard tree holds is reported, not invented
+    _, _, _, _, found = hip_lib.tree_node_records(trees[0].h, [0, 0, height - sb], [int(idx[0]), int(idx[-1]), 0])
+    assert found.tolist() == [1, 0, 1]

@@ -18,6 +18,8 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
 
 def load(d):
     cc = glob.glob(os.path.join(d, "*counter_collection.csv"))
@@ -72,6 +74,11 @@ def main():
         out["cycles_per_valu_inst_per_simd"] = (c["GRBM_GUI_ACTIVE"] / 8) / (c["SQ_INSTS_VALU"] / 1024)
     if "TCC_HIT_sum" in c:
         out["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+    try:                                     # identity of the kernel sources these counters were collected on (bench.py quotes the
+        from bench import kernel_src_sha     # file under roofline.traffic only when it matches the build that is running)
+        out["kernel_src_sha"] = kernel_src_sha()
+    except Exception:
+        pass
     print(json.dumps(out, indent=1))
     if args.out:
         json.dump(out, open(args.out, "w"), indent=1)

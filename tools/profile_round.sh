@@ -11,14 +11,14 @@ OUT=$R/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
 [ -x build/ubench_madd ] && build/ubench_madd > $OUT/${tag}_ubench_madd.txt 2>&1
-python3 bench.py > $OUT/${tag}_bench.json 2> $OUT/${tag}_bench.err || { tail -5 $OUT/${tag}_bench.err; exit 1; }
+python3 bench.py --steps 3 > $OUT/${tag}_bench.json 2> $OUT/${tag}_bench.err || { tail -5 $OUT/${tag}_bench.err; exit 1; }
 tail -c 600 $OUT/${tag}_bench.json; echo
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${tag}_stats -o stats -- python3 $R/bench.py --no-cpu-baseline > $OUT/${tag}_stats.log 2>&1 || { tail -5 $OUT/${tag}_stats.log; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${tag}_stats -o stats -- python3 $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 > $OUT/${tag}_stats.log 2>&1 || { tail -5 $OUT/${tag}_stats.log; exit 1; }
 echo "stats done"
 for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVE_CYCLES" "GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
   n=$(echo $c | cut -d' ' -f1)
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/${tag}_pmc_$n -o pmc -- python3 $R/bench.py --no-cpu-baseline --log2-entities 18 --warmup 0 > $OUT/${tag}_pmc_$n.log 2>&1 || { tail -5 $OUT/${tag}_pmc_$n.log; exit 1; }
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/${tag}_pmc_$n -o pmc -- python3 $R/bench.py --no-cpu-baseline --log2-entities 18 --warmup 0 --steps 1 > $OUT/${tag}_pmc_$n.log 2>&1 || { tail -5 $OUT/${tag}_pmc_$n.log; exit 1; }
   echo "pmc $n done"
   # keep only the rows of the dominant kernel (the merged gpurun_out/ is capped at 64 MiB)
   for f in $(find $OUT/${tag}_pmc_$n -name "*counter_collection.csv"); do head -1 $f > $f.tmp; grep "k_rp_msm" $f >> $f.tmp; mv $f.tmp $f; done
