@@ -255,6 +255,10 @@ __global__ __launch_bounds__(64, DAPOL_MSM_OCC) void k_rp_msm(RangeArgs A, Table
     if constexpr (MODE == MSM_TAIL) tbl.base += b * (size_t)(2 * A.N) * tbl.row_words();
     const dig_t* dig = A.dig + b * A.nwin * (size_t)A.TP + 32 * side;
     const int NW = A.nwin, W = A.wbits;
+    // trips of this lane (PLAIN / TAIL): runs of four consecutive terms when the list divides that way, else one term per trip
+    const bool grp4 = (A.N % (4 * LPL)) == 0;
+    const int trips_all = grp4 ? A.N / LPL : niter_all, unit = grp4 ? 4 : 1;
+    const int it_begin = (int)((long long)(trips_all / unit) * split / nsplit) * unit, it_end = (int)((long long)(trips_all / unit) * (split + 1) / nsplit) * unit;
     ge_p3 acc;
     ge_identity(acc);
     for (int w = NW - 1; w >= 0; w--) {
@@ -266,10 +270,34 @@ __global__ __launch_bounds__(64, DAPOL_MSM_OCC) void k_rp_msm(RangeArgs A, Table
             for (int d = 0; d < W; d++) ge_dbl(acc, acc, d == W - 1);
         }
         const dig_t* dw = dig + (size_t)w * A.TP;
-        for (int i = i_begin; i < niter; i += i_step) {
-            int q = LPL * i + ql;
-            if (q < A.N) {
+        if constexpr (MODE == MSM_MATERIALIZE) {
+            for (int i = i_begin; i < niter; i += i_step) {
+                int q = LPL * i + ql;                       // (N is a multiple of 32 here: every q is a term)
                 int d = dw[64 * (q >> 5) + (q & 31)];
+                bool isH;
+                int j = term_generator(round, A.N, A.lgN, side, q, isH);
+                tbl_madd(acc, tbl, gen_row(tbl, A.n, j, isH), d);
+            }
+        } else {
+            // Which terms a lane sums does not change the result, so a lane takes its terms in runs of FOUR consecutive
+            // positions where the list allows it (grp4): one 16-byte load brings four digits, and the rows of the digit matrix
+            // are read in whole 16-byte pieces per lane instead of 4 bytes per trip (8x less digit traffic at two lanes per
+            // list, where a 64-byte sector used to be fetched again for every pair of digits).  ONE copy of the addition: the
+            // trips are not unrolled (instruction cache, see above); the four digits rotate through d4.
+            dapol_v4i d4 = {0, 0, 0, 0};
+#pragma nounroll
+            for (int it = it_begin; it < it_end; it++) {
+                int q;
+                if (grp4) {
+                    q = 4 * (LPL * (it >> 2) + ql) + (it & 3);
+                    if ((it & 3) == 0) d4 = *reinterpret_cast<const dapol_v4i*>(dw + 64 * (q >> 5) + (q & 31));
+                } else {
+                    q = LPL * it + ql;
+                    if (q >= A.N) continue;
+                    d4.x = dw[64 * (q >> 5) + (q & 31)];
+                }
+                const int d = d4.x;
+                d4.x = d4.y; d4.y = d4.z; d4.z = d4.w;
                 bool isH;
                 int j = term_generator(round, A.N, A.lgN, side, q, isH);
                 int row;

@@ -51,9 +51,13 @@ __host__ __device__ __forceinline__ void niels_store_entry(int32_t* e, const ge_
     for (int i = 0; i < FE_NL; i++) { e[i] = q.ypx.v[i]; e[FE_NL + i] = q.ymx.v[i]; e[2 * FE_NL + i] = q.xy2d.v[i]; }
     for (int i = 3 * FE_NL; i < TBL_ENTRY_WORDS; i++) e[i] = 0;
 }
+// Plain (temporal) loads on purpose.  Tried: non-temporal loads (global_load_dwordx4 ... nt), on the theory that a random
+// gather over 35 GB has no line worth keeping -- 32 % SLOWER and +55 % HBM bytes (profiles/r02_digits_nt_ab.txt): the seven
+// loads of one entry are the same 128-byte line, and only a line that stays in L2 between them is fetched from HBM once.
+typedef int dapol_v4i __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void niels_load_entry(ge_niels& q, const int32_t* e) {
-    const int4* p = reinterpret_cast<const int4*>(e);
-    int4 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3], a4 = p[4], a5 = p[5], a6 = p[6];
+    const dapol_v4i* p = reinterpret_cast<const dapol_v4i*>(e);
+    dapol_v4i a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3], a4 = p[4], a5 = p[5], a6 = p[6];
     q.ypx.v[0] = a0.x; q.ypx.v[1] = a0.y; q.ypx.v[2] = a0.z; q.ypx.v[3] = a0.w;
     q.ypx.v[4] = a1.x; q.ypx.v[5] = a1.y; q.ypx.v[6] = a1.z; q.ypx.v[7] = a1.w;
     q.ypx.v[8] = a2.x;
