@@ -218,6 +218,17 @@ def cpu_baseline(generic_lib, height, n_bits, idx, v, r, sample_paths, budget_s=
     return res, bytes_t, n_t, ps
 
 
+def plan_steps(steps_req, warm_req, t_step, seconds_left):
+    """The wall budget: (further warm-up steps, timed steps) that fit `seconds_left` after the first warm-up step took t_step
+    seconds.  Timed steps are never fewer than min(3, requested); further warm-ups come only out of slack."""
+    if t_step is None or t_step <= 0:
+        return 0, steps_req
+    fit = int(seconds_left / (t_step * 1.03))
+    extra_warm = min(max(0, warm_req - 1), max(0, fit - steps_req))
+    steps = min(steps_req, max(min(3, steps_req), fit - extra_warm))
+    return extra_warm, steps
+
+
 def kernel_src_sha():
     """Identity of the kernel sources a profile was taken on (profiles/*.json carry it; bench.py quotes a profile only
     when it matches the build that is running)."""
@@ -332,12 +343,7 @@ def mode_prove(args):
         warm_done = 1
         if rank == 0:
             log("warm-up step 1: %.2f s" % t_step)
-    if t_step is not None:
-        fit = int((deadline - time.time() - post_reserve) / (t_step * 1.03))
-        extra_warm = min(warm_req - 1, max(0, fit - steps_req))            # extra warm-ups only out of slack
-        steps = min(steps_req, max(min(3, steps_req), fit - extra_warm))
-    else:
-        extra_warm, steps = 0, steps_req
+    extra_warm, steps = plan_steps(steps_req, warm_req, t_step, deadline - time.time() - post_reserve)
     extra_warm, steps = agree_min(extra_warm), agree_min(steps)
     for _ in range(extra_warm):
         prover.step(PAD_SEED, NONCE_SEED, n_bits)

@@ -160,7 +160,7 @@ int32_t dapol_ctx_create(int32_t device, int32_t max_parties, int32_t digest_id,
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)free_b * 0.30 < budget) budget = (double)free_b * 0.30;
         if (eb) budget = atof(eb) * 1e9;
         for (int w = WBITS_MIN; w <= WBITS_AUTO_MAX; w++) {
-            TableView t{nullptr, P, w};
+            TableView t{nullptr, P, w, 0, 0};
             if ((double)t.n_rows() * (double)t.row_words() * 4.0 <= budget) wbits = w;
         }
         const char* ew = getenv("DAPOL_WBITS");
@@ -170,13 +170,24 @@ int32_t dapol_ctx_create(int32_t device, int32_t max_parties, int32_t digest_id,
             wbits = w;
         }
     }
-    TableView tv{nullptr, P, wbits};
+    TableView tv{nullptr, P, wbits, digest_id, 0};
     const int rows = tv.n_rows();
+    {   // High-half rows for the G / H generators (tables.h): worth their memory (as much again as the G / H rows) only for the
+        // prover's materialisation step, so only when they fit beside everything else: DAPOL_TABLE_HI=0 / 1 forces, default = on
+        // when the doubled tables stay below 30 % of the free memory and the context is a prover's (<= 64 parties).  Measured
+        // interleaved (profiles/r02_hi_rows_ab.txt): +0.7 % at 2^18 proofs, +1.5 % at 2^20, for 34 GB more of HBM.
+        size_t free_b = 0, total_b = 0;
+        const double bytes2 = (double)(rows + 128 * P) * (double)tv.row_words() * 4.0;
+        bool hi = P <= 64 && hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes2 <= 0.30 * (double)free_b;
+        if (const char* e = getenv("DAPOL_TABLE_HI")) hi = atoi(e) != 0;
+        if (hi) tv.hi_split = (tv.nwin_c() + 1) / 2;
+    }
+    const int rows_total = tv.n_rows_total();
     DevBuf<uint32_t> uniform;
     DevBuf<int32_t> base_pts;
     HIPCHK(uniform.alloc((size_t)2 * P * 64 * 16));
-    HIPCHK(base_pts.alloc((size_t)rows * 40));
-    HIPCHK(c->table.alloc((size_t)rows * tv.row_words()));
+    HIPCHK(base_pts.alloc((size_t)rows_total * 40));
+    HIPCHK(c->table.alloc((size_t)rows_total * tv.row_words()));
     HIPCHK(c->gens_comp.alloc((size_t)rows * 8));
     hipLaunchKernelGGL(k_ctx_chains, dim3(nblk(2 * P, 64)), dim3(64), 0, c->stream, uniform.p, P);
     LAUNCH_CHECK();
@@ -184,12 +195,18 @@ int32_t dapol_ctx_create(int32_t device, int32_t max_parties, int32_t digest_id,
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_ctx_pedersen, dim3(1), dim3(64), 0, c->stream, base_pts.p, P, wbits, tv.nwin());
     LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_ctx_table, dim3(nblk((size_t)rows * tv.entries(), 64)), dim3(64), 0, c->stream, c->table.p, base_pts.p, rows, wbits, tv.entries());
+    if (tv.hi_split) {
+        hipLaunchKernelGGL(k_ctx_hi_points, dim3(nblk(128 * P, 64)), dim3(64), 0, c->stream, base_pts.p, 128 * P, rows, wbits * tv.hi_split);
+        LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_ctx_table, dim3(nblk((size_t)rows_total * tv.entries(), 64)), dim3(64), 0, c->stream, c->table.p, base_pts.p, rows_total, wbits,
+                       tv.entries());
     LAUNCH_CHECK();
     hipLaunchKernelGGL(k_ctx_compress, dim3(nblk(rows, 64)), dim3(64), 0, c->stream, c->gens_comp.p, base_pts.p, rows);
     LAUNCH_CHECK();
     HIPCHK(hipStreamSynchronize(c->stream));
-    c->tv = TableView{c->table.p, P, wbits, digest_id};
+    c->tv = tv;
+    c->tv.base = c->table.p;
     guard.c = nullptr;
     *out = c;
     return DAPOL_OK;

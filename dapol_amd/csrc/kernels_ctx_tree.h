@@ -95,6 +95,15 @@ __global__ void k_ctx_pedersen(int32_t* base_pts, int P, int wbits, int nwin) {
         for (int d = 0; d < wbits; d++) { ge_p3 q; ge_dbl(q, p, true); p = q; }
     }
 }
+// High-half base points: 2^(shift) * (G / H generator), one lane per generator (TableView::hi_split).
+__global__ void k_ctx_hi_points(int32_t* base_pts, int n_gh, int n_rows, int shift) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_gh) return;
+    ge_p3 p, q;
+    ld_p3(p, base_pts + (size_t)r * 40);
+    for (int d = 0; d < shift; d++) { ge_dbl(q, p, true); p = q; }
+    st_p3(base_pts + (size_t)(n_rows + r) * 40, p);
+}
 // One lane per table entry: k * base, normalised to affine niels form.
 __global__ void k_ctx_table(int32_t* table, const int32_t* base_pts, int n_rows, int wbits, int entries) {
     size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -111,13 +111,17 @@ __device__ __forceinline__ void st_sc(sc* p, const sc& r) {
     q[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
     q[1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
 }
-// digits of a Montgomery-form scalar for list position `pos` of proof b
-__device__ __forceinline__ void write_digits(const RangeArgs& A, size_t b, int pos, const sc& s_mont) {
-    uint32_t c[8];
-    sc_from_mont(c, s_mont);
+// digits of a canonical scalar (eight words, < l) for list position `pos` of proof b
+__device__ __forceinline__ void write_digits_plain(const RangeArgs& A, size_t b, int pos, const uint32_t* c) {
     dig_t* d = A.dig + (size_t)b * A.nwin * A.TP + pos;
     const int TP = A.TP;
     sc_recode_w(A.wbits, A.nwin, c, [&](int i, int digit) { d[(size_t)i * TP] = (dig_t)digit; });
+}
+// digits of a Montgomery-form scalar
+__device__ __forceinline__ void write_digits(const RangeArgs& A, size_t b, int pos, const sc& s_mont) {
+    uint32_t c[8];
+    sc_from_mont(c, s_mont);
+    write_digits_plain(A, b, pos, c);
 }
 __device__ __forceinline__ void zero_digits(const RangeArgs& A, size_t b, int pos) {
     dig_t* d = A.dig + (size_t)b * A.nwin * A.TP + pos;
@@ -261,8 +265,11 @@ __global__ __launch_bounds__(64, DAPOL_MSM_OCC) void k_rp_msm(RangeArgs A, Table
     const int it_begin = (int)((long long)(trips_all / unit) * split / nsplit) * unit, it_end = (int)((long long)(trips_all / unit) * (split + 1) / nsplit) * unit;
     ge_p3 acc;
     ge_identity(acc);
-    for (int w = NW - 1; w >= 0; w--) {
-        if (w != NW - 1) {
+    // Materialisation with high-half rows (TableView::hi_split): only the low hi_split window steps are walked; a step looks a
+    // term up twice, digit w in the generator's row and digit w + hi_split in its 2^(W hi_split) row.
+    const int LW = (MODE == MSM_MATERIALIZE && tbl.hi_split) ? tbl.hi_split : NW;
+    for (int w = LW - 1; w >= 0; w--) {
+        if (w != LW - 1) {
             // ONE inlined copy of the doubling (T under a runtime flag).  Measured (profiles/r01_msm_variants.txt): a
             // second, T-less copy made the launch 17 % SLOWER (127 vs 109 ms) -- the loop body is ~25 KB of code and
             // the extra copy costs more in instruction-cache misses than the skipped multiplication saves.
@@ -271,12 +278,18 @@ __global__ __launch_bounds__(64, DAPOL_MSM_OCC) void k_rp_msm(RangeArgs A, Table
         }
         const dig_t* dw = dig + (size_t)w * A.TP;
         if constexpr (MODE == MSM_MATERIALIZE) {
-            for (int i = i_begin; i < niter; i += i_step) {
+            const int halves = LW < NW ? 2 : 1;             // ONE copy of the addition: the two lookups of a term are two trips
+            const int own = (niter - i_begin + i_step - 1) / i_step;        // this block's terms: i = i_begin + k * i_step
+#pragma nounroll
+            for (int it = 0; it < 2 * own; it += (halves == 2 ? 1 : 2)) {
+                const int i = i_begin + (it >> 1) * i_step, hi = it & 1;
+                if (hi && w + LW >= NW) continue;
                 int q = LPL * i + ql;                       // (N is a multiple of 32 here: every q is a term)
-                int d = dw[64 * (q >> 5) + (q & 31)];
+                int d = (hi ? dw + (size_t)LW * A.TP : dw)[64 * (q >> 5) + (q & 31)];
                 bool isH;
                 int j = term_generator(round, A.N, A.lgN, side, q, isH);
-                tbl_madd(acc, tbl, gen_row(tbl, A.n, j, isH), d);
+                int row = gen_row(tbl, A.n, j, isH);
+                tbl_madd(acc, tbl, hi ? tbl.row_hi(row) : row, d);
             }
         } else {
             // Which terms a lane sums does not change the result, so a lane takes its terms in runs of FOUR consecutive
@@ -381,7 +394,7 @@ __global__ __launch_bounds__(64) void k_rp_tail_table(RangeArgs A) {
     int g = (int)(blockIdx.x % bpp) * 64 + threadIdx.x;          // row: G'_g (g < T) or H'_(g-T)
     build_niels_row<TAIL_ENTRIES>(A.tailT + (b * (size_t)(2 * T) + g) * TAIL_ROW_WORDS);
     sc one, v;
-    sc_one_mont(one);
+    sc_zero(one); one.v[0] = 1;                              // plain 1 (the s-vectors are kept in plain form)
     int i = g < T ? g : g - T;
     st_sc((g < T ? A.tail_s1 : A.tail_s2) + b * T + i, one);
     ld_sc(v, (g < T ? A.a : A.b) + b * A.N + i);
@@ -396,8 +409,8 @@ __global__ __launch_bounds__(64) void k_rp_mat_prep(RangeArgs A) {
     int ch = blockIdx.x % nch, l = threadIdx.x, side = l >> 5, q = 32 * ch + (l & 31), pos = 64 * ch + l;
     if (q >= A.N) { zero_digits(A, b, pos); return; }
     sc s;
-    ld_sc(s, (side ? A.s2 : A.s1) + b * A.N + q);
-    write_digits(A, b, pos, s);
+    ld_sc(s, (side ? A.s2 : A.s1) + b * A.N + q);           // plain form already
+    write_digits_plain(A, b, pos, s.v);
 }
 
 // --------------------------------------------------------------------------------------- transcript helpers
@@ -581,8 +594,13 @@ __global__ __launch_bounds__(64) void k_rp_lr(RangeArgs A) {
         sc_add(tx, tx, t);
         st_sc(A.a + b * A.N + i, lv);
         st_sc(A.b + b * A.N + i, rv);
-        st_sc(A.s1 + b * A.N + i, one);          // s_G[i] = 1
-        st_sc(A.s2 + b * A.N + i, yi);           // s_H[i] = y^-i   (H' = y^-i H, folded into the scalar)
+        // The coefficient vectors s_G, s_H live in PLAIN form (not Montgomery): montmul(x_mont, s_plain) = x * s is then the
+        // canonical product k_rp_round_prep recodes, with no conversion per term; montmul(s_plain, u_mont) keeps them plain.
+        sc pl;
+        sc_zero(pl); pl.v[0] = 1;
+        st_sc(A.s1 + b * A.N + i, pl);           // s_G[i] = 1
+        sc_from_mont(pl.v, yi);
+        st_sc(A.s2 + b * A.N + i, pl);           // s_H[i] = y^-i   (H' = y^-i H, folded into the scalar)
         sc_montmul(yi, yi, y64);
     }
     wave_reduce_sc(tx);
@@ -648,9 +666,9 @@ __global__ __launch_bounds__(64) void k_rp_round_prep(RangeArgs A, int round) {
     int vi = upper ? off : off + half;
     sc v, s, p;
     ld_sc(v, (isH ? A.b : A.a) + b * A.N + vi);
-    ld_sc(s, (isH ? A.s2 : A.s1) + b * A.N + j);
-    sc_montmul(p, v, s);
-    write_digits(A, b, pos, p);
+    ld_sc(s, (isH ? A.s2 : A.s1) + b * A.N + j);          // plain form (k_rp_lr)
+    sc_montmul(p, v, s);                                   // Montgomery x plain = the canonical product
+    write_digits_plain(A, b, pos, p.v);
 }
 // c_L = <a_L, b_R>, c_R = <a_R, b_L>  (wave per proof)
 __global__ __launch_bounds__(64) void k_rp_round_ip(RangeArgs A, int round) {

@@ -29,6 +29,11 @@ struct TableView {
     int32_t max_parties;
     int32_t wbits;         // W
     int32_t digest;        // node hash D of the context: DG_BLAKE3 (0) or DG_BLAKE2S (1)
+    // High-half rows (0 = none): a second row per G / H generator holding the multiples of 2^(W * hi_split) * P, so that a sum
+    // whose accumulators cannot share doublings (the materialisation of the folded generators: one accumulator per lane, 255
+    // doublings for 480 additions) walks hi_split windows instead of nwin_c(): the scalar is split s = s_lo + 2^(W hi_split) s_hi
+    // and both halves are looked up in the same window step.  Row of generator row r: n_rows() + r.
+    int32_t hi_split;
     // Windows of an UNREDUCED 255-bit integer (Scalar::from_bits leaf blindings): the top window must hold its value
     // plus the recoding carry within 2^(W-1), i.e. be at most W-1 bits wide -> 255/W + 1 windows.  Canonical scalars
     // (< 2^253, everything in the digit matrices) need 253/W + 1.
@@ -42,6 +47,8 @@ struct TableView {
     __host__ __device__ int row_Bb(int w) const { return 128 * max_parties + w; }
     __host__ __device__ int row_B(int w) const { return 128 * max_parties + nwin() + w; }
     __host__ __device__ int n_rows() const { return 128 * max_parties + 2 * nwin(); }
+    __host__ __device__ int n_rows_total() const { return n_rows() + (hi_split ? 128 * max_parties : 0); }
+    __host__ __device__ int row_hi(int gh_row) const { return n_rows() + gh_row; }
 };
 
 #if defined(__HIPCC__)

@@ -81,15 +81,36 @@ class ShardedProver:
             if comm_device == "cuda":
                 self._create_comm()
 
-    def _create_comm(self):
-        """RCCL communicator inside the library: rank 0 draws the id, torch.distributed carries it to the other ranks."""
+    def _create_comm(self, timeout_s=90.0):
+        """RCCL communicator inside the library: rank 0 draws the id, torch.distributed carries it to the other ranks.
+        ncclCommInitRank blocks until every rank has called it, so it runs on a helper thread with a deadline: a rank that
+        cannot join (or a bootstrap that never completes) must not hang the job -- every rank then falls back to the
+        torch.distributed transport, and the line says which one ran."""
+        import os
+        import threading
         t, ok = self.torch, 1
+        if os.environ.get("DAPOL_EXCHANGE", "").lower() == "torch":
+            return
+        box = {}
+
+        def create(uid_bytes):
+            try:
+                box["comm"] = capi.Comm(self.ctx, uid_bytes, self.rank, self.world)
+            except Exception as e:                          # stay on the torch.distributed path, and say so
+                box["err"] = repr(e)
+
         try:
             uid = capi.comm_unique_id() if self.rank == 0 else bytes(capi.COMM_ID_BYTES)
             buf = t.from_numpy(np.frombuffer(uid, np.uint8).copy()).to(self.comm_device)
             self.dist.broadcast(buf, src=0)
-            self.comm = capi.Comm(self.ctx, buf.cpu().numpy().tobytes(), self.rank, self.world)
-        except Exception as e:                              # stay on the torch.distributed path, and say so
+            th = threading.Thread(target=create, args=(buf.cpu().numpy().tobytes(),), daemon=True)
+            th.start()
+            th.join(timeout_s)
+            if th.is_alive() or "comm" not in box:
+                self.comm_error, ok = box.get("err", "ncclCommInitRank did not return within %.0f s" % timeout_s), 0
+            else:
+                self.comm = box["comm"]
+        except Exception as e:
             self.comm_error, ok = repr(e), 0
         flag = t.tensor([ok], dtype=t.int64, device=self.comm_device)
         self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)

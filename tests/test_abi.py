@@ -147,3 +147,17 @@ def test_dapol_proof_wire_layout_host_only(hip_lib, pyref):
 def load_golden_cases():
     from conftest import load_golden
     return load_golden("dapol.json")
+
+
+def test_bench_wall_budget_plan():
+    """bench.py's step plan under the wall budget (the driver's --steps 20 --warmup 5 never fit 600 s)."""
+    import bench
+    assert bench.plan_steps(20, 5, 22.0, 450 - 30 - 45) == (0, 16)            # driver's call: clamp, no further warm-up
+    assert bench.plan_steps(20, 5, 22.0, 30.0) == (0, 3)                      # never fewer than three timed steps
+    assert bench.plan_steps(3, 1, 22.0, 400.0) == (0, 3)                      # the default call is untouched
+    assert bench.plan_steps(2, 3, 1.0, 400.0) == (2, 2)                       # cheap steps: everything asked for
+    assert bench.plan_steps(1, 1, 500.0, 10.0) == (0, 1)
+    assert bench.plan_steps(5, 0, None, 100.0) == (0, 5)                      # no warm-up: nothing measured to plan with
+    prove, tree = bench.algorithmic_bytes(32, 64, 20)
+    assert (prove, tree, prove + tree) == (6384, 2752, 9136)                  # SURVEY 8d
+    assert bench.algorithmic_bytes(24, 64, 16) == (5040, 1920)

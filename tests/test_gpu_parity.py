@@ -1307,3 +1307,32 @@ def test_batch_proof_on_a_sharded_tree(gpu_ctx, hip_lib, policy, agg):
     # a position no shard tree holds is reported, not invented
     _, _, _, _, found = hip_lib.tree_node_records(trees[0].h, [0, 0, height - sb], [int(idx[0]), int(idx[-1]), 0])
     assert found.tolist() == [1, 0, 1]
+
+
+@pytest.mark.gpu
+def test_high_half_rows_do_not_change_bytes(hip_lib, ref):
+    """TableView::hi_split: the materialisation of the folded generators may look every term up in two rows (P and 2^(W*8) P)
+    and walk half the window steps; with and without those rows, and at two window widths, the proofs are the oracle's."""
+    import os
+    n_bits, m, b = 64, 32, 6
+    rng = np.random.default_rng(77)
+    v = rng.integers(0, 2**63, size=(b, m), dtype=np.uint64)
+    r = rng.integers(0, 256, size=(b, m, 32), dtype=np.uint8)
+    r[:, :, 31] &= 0x0F
+    sid = np.arange(b, dtype=np.uint64) + 1000
+    outs = []
+    for env in ({"DAPOL_TABLE_HI": "0", "DAPOL_TABLE_GB": "3"}, {"DAPOL_TABLE_HI": "1", "DAPOL_TABLE_GB": "3"}, {"DAPOL_TABLE_HI": "1", "DAPOL_WBITS": "10"}):
+        os.environ.update(env)
+        try:
+            ctx = hip_lib.Context(0, m)
+            outs.append(ctx.range_prove_batch(n_bits, m, v, r, nonce_seed=SEED, stream_id=sid).tobytes())
+            ctx.close()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    assert outs[0] == outs[1] == outs[2]
+    ps = len(outs[0]) // b
+    out = ctypes.create_string_buffer(ps)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    assert ref.ref_range_prove(n_bits, m, p(v[0]), p(r[0]), SEED, ctypes.c_uint64(int(sid[0])), ctypes.c_uint64(0), None, 0, out) == 0
+    assert out.raw == outs[0][:ps]
