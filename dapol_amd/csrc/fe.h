@@ -80,130 +80,35 @@ DAPOL_HD void fe_limbs_from_cols(fe& h, int64_t c0, int64_t c1, int64_t c2, int6
 // column below, so no 64-bit carry addition is ever issued on its own.  Inline assembly, one statement per column, because
 // LLVM re-associates a C sum so that the carry is added last, as a separate instruction; one statement per column (not per
 // MAD) keeps the hazard recogniser from padding the dependent MADs with s_nop.  madNc: N products added to a carry;
-// madNz: N products from zero.  (Generated once; the second destination is VOP3b's unused scalar carry-out.)
+// madNz: N products from zero; suffix l / h: plus the low (unsigned) / high (signed) half of a wrapped high column times its
+// constant.  (Generated once; the second destination is VOP3b's unused scalar carry-out.)
 #define DAPOL_MAD_CHAIN 1
-__device__ __forceinline__ int64_t mad1c(int64_t d, int32_t a0, int32_t b0) {
+__device__ __forceinline__ int64_t mad1z(int32_t a0, int32_t b0) {
+    int64_t d;
     uint64_t sdst;
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
-        : "+v"(d), "=s"(sdst)
+    asm("v_mad_i64_i32 %0, %1, %2, %3, 0"
+        : "=&v"(d), "=s"(sdst)
         : "v"(a0), "v"(b0));
     return d;
 }
 
-__device__ __forceinline__ int64_t mad2c(int64_t d, int32_t a0, int32_t b0, int32_t a1, int32_t b1) {
+__device__ __forceinline__ int64_t mad1zl(int32_t a0, int32_t b0, uint32_t lo, uint32_t kl) {
+    int64_t d;
     uint64_t sdst;
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %4, %5, %0"
-        : "+v"(d), "=s"(sdst)
-        : "v"(a0), "v"(b0), "v"(a1), "v"(b1));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, 0\n\t"
+        "v_mad_u64_u32 %0, %1, %4, %5, %0"
+        : "=&v"(d), "=s"(sdst)
+        : "v"(a0), "v"(b0), "v"(lo), "v"(kl));
     return d;
 }
 
-__device__ __forceinline__ int64_t mad3c(int64_t d, int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2) {
+__device__ __forceinline__ int64_t mad1clh(int64_t d, int32_t a0, int32_t b0, uint32_t lo, uint32_t kl, int32_t hi, int32_t kh) {
     uint64_t sdst;
     asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %4, %5, %0\n\t"
         "v_mad_i64_i32 %0, %1, %6, %7, %0"
         : "+v"(d), "=s"(sdst)
-        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2));
-    return d;
-}
-
-__device__ __forceinline__ int64_t mad4c(int64_t d, int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2, int32_t a3, int32_t b3) {
-    uint64_t sdst;
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %8, %9, %0"
-        : "+v"(d), "=s"(sdst)
-        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3));
-    return d;
-}
-
-__device__ __forceinline__ int64_t mad5c(int64_t d, int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2, int32_t a3, int32_t b3, int32_t a4, int32_t b4) {
-    uint64_t sdst;
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %10, %11, %0"
-        : "+v"(d), "=s"(sdst)
-        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4));
-    return d;
-}
-
-__device__ __forceinline__ int64_t mad6c(int64_t d, int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2, int32_t a3, int32_t b3, int32_t a4, int32_t b4, int32_t a5, int32_t b5) {
-    uint64_t sdst;
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %10, %11, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %12, %13, %0"
-        : "+v"(d), "=s"(sdst)
-        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5));
-    return d;
-}
-
-__device__ __forceinline__ int64_t mad7c(int64_t d, int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2, int32_t a3, int32_t b3, int32_t a4, int32_t b4, int32_t a5, int32_t b5, int32_t a6, int32_t b6) {
-    uint64_t sdst;
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %10, %11, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %12, %13, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %14, %15, %0"
-        : "+v"(d), "=s"(sdst)
-        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), "v"(a6), "v"(b6));
-    return d;
-}
-
-__device__ __forceinline__ int64_t mad8c(int64_t d, int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2, int32_t a3, int32_t b3, int32_t a4, int32_t b4, int32_t a5, int32_t b5, int32_t a6, int32_t b6, int32_t a7, int32_t b7) {
-    uint64_t sdst;
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %10, %11, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %12, %13, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %14, %15, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %16, %17, %0"
-        : "+v"(d), "=s"(sdst)
-        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), "v"(a6), "v"(b6), "v"(a7), "v"(b7));
-    return d;
-}
-
-__device__ __forceinline__ int64_t mad9c(int64_t d, int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2, int32_t a3, int32_t b3, int32_t a4, int32_t b4, int32_t a5, int32_t b5, int32_t a6, int32_t b6, int32_t a7, int32_t b7, int32_t a8, int32_t b8) {
-    uint64_t sdst;
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %10, %11, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %12, %13, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %14, %15, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %16, %17, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %18, %19, %0"
-        : "+v"(d), "=s"(sdst)
-        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), "v"(a6), "v"(b6), "v"(a7), "v"(b7), "v"(a8), "v"(b8));
-    return d;
-}
-
-__device__ __forceinline__ int64_t mad10c(int64_t d, int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2, int32_t a3, int32_t b3, int32_t a4, int32_t b4, int32_t a5, int32_t b5, int32_t a6, int32_t b6, int32_t a7, int32_t b7, int32_t a8, int32_t b8, int32_t a9, int32_t b9) {
-    uint64_t sdst;
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %10, %11, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %12, %13, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %14, %15, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %16, %17, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %18, %19, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %20, %21, %0"
-        : "+v"(d), "=s"(sdst)
-        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), "v"(a6), "v"(b6), "v"(a7), "v"(b7), "v"(a8), "v"(b8), "v"(a9), "v"(b9));
+        : "v"(a0), "v"(b0), "v"(lo), "v"(kl), "v"(hi), "v"(kh));
     return d;
 }
 
@@ -214,6 +119,165 @@ __device__ __forceinline__ int64_t mad2z(int32_t a0, int32_t b0, int32_t a1, int
         "v_mad_i64_i32 %0, %1, %4, %5, %0"
         : "=&v"(d), "=s"(sdst)
         : "v"(a0), "v"(b0), "v"(a1), "v"(b1));
+    return d;
+}
+
+__device__ __forceinline__ int64_t mad2clh(int64_t d, int32_t a0, int32_t b0, int32_t a1, int32_t b1, uint32_t lo, uint32_t kl, int32_t hi, int32_t kh) {
+    uint64_t sdst;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %6, %7, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "+v"(d), "=s"(sdst)
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(lo), "v"(kl), "v"(hi), "v"(kh));
+    return d;
+}
+
+__device__ __forceinline__ int64_t mad3z(int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2) {
+    int64_t d;
+    uint64_t sdst;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, 0\n\t"
+        "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %6, %7, %0"
+        : "=&v"(d), "=s"(sdst)
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2));
+    return d;
+}
+
+__device__ __forceinline__ int64_t mad3clh(int64_t d, int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2, uint32_t lo, uint32_t kl, int32_t hi, int32_t kh) {
+    uint64_t sdst;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %8, %9, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %10, %11, %0"
+        : "+v"(d), "=s"(sdst)
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(lo), "v"(kl), "v"(hi), "v"(kh));
+    return d;
+}
+
+__device__ __forceinline__ int64_t mad4z(int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2, int32_t a3, int32_t b3) {
+    int64_t d;
+    uint64_t sdst;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, 0\n\t"
+        "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "=&v"(d), "=s"(sdst)
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3));
+    return d;
+}
+
+__device__ __forceinline__ int64_t mad4clh(int64_t d, int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2, int32_t a3, int32_t b3, uint32_t lo, uint32_t kl, int32_t hi, int32_t kh) {
+    uint64_t sdst;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %10, %11, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %12, %13, %0"
+        : "+v"(d), "=s"(sdst)
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(lo), "v"(kl), "v"(hi), "v"(kh));
+    return d;
+}
+
+__device__ __forceinline__ int64_t mad5z(int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2, int32_t a3, int32_t b3, int32_t a4, int32_t b4) {
+    int64_t d;
+    uint64_t sdst;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, 0\n\t"
+        "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %10, %11, %0"
+        : "=&v"(d), "=s"(sdst)
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4));
+    return d;
+}
+
+__device__ __forceinline__ int64_t mad5ch(int64_t d, int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2, int32_t a3, int32_t b3, int32_t a4, int32_t b4, int32_t hi, int32_t kh) {
+    uint64_t sdst;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %10, %11, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %12, %13, %0"
+        : "+v"(d), "=s"(sdst)
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(hi), "v"(kh));
+    return d;
+}
+
+__device__ __forceinline__ int64_t mad5clh(int64_t d, int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2, int32_t a3, int32_t b3, int32_t a4, int32_t b4, uint32_t lo, uint32_t kl, int32_t hi, int32_t kh) {
+    uint64_t sdst;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %10, %11, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %12, %13, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %14, %15, %0"
+        : "+v"(d), "=s"(sdst)
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(lo), "v"(kl), "v"(hi), "v"(kh));
+    return d;
+}
+
+__device__ __forceinline__ int64_t mad6z(int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2, int32_t a3, int32_t b3, int32_t a4, int32_t b4, int32_t a5, int32_t b5) {
+    int64_t d;
+    uint64_t sdst;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, 0\n\t"
+        "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %10, %11, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %12, %13, %0"
+        : "=&v"(d), "=s"(sdst)
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5));
+    return d;
+}
+
+__device__ __forceinline__ int64_t mad6clh(int64_t d, int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2, int32_t a3, int32_t b3, int32_t a4, int32_t b4, int32_t a5, int32_t b5, uint32_t lo, uint32_t kl, int32_t hi, int32_t kh) {
+    uint64_t sdst;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %10, %11, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %12, %13, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %14, %15, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %16, %17, %0"
+        : "+v"(d), "=s"(sdst)
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), "v"(lo), "v"(kl), "v"(hi), "v"(kh));
+    return d;
+}
+
+__device__ __forceinline__ int64_t mad7z(int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2, int32_t a3, int32_t b3, int32_t a4, int32_t b4, int32_t a5, int32_t b5, int32_t a6, int32_t b6) {
+    int64_t d;
+    uint64_t sdst;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, 0\n\t"
+        "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %10, %11, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %12, %13, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %14, %15, %0"
+        : "=&v"(d), "=s"(sdst)
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), "v"(a6), "v"(b6));
+    return d;
+}
+
+__device__ __forceinline__ int64_t mad7clh(int64_t d, int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2, int32_t a3, int32_t b3, int32_t a4, int32_t b4, int32_t a5, int32_t b5, int32_t a6, int32_t b6, uint32_t lo, uint32_t kl, int32_t hi, int32_t kh) {
+    uint64_t sdst;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %10, %11, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %12, %13, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %14, %15, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %16, %17, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %18, %19, %0"
+        : "+v"(d), "=s"(sdst)
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), "v"(a6), "v"(b6), "v"(lo), "v"(kl), "v"(hi), "v"(kh));
     return d;
 }
 
@@ -233,15 +297,37 @@ __device__ __forceinline__ int64_t mad8z(int32_t a0, int32_t b0, int32_t a1, int
     return d;
 }
 
-__device__ __forceinline__ int64_t mad4z(int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2, int32_t a3, int32_t b3) {
-    int64_t d;
+__device__ __forceinline__ int64_t mad8clh(int64_t d, int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2, int32_t a3, int32_t b3, int32_t a4, int32_t b4, int32_t a5, int32_t b5, int32_t a6, int32_t b6, int32_t a7, int32_t b7, uint32_t lo, uint32_t kl, int32_t hi, int32_t kh) {
     uint64_t sdst;
-    asm("v_mad_i64_i32 %0, %1, %2, %3, 0\n\t"
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t"
         "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
         "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t"
-        "v_mad_i64_i32 %0, %1, %8, %9, %0"
-        : "=&v"(d), "=s"(sdst)
-        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3));
+        "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %10, %11, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %12, %13, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %14, %15, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %16, %17, %0\n\t"
+        "v_mad_u64_u32 %0, %1, %18, %19, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %20, %21, %0"
+        : "+v"(d), "=s"(sdst)
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), "v"(a6), "v"(b6), "v"(a7), "v"(b7), "v"(lo), "v"(kl), "v"(hi), "v"(kh));
+    return d;
+}
+
+__device__ __forceinline__ int64_t mad9ch(int64_t d, int32_t a0, int32_t b0, int32_t a1, int32_t b1, int32_t a2, int32_t b2, int32_t a3, int32_t b3, int32_t a4, int32_t b4, int32_t a5, int32_t b5, int32_t a6, int32_t b6, int32_t a7, int32_t b7, int32_t a8, int32_t b8, int32_t hi, int32_t kh) {
+    uint64_t sdst;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %4, %5, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %6, %7, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %8, %9, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %10, %11, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %12, %13, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %14, %15, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %16, %17, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %18, %19, %0\n\t"
+        "v_mad_i64_i32 %0, %1, %20, %21, %0"
+        : "+v"(d), "=s"(sdst)
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3), "v"(a4), "v"(b4), "v"(a5), "v"(b5), "v"(a6), "v"(b6), "v"(a7), "v"(b7), "v"(a8), "v"(b8), "v"(hi), "v"(kh));
     return d;
 }
 #endif
@@ -252,61 +338,42 @@ DAPOL_HD void fe_mul(fe& h, const fe& f, const fe& g) {
     const int32_t f0 = f.v[0], f1 = f.v[1], f2 = f.v[2], f3 = f.v[3], f4 = f.v[4], f5 = f.v[5], f6 = f.v[6], f7 = f.v[7], f8 = f.v[8];
     const int32_t g0 = g.v[0], g1 = g.v[1], g2 = g.v[2], g3 = g.v[3], g4 = g.v[4], g5 = g.v[5], g6 = g.v[6], g7 = g.v[7], g8 = g.v[8];
 #if defined(DAPOL_MAD_CHAIN)
-    const int32_t k1216 = 1216;
+    const int32_t k1216 = 1216, k9728 = 9728;
     const int64_t c9 = mad8z(f1, g8, f2, g7, f3, g6, f4, g5, f5, g4, f6, g3, f7, g2, f8, g1);
-    const int64_t c10 = mad7c(c9 >> 29, f2, g8, f3, g7, f4, g6, f5, g5, f6, g4, f7, g3, f8, g2);
-    const int64_t c11 = mad6c(c10 >> 29, f3, g8, f4, g7, f5, g6, f6, g5, f7, g4, f8, g3);
-    const int64_t c12 = mad5c(c11 >> 29, f4, g8, f5, g7, f6, g6, f7, g5, f8, g4);
-    const int64_t c13 = mad4c(c12 >> 29, f5, g8, f6, g7, f7, g6, f8, g5);
-    const int64_t c14 = mad3c(c13 >> 29, f6, g8, f7, g7, f8, g6);
-    const int64_t c15 = mad2c(c14 >> 29, f7, g8, f8, g7);
-    const int64_t c16 = mad1c(c15 >> 29, f8, g8);
-    // the high half as limbs h9..h16 (+ the last carry h17): column k wraps to column k - 9 times 2^261 mod p = 1216
-    const int32_t h9 = (int32_t)c9 & FE_M29;
-    const int32_t h10 = (int32_t)c10 & FE_M29;
-    const int32_t h11 = (int32_t)c11 & FE_M29;
-    const int32_t h12 = (int32_t)c12 & FE_M29;
-    const int32_t h13 = (int32_t)c13 & FE_M29;
-    const int32_t h14 = (int32_t)c14 & FE_M29;
-    const int32_t h15 = (int32_t)c15 & FE_M29;
-    const int32_t h16 = (int32_t)c16 & FE_M29;
-    const int32_t h17 = (int32_t)(c16 >> 29);
-    const int64_t c0 = mad2z(f0, g0, h9, k1216);
-    const int64_t c1 = mad3c(c0 >> 29, f0, g1, f1, g0, h10, k1216);
-    const int64_t c2 = mad4c(c1 >> 29, f0, g2, f1, g1, f2, g0, h11, k1216);
-    const int64_t c3 = mad5c(c2 >> 29, f0, g3, f1, g2, f2, g1, f3, g0, h12, k1216);
-    const int64_t c4 = mad6c(c3 >> 29, f0, g4, f1, g3, f2, g2, f3, g1, f4, g0, h13, k1216);
-    const int64_t c5 = mad7c(c4 >> 29, f0, g5, f1, g4, f2, g3, f3, g2, f4, g1, f5, g0, h14, k1216);
-    const int64_t c6 = mad8c(c5 >> 29, f0, g6, f1, g5, f2, g4, f3, g3, f4, g2, f5, g1, f6, g0, h15, k1216);
-    const int64_t c7 = mad9c(c6 >> 29, f0, g7, f1, g6, f2, g5, f3, g4, f4, g3, f5, g2, f6, g1, f7, g0, h16, k1216);
-    const int64_t c8 = mad10c(c7 >> 29, f0, g8, f1, g7, f2, g6, f3, g5, f4, g4, f5, g3, f6, g2, f7, g1, f8, g0, h17, k1216);
+    const int64_t c10 = mad7z(f2, g8, f3, g7, f4, g6, f5, g5, f6, g4, f7, g3, f8, g2);
+    const int64_t c11 = mad6z(f3, g8, f4, g7, f5, g6, f6, g5, f7, g4, f8, g3);
+    const int64_t c12 = mad5z(f4, g8, f5, g7, f6, g6, f7, g5, f8, g4);
+    const int64_t c13 = mad4z(f5, g8, f6, g7, f7, g6, f8, g5);
+    const int64_t c14 = mad3z(f6, g8, f7, g7, f8, g6);
+    const int64_t c15 = mad2z(f7, g8, f8, g7);
+    const int64_t c16 = mad1z(f8, g8);
+    const int64_t c0 = mad1zl(f0, g0, (uint32_t)c9, k1216);
+    const int64_t c1 = mad2clh(c0 >> 29, f0, g1, f1, g0, (uint32_t)c10, k1216, (int32_t)(c9 >> 32), k9728);
+    const int64_t c2 = mad3clh(c1 >> 29, f0, g2, f1, g1, f2, g0, (uint32_t)c11, k1216, (int32_t)(c10 >> 32), k9728);
+    const int64_t c3 = mad4clh(c2 >> 29, f0, g3, f1, g2, f2, g1, f3, g0, (uint32_t)c12, k1216, (int32_t)(c11 >> 32), k9728);
+    const int64_t c4 = mad5clh(c3 >> 29, f0, g4, f1, g3, f2, g2, f3, g1, f4, g0, (uint32_t)c13, k1216, (int32_t)(c12 >> 32), k9728);
+    const int64_t c5 = mad6clh(c4 >> 29, f0, g5, f1, g4, f2, g3, f3, g2, f4, g1, f5, g0, (uint32_t)c14, k1216, (int32_t)(c13 >> 32), k9728);
+    const int64_t c6 = mad7clh(c5 >> 29, f0, g6, f1, g5, f2, g4, f3, g3, f4, g2, f5, g1, f6, g0, (uint32_t)c15, k1216, (int32_t)(c14 >> 32), k9728);
+    const int64_t c7 = mad8clh(c6 >> 29, f0, g7, f1, g6, f2, g5, f3, g4, f4, g3, f5, g2, f6, g1, f7, g0, (uint32_t)c16, k1216, (int32_t)(c15 >> 32), k9728);
+    const int64_t c8 = mad9ch(c7 >> 29, f0, g8, f1, g7, f2, g6, f3, g5, f4, g4, f5, g3, f6, g2, f7, g1, f8, g0, (int32_t)(c16 >> 32), k9728);
 #else
     const int64_t c9 = M64(f1, g8) + M64(f2, g7) + M64(f3, g6) + M64(f4, g5) + M64(f5, g4) + M64(f6, g3) + M64(f7, g2) + M64(f8, g1);
-    const int64_t c10 = (c9 >> 29) + M64(f2, g8) + M64(f3, g7) + M64(f4, g6) + M64(f5, g5) + M64(f6, g4) + M64(f7, g3) + M64(f8, g2);
-    const int64_t c11 = (c10 >> 29) + M64(f3, g8) + M64(f4, g7) + M64(f5, g6) + M64(f6, g5) + M64(f7, g4) + M64(f8, g3);
-    const int64_t c12 = (c11 >> 29) + M64(f4, g8) + M64(f5, g7) + M64(f6, g6) + M64(f7, g5) + M64(f8, g4);
-    const int64_t c13 = (c12 >> 29) + M64(f5, g8) + M64(f6, g7) + M64(f7, g6) + M64(f8, g5);
-    const int64_t c14 = (c13 >> 29) + M64(f6, g8) + M64(f7, g7) + M64(f8, g6);
-    const int64_t c15 = (c14 >> 29) + M64(f7, g8) + M64(f8, g7);
-    const int64_t c16 = (c15 >> 29) + M64(f8, g8);
-    const int32_t h9 = (int32_t)c9 & FE_M29;
-    const int32_t h10 = (int32_t)c10 & FE_M29;
-    const int32_t h11 = (int32_t)c11 & FE_M29;
-    const int32_t h12 = (int32_t)c12 & FE_M29;
-    const int32_t h13 = (int32_t)c13 & FE_M29;
-    const int32_t h14 = (int32_t)c14 & FE_M29;
-    const int32_t h15 = (int32_t)c15 & FE_M29;
-    const int32_t h16 = (int32_t)c16 & FE_M29;
-    const int32_t h17 = (int32_t)(c16 >> 29);
-    const int64_t c0 = M64(f0, g0) + M64(h9, 1216);
-    const int64_t c1 = (c0 >> 29) + M64(f0, g1) + M64(f1, g0) + M64(h10, 1216);
-    const int64_t c2 = (c1 >> 29) + M64(f0, g2) + M64(f1, g1) + M64(f2, g0) + M64(h11, 1216);
-    const int64_t c3 = (c2 >> 29) + M64(f0, g3) + M64(f1, g2) + M64(f2, g1) + M64(f3, g0) + M64(h12, 1216);
-    const int64_t c4 = (c3 >> 29) + M64(f0, g4) + M64(f1, g3) + M64(f2, g2) + M64(f3, g1) + M64(f4, g0) + M64(h13, 1216);
-    const int64_t c5 = (c4 >> 29) + M64(f0, g5) + M64(f1, g4) + M64(f2, g3) + M64(f3, g2) + M64(f4, g1) + M64(f5, g0) + M64(h14, 1216);
-    const int64_t c6 = (c5 >> 29) + M64(f0, g6) + M64(f1, g5) + M64(f2, g4) + M64(f3, g3) + M64(f4, g2) + M64(f5, g1) + M64(f6, g0) + M64(h15, 1216);
-    const int64_t c7 = (c6 >> 29) + M64(f0, g7) + M64(f1, g6) + M64(f2, g5) + M64(f3, g4) + M64(f4, g3) + M64(f5, g2) + M64(f6, g1) + M64(f7, g0) + M64(h16, 1216);
-    const int64_t c8 = (c7 >> 29) + M64(f0, g8) + M64(f1, g7) + M64(f2, g6) + M64(f3, g5) + M64(f4, g4) + M64(f5, g3) + M64(f6, g2) + M64(f7, g1) + M64(f8, g0) + M64(h17, 1216);
+    const int64_t c10 = M64(f2, g8) + M64(f3, g7) + M64(f4, g6) + M64(f5, g5) + M64(f6, g4) + M64(f7, g3) + M64(f8, g2);
+    const int64_t c11 = M64(f3, g8) + M64(f4, g7) + M64(f5, g6) + M64(f6, g5) + M64(f7, g4) + M64(f8, g3);
+    const int64_t c12 = M64(f4, g8) + M64(f5, g7) + M64(f6, g6) + M64(f7, g5) + M64(f8, g4);
+    const int64_t c13 = M64(f5, g8) + M64(f6, g7) + M64(f7, g6) + M64(f8, g5);
+    const int64_t c14 = M64(f6, g8) + M64(f7, g7) + M64(f8, g6);
+    const int64_t c15 = M64(f7, g8) + M64(f8, g7);
+    const int64_t c16 = M64(f8, g8);
+    const int64_t c0 = M64(f0, g0) + (int64_t)((uint64_t)(uint32_t)c9 * 1216u);
+    const int64_t c1 = (c0 >> 29) + M64(f0, g1) + M64(f1, g0) + (int64_t)((uint64_t)(uint32_t)c10 * 1216u) + M64((int32_t)(c9 >> 32), 9728);
+    const int64_t c2 = (c1 >> 29) + M64(f0, g2) + M64(f1, g1) + M64(f2, g0) + (int64_t)((uint64_t)(uint32_t)c11 * 1216u) + M64((int32_t)(c10 >> 32), 9728);
+    const int64_t c3 = (c2 >> 29) + M64(f0, g3) + M64(f1, g2) + M64(f2, g1) + M64(f3, g0) + (int64_t)((uint64_t)(uint32_t)c12 * 1216u) + M64((int32_t)(c11 >> 32), 9728);
+    const int64_t c4 = (c3 >> 29) + M64(f0, g4) + M64(f1, g3) + M64(f2, g2) + M64(f3, g1) + M64(f4, g0) + (int64_t)((uint64_t)(uint32_t)c13 * 1216u) + M64((int32_t)(c12 >> 32), 9728);
+    const int64_t c5 = (c4 >> 29) + M64(f0, g5) + M64(f1, g4) + M64(f2, g3) + M64(f3, g2) + M64(f4, g1) + M64(f5, g0) + (int64_t)((uint64_t)(uint32_t)c14 * 1216u) + M64((int32_t)(c13 >> 32), 9728);
+    const int64_t c6 = (c5 >> 29) + M64(f0, g6) + M64(f1, g5) + M64(f2, g4) + M64(f3, g3) + M64(f4, g2) + M64(f5, g1) + M64(f6, g0) + (int64_t)((uint64_t)(uint32_t)c15 * 1216u) + M64((int32_t)(c14 >> 32), 9728);
+    const int64_t c7 = (c6 >> 29) + M64(f0, g7) + M64(f1, g6) + M64(f2, g5) + M64(f3, g4) + M64(f4, g3) + M64(f5, g2) + M64(f6, g1) + M64(f7, g0) + (int64_t)((uint64_t)(uint32_t)c16 * 1216u) + M64((int32_t)(c15 >> 32), 9728);
+    const int64_t c8 = (c7 >> 29) + M64(f0, g8) + M64(f1, g7) + M64(f2, g6) + M64(f3, g5) + M64(f4, g4) + M64(f5, g3) + M64(f6, g2) + M64(f7, g1) + M64(f8, g0) + M64((int32_t)(c16 >> 32), 9728);
 #endif
     fe_limbs_from_cols(h, c0, c1, c2, c3, c4, c5, c6, c7, c8);
 }
@@ -315,60 +382,42 @@ DAPOL_HD void fe_sq(fe& h, const fe& f) {
     const int32_t f0 = f.v[0], f1 = f.v[1], f2 = f.v[2], f3 = f.v[3], f4 = f.v[4], f5 = f.v[5], f6 = f.v[6], f7 = f.v[7], f8 = f.v[8];
     const int32_t f0_2 = 2 * f0, f1_2 = 2 * f1, f2_2 = 2 * f2, f3_2 = 2 * f3, f4_2 = 2 * f4, f5_2 = 2 * f5, f6_2 = 2 * f6, f7_2 = 2 * f7;
 #if defined(DAPOL_MAD_CHAIN)
-    const int32_t k1216 = 1216;
+    const int32_t k1216 = 1216, k9728 = 9728;
     const int64_t c9 = mad4z(f1_2, f8, f2_2, f7, f3_2, f6, f4_2, f5);
-    const int64_t c10 = mad4c(c9 >> 29, f2_2, f8, f3_2, f7, f4_2, f6, f5, f5);
-    const int64_t c11 = mad3c(c10 >> 29, f3_2, f8, f4_2, f7, f5_2, f6);
-    const int64_t c12 = mad3c(c11 >> 29, f4_2, f8, f5_2, f7, f6, f6);
-    const int64_t c13 = mad2c(c12 >> 29, f5_2, f8, f6_2, f7);
-    const int64_t c14 = mad2c(c13 >> 29, f6_2, f8, f7, f7);
-    const int64_t c15 = mad1c(c14 >> 29, f7_2, f8);
-    const int64_t c16 = mad1c(c15 >> 29, f8, f8);
-    const int32_t h9 = (int32_t)c9 & FE_M29;
-    const int32_t h10 = (int32_t)c10 & FE_M29;
-    const int32_t h11 = (int32_t)c11 & FE_M29;
-    const int32_t h12 = (int32_t)c12 & FE_M29;
-    const int32_t h13 = (int32_t)c13 & FE_M29;
-    const int32_t h14 = (int32_t)c14 & FE_M29;
-    const int32_t h15 = (int32_t)c15 & FE_M29;
-    const int32_t h16 = (int32_t)c16 & FE_M29;
-    const int32_t h17 = (int32_t)(c16 >> 29);
-    const int64_t c0 = mad2z(f0, f0, h9, k1216);
-    const int64_t c1 = mad2c(c0 >> 29, f0_2, f1, h10, k1216);
-    const int64_t c2 = mad3c(c1 >> 29, f0_2, f2, f1, f1, h11, k1216);
-    const int64_t c3 = mad3c(c2 >> 29, f0_2, f3, f1_2, f2, h12, k1216);
-    const int64_t c4 = mad4c(c3 >> 29, f0_2, f4, f1_2, f3, f2, f2, h13, k1216);
-    const int64_t c5 = mad4c(c4 >> 29, f0_2, f5, f1_2, f4, f2_2, f3, h14, k1216);
-    const int64_t c6 = mad5c(c5 >> 29, f0_2, f6, f1_2, f5, f2_2, f4, f3, f3, h15, k1216);
-    const int64_t c7 = mad5c(c6 >> 29, f0_2, f7, f1_2, f6, f2_2, f5, f3_2, f4, h16, k1216);
-    const int64_t c8 = mad6c(c7 >> 29, f0_2, f8, f1_2, f7, f2_2, f6, f3_2, f5, f4, f4, h17, k1216);
+    const int64_t c10 = mad4z(f2_2, f8, f3_2, f7, f4_2, f6, f5, f5);
+    const int64_t c11 = mad3z(f3_2, f8, f4_2, f7, f5_2, f6);
+    const int64_t c12 = mad3z(f4_2, f8, f5_2, f7, f6, f6);
+    const int64_t c13 = mad2z(f5_2, f8, f6_2, f7);
+    const int64_t c14 = mad2z(f6_2, f8, f7, f7);
+    const int64_t c15 = mad1z(f7_2, f8);
+    const int64_t c16 = mad1z(f8, f8);
+    const int64_t c0 = mad1zl(f0, f0, (uint32_t)c9, k1216);
+    const int64_t c1 = mad1clh(c0 >> 29, f0_2, f1, (uint32_t)c10, k1216, (int32_t)(c9 >> 32), k9728);
+    const int64_t c2 = mad2clh(c1 >> 29, f0_2, f2, f1, f1, (uint32_t)c11, k1216, (int32_t)(c10 >> 32), k9728);
+    const int64_t c3 = mad2clh(c2 >> 29, f0_2, f3, f1_2, f2, (uint32_t)c12, k1216, (int32_t)(c11 >> 32), k9728);
+    const int64_t c4 = mad3clh(c3 >> 29, f0_2, f4, f1_2, f3, f2, f2, (uint32_t)c13, k1216, (int32_t)(c12 >> 32), k9728);
+    const int64_t c5 = mad3clh(c4 >> 29, f0_2, f5, f1_2, f4, f2_2, f3, (uint32_t)c14, k1216, (int32_t)(c13 >> 32), k9728);
+    const int64_t c6 = mad4clh(c5 >> 29, f0_2, f6, f1_2, f5, f2_2, f4, f3, f3, (uint32_t)c15, k1216, (int32_t)(c14 >> 32), k9728);
+    const int64_t c7 = mad4clh(c6 >> 29, f0_2, f7, f1_2, f6, f2_2, f5, f3_2, f4, (uint32_t)c16, k1216, (int32_t)(c15 >> 32), k9728);
+    const int64_t c8 = mad5ch(c7 >> 29, f0_2, f8, f1_2, f7, f2_2, f6, f3_2, f5, f4, f4, (int32_t)(c16 >> 32), k9728);
 #else
     const int64_t c9 = M64(f1_2, f8) + M64(f2_2, f7) + M64(f3_2, f6) + M64(f4_2, f5);
-    const int64_t c10 = (c9 >> 29) + M64(f2_2, f8) + M64(f3_2, f7) + M64(f4_2, f6) + M64(f5, f5);
-    const int64_t c11 = (c10 >> 29) + M64(f3_2, f8) + M64(f4_2, f7) + M64(f5_2, f6);
-    const int64_t c12 = (c11 >> 29) + M64(f4_2, f8) + M64(f5_2, f7) + M64(f6, f6);
-    const int64_t c13 = (c12 >> 29) + M64(f5_2, f8) + M64(f6_2, f7);
-    const int64_t c14 = (c13 >> 29) + M64(f6_2, f8) + M64(f7, f7);
-    const int64_t c15 = (c14 >> 29) + M64(f7_2, f8);
-    const int64_t c16 = (c15 >> 29) + M64(f8, f8);
-    const int32_t h9 = (int32_t)c9 & FE_M29;
-    const int32_t h10 = (int32_t)c10 & FE_M29;
-    const int32_t h11 = (int32_t)c11 & FE_M29;
-    const int32_t h12 = (int32_t)c12 & FE_M29;
-    const int32_t h13 = (int32_t)c13 & FE_M29;
-    const int32_t h14 = (int32_t)c14 & FE_M29;
-    const int32_t h15 = (int32_t)c15 & FE_M29;
-    const int32_t h16 = (int32_t)c16 & FE_M29;
-    const int32_t h17 = (int32_t)(c16 >> 29);
-    const int64_t c0 = M64(f0, f0) + M64(h9, 1216);
-    const int64_t c1 = (c0 >> 29) + M64(f0_2, f1) + M64(h10, 1216);
-    const int64_t c2 = (c1 >> 29) + M64(f0_2, f2) + M64(f1, f1) + M64(h11, 1216);
-    const int64_t c3 = (c2 >> 29) + M64(f0_2, f3) + M64(f1_2, f2) + M64(h12, 1216);
-    const int64_t c4 = (c3 >> 29) + M64(f0_2, f4) + M64(f1_2, f3) + M64(f2, f2) + M64(h13, 1216);
-    const int64_t c5 = (c4 >> 29) + M64(f0_2, f5) + M64(f1_2, f4) + M64(f2_2, f3) + M64(h14, 1216);
-    const int64_t c6 = (c5 >> 29) + M64(f0_2, f6) + M64(f1_2, f5) + M64(f2_2, f4) + M64(f3, f3) + M64(h15, 1216);
-    const int64_t c7 = (c6 >> 29) + M64(f0_2, f7) + M64(f1_2, f6) + M64(f2_2, f5) + M64(f3_2, f4) + M64(h16, 1216);
-    const int64_t c8 = (c7 >> 29) + M64(f0_2, f8) + M64(f1_2, f7) + M64(f2_2, f6) + M64(f3_2, f5) + M64(f4, f4) + M64(h17, 1216);
+    const int64_t c10 = M64(f2_2, f8) + M64(f3_2, f7) + M64(f4_2, f6) + M64(f5, f5);
+    const int64_t c11 = M64(f3_2, f8) + M64(f4_2, f7) + M64(f5_2, f6);
+    const int64_t c12 = M64(f4_2, f8) + M64(f5_2, f7) + M64(f6, f6);
+    const int64_t c13 = M64(f5_2, f8) + M64(f6_2, f7);
+    const int64_t c14 = M64(f6_2, f8) + M64(f7, f7);
+    const int64_t c15 = M64(f7_2, f8);
+    const int64_t c16 = M64(f8, f8);
+    const int64_t c0 = M64(f0, f0) + (int64_t)((uint64_t)(uint32_t)c9 * 1216u);
+    const int64_t c1 = (c0 >> 29) + M64(f0_2, f1) + (int64_t)((uint64_t)(uint32_t)c10 * 1216u) + M64((int32_t)(c9 >> 32), 9728);
+    const int64_t c2 = (c1 >> 29) + M64(f0_2, f2) + M64(f1, f1) + (int64_t)((uint64_t)(uint32_t)c11 * 1216u) + M64((int32_t)(c10 >> 32), 9728);
+    const int64_t c3 = (c2 >> 29) + M64(f0_2, f3) + M64(f1_2, f2) + (int64_t)((uint64_t)(uint32_t)c12 * 1216u) + M64((int32_t)(c11 >> 32), 9728);
+    const int64_t c4 = (c3 >> 29) + M64(f0_2, f4) + M64(f1_2, f3) + M64(f2, f2) + (int64_t)((uint64_t)(uint32_t)c13 * 1216u) + M64((int32_t)(c12 >> 32), 9728);
+    const int64_t c5 = (c4 >> 29) + M64(f0_2, f5) + M64(f1_2, f4) + M64(f2_2, f3) + (int64_t)((uint64_t)(uint32_t)c14 * 1216u) + M64((int32_t)(c13 >> 32), 9728);
+    const int64_t c6 = (c5 >> 29) + M64(f0_2, f6) + M64(f1_2, f5) + M64(f2_2, f4) + M64(f3, f3) + (int64_t)((uint64_t)(uint32_t)c15 * 1216u) + M64((int32_t)(c14 >> 32), 9728);
+    const int64_t c7 = (c6 >> 29) + M64(f0_2, f7) + M64(f1_2, f6) + M64(f2_2, f5) + M64(f3_2, f4) + (int64_t)((uint64_t)(uint32_t)c16 * 1216u) + M64((int32_t)(c15 >> 32), 9728);
+    const int64_t c8 = (c7 >> 29) + M64(f0_2, f8) + M64(f1_2, f7) + M64(f2_2, f6) + M64(f3_2, f5) + M64(f4, f4) + M64((int32_t)(c16 >> 32), 9728);
 #endif
     fe_limbs_from_cols(h, c0, c1, c2, c3, c4, c5, c6, c7, c8);
 }
