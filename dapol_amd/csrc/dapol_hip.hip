@@ -130,7 +130,7 @@ int32_t dapol_ctx_create(int32_t device, int32_t max_parties, int32_t digest_id,
         // cap more resident wavefronts are not automatically faster, profiles/r01_madchain_ab.txt).
         if (const char* e = getenv("DAPOL_MSM_OCC_CAP")) {
             int cap = atoi(e);
-            const size_t lds_cu = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 163840, stat = sizeof(int32_t) * 4 * FE_NL * 64;
+            const size_t lds_cu = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 163840, stat = 0;   // (the kernel itself uses no LDS)
             if (cap >= 1 && cap <= 8) {
                 size_t per_block = lds_cu / (size_t)(4 * cap) / 512 * 512;          // LDS is granted in 512-byte granules
                 if (per_block > stat) c->msm_dyn_lds = (unsigned)(per_block - stat);

@@ -153,27 +153,20 @@ __device__ __forceinline__ int gen_row(const TableView& t, int n, int j, bool is
 }
 
 // ----------------------------------------------------------------------------------------- wave reductions
-__device__ __forceinline__ void wave_reduce_point(ge_p3& acc, int32_t* lds /*[4 * FE_NL][64]*/, int lane, int width) {
+// Sum of one point per lane over groups of `width` adjacent lanes (a power of two <= 64), by wavefront shuffles: every step
+// brings the partner's 36 limbs over with __shfl_down (DPP / ds_bpermute, no LDS round trip, no barrier) and adds.  The lane
+// whose index is a multiple of `width` ends with the group's sum; the other lanes hold partial sums nobody reads.
+__device__ __forceinline__ void wave_reduce_point(ge_p3& acc, int width) {
     for (int off = width >> 1; off >= 1; off >>= 1) {
+        ge_p3 o, r;
         for (int i = 0; i < FE_NL; i++) {
-            lds[(i)*64 + lane] = acc.X.v[i];
-            lds[(FE_NL + i) * 64 + lane] = acc.Y.v[i];
-            lds[(2 * FE_NL + i) * 64 + lane] = acc.Z.v[i];
-            lds[(3 * FE_NL + i) * 64 + lane] = acc.T.v[i];
+            o.X.v[i] = __shfl_down(acc.X.v[i], off, 64);
+            o.Y.v[i] = __shfl_down(acc.Y.v[i], off, 64);
+            o.Z.v[i] = __shfl_down(acc.Z.v[i], off, 64);
+            o.T.v[i] = __shfl_down(acc.T.v[i], off, 64);
         }
-        __syncthreads();
-        if ((lane & (width - 1)) < off) {
-            ge_p3 o, r;
-            for (int i = 0; i < FE_NL; i++) {
-                o.X.v[i] = lds[(i)*64 + lane + off];
-                o.Y.v[i] = lds[(FE_NL + i) * 64 + lane + off];
-                o.Z.v[i] = lds[(2 * FE_NL + i) * 64 + lane + off];
-                o.T.v[i] = lds[(3 * FE_NL + i) * 64 + lane + off];
-            }
-            ge_add(r, acc, o);
-            acc = r;
-        }
-        __syncthreads();
+        ge_add(r, acc, o);
+        acc = r;
     }
 }
 // Sum of one scalar per lane over the wavefront, by wavefront shuffles (DPP / ds_bpermute; no LDS round trip, no barrier):
@@ -205,7 +198,6 @@ __global__ __launch_bounds__(64) void k_rp_nonces(RangeArgs A) {
 
 // ------------------------------------------------------------------------- K1: A = sum_i (bit ? G_i : -H_i)
 __global__ __launch_bounds__(64) void k_rp_A(RangeArgs A, TableView tbl) {
-    __shared__ int32_t lds[4 * FE_NL * 64];
     size_t b = blockIdx.x;
     int l = threadIdx.x;
     ge_p3 acc;
@@ -215,7 +207,7 @@ __global__ __launch_bounds__(64) void k_rp_A(RangeArgs A, TableView tbl) {
         int bit = (int)((A.vals[b * A.m + j] >> ii) & 1ull);
         tbl_madd(acc, tbl, bit ? tbl.row_G(j, ii) : tbl.row_H(j, ii), bit ? 1 : -1);
     }
-    wave_reduce_point(acc, lds, l, 64);
+    wave_reduce_point(acc, 64);
     if (l == 0) st_p3(A.PA + b * 40, acc);
 }
 
@@ -234,7 +226,6 @@ __global__ __launch_bounds__(64, DAPOL_MSM_OCC) void k_rp_msm(RangeArgs A, Table
     // at LPL = 32) over more mixed adds.  The digit layout is the same for every LPL.
     // MODE: MSM_PLAIN -> P0 / P1;  MSM_MATERIALIZE -> the 64 per-lane sums are kept (folded generators; T / 32 blocks
     // per proof, block c taking every (T/32)-th term);  MSM_TAIL -> the table is the PROOF's own (2N rows).
-    __shared__ int32_t lds[4 * FE_NL * 64];
     constexpr int PPW = 32 / LPL;
     int l = threadIdx.x;
     int sub = l / (2 * LPL), ll = l % (2 * LPL), side = ll / LPL, ql = ll % LPL;
@@ -328,7 +319,7 @@ __global__ __launch_bounds__(64, DAPOL_MSM_OCC) void k_rp_msm(RangeArgs A, Table
         const int T = A.tail_n;
         st_p3(A.tailT + (b * (size_t)(2 * T) + (size_t)(side * T + ql + 32 * i_begin)) * TAIL_ROW_WORDS, acc);
     } else {
-        wave_reduce_point(acc, lds, l, LPL);
+        wave_reduce_point(acc, LPL);
         if (ql == 0 && valid) st_p3((side ? A.P1 : A.P0) + (b * nsplit + split) * 40, acc);
     }
 }

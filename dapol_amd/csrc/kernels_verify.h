@@ -464,7 +464,6 @@ __device__ __forceinline__ void ge_scalarmul_vartime(ge_p3& out, const ge_p3& p,
     out = acc;
 }
 __global__ __launch_bounds__(64) void k_rv_varpoints(VerifyArgs V) {
-    __shared__ int32_t lds[4 * FE_NL * 64];
     const RangeArgs& A = V.R;
     size_t b = blockIdx.x;
     int l = threadIdx.x;
@@ -484,7 +483,7 @@ __global__ __launch_bounds__(64) void k_rv_varpoints(VerifyArgs V) {
         ge_add(r, acc, q);
         acc = r;
     }
-    wave_reduce_point(acc, lds, l, 64);
+    wave_reduce_point(acc, 64);
     if (l == 0) st_p3(A.PA + b * 40, acc);
     if (!ok) atomicAnd(&V.vs[b].ok, 0u);
 }
@@ -914,7 +913,6 @@ __global__ __launch_bounds__(64) void k_rvp_scatter(RlcArgs R) {
 }
 // Bucket sums: RVP_S adjacent lanes share a bucket (every RVP_S-th point each), then a tree reduction.  grid = NW * NB * S / 64.
 __global__ __launch_bounds__(64) void k_rvp_buckets(RlcArgs R) {
-    __shared__ int32_t lds[4 * FE_NL * 64];
     const int l = threadIdx.x;
     const size_t gid = (size_t)blockIdx.x * 64 + l;
     const int s = (int)(gid % RVP_S), bidx = (int)((gid / RVP_S) % RVP_NB), w = (int)(gid / ((size_t)RVP_S * RVP_NB));
@@ -928,13 +926,12 @@ __global__ __launch_bounds__(64) void k_rvp_buckets(RlcArgs R) {
         niels_load_entry(q, R.pN + (size_t)(e & 0x7fffffffu) * 32);
         ge_madd(acc, acc, q, (e >> 31) != 0);
     }
-    wave_reduce_point(acc, lds, l, RVP_S);
+    wave_reduce_point(acc, RVP_S);
     if (s == 0) st_p3(R.pbsum + ((size_t)w * RVP_NB + bidx) * 40, acc);
 }
 // Window sums: W_w = sum_k k B_k, scaled by 2^(C w), into Q0[w] (Q1[w] = identity) for k_rvb_finish.  One wavefront per
 // window: lane l owns the L = NB / 64 buckets of weights l L + 1 .. l L + L.
 __global__ __launch_bounds__(64) void k_rvp_window(RlcArgs R) {
-    __shared__ int32_t lds[4 * FE_NL * 64];
     const int w = blockIdx.x, l = threadIdx.x, L = RVP_NB / 64;
     ge_p3 run, aseg, b, t;
     ge_identity(run);
@@ -950,10 +947,10 @@ __global__ __launch_bounds__(64) void k_rvp_window(RlcArgs R) {
     for (int j = 5; j >= 0; j--) {
         ge_p3 m;
         if ((l >> j) & 1) m = run; else ge_identity(m);
-        wave_reduce_point(m, lds, l, 64);
+        wave_reduce_point(m, 64);
         if (l == 0) { ge_dbl(t, U, true); ge_add(U, t, m); }
     }
-    wave_reduce_point(aseg, lds, l, 64);
+    wave_reduce_point(aseg, 64);
     if (l == 0) {
         for (int i = 1; i < L; i <<= 1) { ge_dbl(t, U, 2 * i >= L); U = t; }  // times L
         ge_add(t, aseg, U);
@@ -966,7 +963,6 @@ __global__ __launch_bounds__(64) void k_rvp_window(RlcArgs R) {
 }
 // Sums everything and tests for the identity (one wavefront).
 __global__ __launch_bounds__(64) void k_rvb_finish(RlcArgs R, TableView tbl) {
-    __shared__ int32_t lds[4 * FE_NL * 64];
     const RangeArgs& A = R.V.R;
     int l = threadIdx.x;
     const int ns1 = A.nsplit > 1 ? A.nsplit : 1;
@@ -979,7 +975,7 @@ __global__ __launch_bounds__(64) void k_rvb_finish(RlcArgs R, TableView tbl) {
         ge_add(t, acc, p);
         acc = t;
     }
-    wave_reduce_point(acc, lds, l, 64);
+    wave_reduce_point(acc, 64);
     sc bb, bs, x;
     sc_zero(bb); sc_zero(bs);
     for (size_t i = l; i < A.B; i += 64) {

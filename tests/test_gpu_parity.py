@@ -101,7 +101,7 @@ def test_entity_proofs_golden_both_policies(gpu_ctx, hip_lib):
 
 
 # ------------------------------------------------------------------------------------------------ vs the C oracle, seeded
-@pytest.mark.parametrize("height,n", [(12, 700), (24, 4096), (32, 2048), (64, 300)])
+@pytest.mark.parametrize("height,n", [(1, 1), (1, 2), (2, 3), (11, 2048), (12, 700), (24, 4096), (32, 2048), (64, 300)])
 def test_tree_vs_oracle_random(gpu_ctx, hip_lib, ref, height, n):
     rng = np.random.default_rng(height * 1000 + n)
     idx, v, r = _rand_leaves(rng, height, n)
