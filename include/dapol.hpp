@@ -125,11 +125,70 @@ inline RangeProofs generate_proof(const Context& ctx, Policy policy, const std::
     return out;
 }
 
+// DapolProof::serialize / deserialize (src/proof/mod.rs:68-85): range_proof || merkle_path, shared by the two proof shapes
+// below.  Deserialisation throws DapolError with DecodingError's codes (BytesNotEnough / ValueDecodingError); every sibling
+// commitment is decompress-validated on the GPU (src/proof/node.rs:88-94).
+inline std::vector<uint8_t> proof_serialize(int height, const std::vector<uint64_t>& leaves, const std::vector<DapolProofNode>& siblings, Policy policy,
+                                            size_t aggregation_factor, int n_bits, const std::vector<uint8_t>& range_proofs) {
+    size_t S = siblings.size(), n = dapol_proof_wire_size(height, leaves.size(), S, (int)policy, (int)aggregation_factor, n_bits);
+    if (n == 0) throw DapolError(DAPOL_ERR_INVALID_ARGUMENT);
+    std::vector<uint8_t> C(S * 32 + 1), H(S * 32 + 1), wire(n);
+    for (size_t i = 0; i < S; i++) { std::memcpy(&C[i * 32], siblings[i].com.data(), 32); std::memcpy(&H[i * 32], siblings[i].hash.data(), 32); }
+    check(dapol_proof_serialize(height, leaves.size(), leaves.data(), S, C.data(), H.data(), (int)policy, (int)aggregation_factor, n_bits, range_proofs.data(),
+                                wire.data()));
+    return wire;
+}
+struct DecodedProof {
+    int height = 0;
+    size_t aggregation_factor = 0;
+    std::vector<uint64_t> leaves;
+    std::vector<DapolProofNode> siblings;
+    std::vector<uint8_t> range_proofs;
+};
+inline DecodedProof proof_deserialize(const Context& ctx, Policy policy, int n_bits, const std::vector<uint8_t>& wire) {
+    int32_t h = 0, agg = 0;
+    size_t k = 0, S = 0, bl = 0;
+    check(dapol_proof_deserialize(ctx.get(), (int)policy, n_bits, wire.data(), wire.size(), &h, &k, &S, &agg, &bl, nullptr, nullptr, nullptr, nullptr, nullptr));
+    DecodedProof d;
+    d.height = h; d.aggregation_factor = (size_t)agg;
+    d.leaves.resize(k); d.siblings.resize(S); d.range_proofs.resize(bl);
+    std::vector<uint8_t> C(S * 32 + 1), H(S * 32 + 1);
+    std::vector<uint64_t> leaf(k + 1);
+    std::vector<uint8_t> blob(bl + 1);
+    check(dapol_proof_deserialize(ctx.get(), (int)policy, n_bits, wire.data(), wire.size(), &h, &k, &S, &agg, &bl, leaf.data(), C.data(), H.data(), blob.data(), nullptr));
+    for (size_t i = 0; i < k; i++) d.leaves[i] = leaf[i];
+    for (size_t i = 0; i < S; i++) { std::memcpy(d.siblings[i].com.data(), &C[i * 32], 32); std::memcpy(d.siblings[i].hash.data(), &H[i * 32], 32); }
+    std::memcpy(d.range_proofs.data(), blob.data(), bl);
+    return d;
+}
+
 // DapolProof<D, R> (src/proof/mod.rs:15-22) for single leaves: Merkle siblings (root side first) + range proofs.
 struct DapolProof {
     uint64_t leaf_index = 0;
     std::vector<DapolProofNode> merkle_siblings;
     std::vector<uint8_t> range_proofs;           // aggregated proofs then individual proofs, concatenated
+    Policy policy = Policy::Padding;
+    size_t aggregation_factor = 0;
+    int n_bits = 64, height = 0;
+    std::vector<uint8_t> serialize() const { return proof_serialize(height, {leaf_index}, merkle_siblings, policy, aggregation_factor, n_bits, range_proofs); }
+    static DapolProof deserialize(const Context& ctx, Policy policy, int n_bits, const std::vector<uint8_t>& wire) {
+        DecodedProof d = proof_deserialize(ctx, policy, n_bits, wire);
+        if (d.leaves.size() != 1) throw DapolError(DAPOL_ERR_VALUE_DECODING);
+        DapolProof p;
+        p.leaf_index = d.leaves[0]; p.merkle_siblings = std::move(d.siblings); p.range_proofs = std::move(d.range_proofs);
+        p.policy = policy; p.aggregation_factor = d.aggregation_factor; p.n_bits = n_bits; p.height = d.height;
+        return p;
+    }
+    // DapolProof::verify (src/proof/mod.rs:41-47)
+    bool verify(const Context& ctx, const DapolProofNode& root, const DapolProofNode& leaf) const {
+        size_t h = merkle_siblings.size();
+        std::vector<uint8_t> C(h * 32 + 1), H(h * 32 + 1);
+        for (size_t i = 0; i < h; i++) { std::memcpy(&C[i * 32], merkle_siblings[i].com.data(), 32); std::memcpy(&H[i * 32], merkle_siblings[i].hash.data(), 32); }
+        uint8_t ok = 0;
+        check(dapol_verify_entities(ctx.get(), height, 1, &leaf_index, leaf.com.data(), leaf.hash.data(), C.data(), H.data(), root.com.data(), root.hash.data(),
+                                    (int)policy, (int)aggregation_factor, n_bits, range_proofs.data(), nullptr, &ok));
+        return ok != 0;
+    }
 };
 // DapolProof<D, R> made by generate_proof_batch: MerkleProof::new_batch(leaf indexes) + the deduplicated siblings
 // (level by level from the root side, left to right) + the range proofs over exactly those siblings.
@@ -140,6 +199,14 @@ struct DapolBatchProof {
     Policy policy = Policy::Padding;
     size_t aggregation_factor = 0;
     int n_bits = 64, height = 0;
+    std::vector<uint8_t> serialize() const { return proof_serialize(height, leaf_indexes, merkle_siblings, policy, aggregation_factor, n_bits, range_proofs); }
+    static DapolBatchProof deserialize(const Context& ctx, Policy policy, int n_bits, const std::vector<uint8_t>& wire) {
+        DecodedProof d = proof_deserialize(ctx, policy, n_bits, wire);
+        DapolBatchProof p;
+        p.leaf_indexes = std::move(d.leaves); p.merkle_siblings = std::move(d.siblings); p.range_proofs = std::move(d.range_proofs);
+        p.policy = policy; p.aggregation_factor = d.aggregation_factor; p.n_bits = n_bits; p.height = d.height;
+        return p;
+    }
     // DapolProof::verify_batch (src/proof/mod.rs:49-54)
     // Without a seed the library draws the verifier's batching scalars' seed from the OS (the crate uses thread_rng).
     bool verify_batch(const Context& ctx, const DapolProofNode& root, const std::vector<DapolProofNode>& leaves) const {
@@ -319,6 +386,7 @@ class Dapol {
                 std::memcpy(out[e].merkle_siblings[s].hash.data(), &H[(e * h + s) * 32], 32);
             }
             out[e].range_proofs.assign(R.begin() + e * es, R.begin() + (e + 1) * es);
+            out[e].policy = policy_; out[e].aggregation_factor = aggregation_factor_; out[e].n_bits = n_bits; out[e].height = height_;
         }
         return out;
     }

@@ -67,6 +67,19 @@ int main(int argc, char** argv) {
         std::swap(lv[0], lv[1]);
         if (bp->verify_batch(*ctx, bd.root(), lv, seed)) { std::printf("FAIL batch verify accepted swapped leaves\n"); return 1; }
         if (bd.generate_proof_batch({3, 41}, seed, 8)) { std::printf("FAIL batch none\n"); return 1; }
+        // src/proof/tests.rs:6-35: serialize -> deserialize -> verify_batch; and the single-leaf flavour (src/tests.rs:72-93)
+        std::swap(lv[0], lv[1]);
+        std::vector<uint8_t> wire = bp->serialize();
+        DapolBatchProof back = DapolBatchProof::deserialize(*ctx, Policy::Splitting, 8, wire);
+        if (back.leaf_indexes != bp->leaf_indexes || back.range_proofs != bp->range_proofs || back.aggregation_factor != 2 ||
+            !back.verify_batch(*ctx, bd.root(), lv)) { std::printf("FAIL batch wire round trip\n"); return 1; }
+        auto sp = bd.generate_proof(40, seed, 8);
+        DapolProof sback = DapolProof::deserialize(*ctx, Policy::Splitting, 8, sp->serialize());
+        if (sback.leaf_index != 40 || !sback.verify(*ctx, bd.root(), lv[1])) { std::printf("FAIL single wire round trip\n"); return 1; }
+        if (sback.verify(*ctx, bd.root(), lv[0])) { std::printf("FAIL single verify accepted another leaf\n"); return 1; }
+        wire.pop_back();
+        try { DapolBatchProof::deserialize(*ctx, Policy::Splitting, 8, wire); std::printf("FAIL truncated accepted\n"); return 1; }
+        catch (const DapolError& e) { if (e.code != DAPOL_ERR_BYTES_NOT_ENOUGH) { std::printf("FAIL truncated code %d\n", e.code); return 1; } }
     }
     {   // src/dapol/tests.rs:18-107 with Dapol::<blake2::Blake2s, RangeProofPadding>::new
         auto c2 = std::make_shared<Context>(0, 8, DAPOL_DIGEST_BLAKE2S);
