@@ -5,6 +5,8 @@ generation (one padding-policy inclusion proof per entity, aggregation_factor = 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--budget-s S]      (N > 1: launched by torch.distributed.run)
   python bench.py --mode build      the reference's `build` criterion group (benches/dapol.rs:24-57) on the GPU
   python bench.py --mode verify     BASELINE configs[4]: verification-only, aggregated proofs of 1,024 parties
+  python bench.py --mode criterion  the reference's three criterion groups as it defines them (benches/dapol.rs:24-141):
+                                    build, prove (ONE inclusion proof per iteration), verify; N = 1,024, heights 16 / 24 / 32
 
 A step = one pass of the hot path over the whole synthetic entity set, inputs already resident in HBM:
 tree build (commit + hash + merge, padding nodes made on the fly) followed by one aggregated Bulletproof per
@@ -564,12 +566,91 @@ def mode_verify(args):
                       "cpu_baseline": cpu}), flush=True)
 
 
+def _plan(policy, n, agg):
+    """(start, count, parties) of the aggregated sub-proofs + the individual ones (padding.rs:88-118, splitting.rs:100-129)."""
+    out = []
+    if policy == 0:
+        out.append((0, agg, _np2(agg)))
+    else:
+        base, pos = _np2(agg), 0
+        while pos < agg:
+            if agg & base:
+                out.append((pos, base, base))
+                pos += base
+            base >>= 1
+    return out + [(i, 1, 1) for i in range(agg, n)]
+
+
+def mode_criterion(args):
+    """benches/dapol.rs as the reference defines it: group `build` (:24-57), group `prove` (:59-91: Dapol::generate_proof of one
+    random leaf per iteration, N = 1,024, heights 16 / 24 / 32, RangeProofSplitting and RangeProofPadding, aggregation_factor =
+    height) and group `verify` (:93-141: DapolProof::verify of such a proof).  These are LATENCY measurements of single calls
+    (host-inclusive: the proof comes back to the host), median of 10 like criterion's sample_size(10).  CPU beside each: the C
+    restatement, single-threaded like the reference, faithful (per-call generators)."""
+    import torch
+    from __graft_entry__ import build, ORACLE_LIB
+    build()
+    from dapol_amd import capi
+    ctx = capi.Context(0, 32)
+    ref = None
+    if not args.no_cpu_baseline and os.path.exists(ORACLE_LIB):
+        native, _ = build_native_oracle()
+        ref = ctypes.CDLL(native or ORACLE_LIB)
+        ref.ref_range_proof_size.restype = ctypes.c_size_t
+        if hasattr(ref, "ref_set_threads"):
+            ref.ref_set_threads(1)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    rng = np.random.default_rng(0xD4)
+    n, n_bits, rows = 1024, 64, []
+    for height in (16, 24, 32):
+        idx, v, r = synth_inputs(n, height, 0, n)
+        tree = capi.Tree(ctx, height, idx, v, r, PAD_SEED)
+        rC, rH, _, _ = tree.root()
+        lC, lH = ctx.commit_hash_batch(v, r)
+        for pol, name in ((capi.POLICY_SPLITTING, "splitting"), (capi.POLICY_PADDING, "padding")):
+            picks = rng.integers(0, n, size=11)
+            tp, tv = [], []
+            for it, k in enumerate(picks):
+                leaf = idx[k:k + 1]
+                t0 = time.perf_counter()
+                pC, pH, proofs = tree.prove_entities(leaf, pol, height, n_bits, NONCE_SEED)
+                t1 = time.perf_counter()
+                ok = ctx.verify_entities(height, leaf, lC[k:k + 1], lH[k:k + 1], pC, pH, rC, rH, pol, height, n_bits, proofs)
+                t2 = time.perf_counter()
+                assert ok.all()
+                if it:                                              # the first iteration warms the call path up
+                    tp.append(t1 - t0)
+                    tv.append(t2 - t1)
+            row = {"height": height, "policy": name, "prove_ms": 1e3 * sorted(tp)[len(tp) // 2], "verify_ms": 1e3 * sorted(tv)[len(tv) // 2],
+                   "proof_bytes": int(proofs.shape[1])}
+            if ref is not None:
+                _, _, sv, sr = tree.paths(idx[picks[0]:picks[0] + 1])
+                t0 = time.perf_counter()
+                slot = 0
+                for start, cnt, m in _plan(pol, height, height):
+                    pv, pr = np.zeros(m, np.uint64), np.zeros((m, 32), np.uint8)
+                    pv[:cnt], pr[:cnt] = sv[0, start:start + cnt], sr[0, start:start + cnt]
+                    pr[cnt:, 0] = 1
+                    out = ctypes.create_string_buffer(ref.ref_range_proof_size(n_bits, m))
+                    ref.ref_range_prove(n_bits, m, p(pv), p(pr), NONCE_SEED, ctypes.c_uint64(int(idx[picks[0]])), ctypes.c_uint64(slot), None, 1, out)
+                    slot += m * (2 * n_bits + 4)
+                row["cpu_prove_1thread_faithful_ms"] = 1e3 * (time.perf_counter() - t0)
+            rows.append(row)
+            log("prove/%s/%d: %.2f ms, verify: %.2f ms" % (name, height, row["prove_ms"], row["verify_ms"]))
+        tree.close()
+    print(json.dumps({"metric": "criterion groups of the reference (benches/dapol.rs:59-141): latency of ONE generate_proof / verify, ms",
+                      "unit": "ms", "higher_is_better": False, "n_gpus": 1, "data": "synthetic", "dtype": "int32 limbs (255-bit modular integers)",
+                      "config": {"workload": "N = 1,024 strided leaves, heights 16 / 24 / 32, 64-bit proofs, aggregation_factor = height, BLAKE3"},
+                      "value": [r_["prove_ms"] for r_ in rows if r_["height"] == 32 and r_["policy"] == "padding"][0],
+                      "prove_verify": rows, "build": "python bench.py --mode build"}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--mode", choices=("prove", "build", "verify"), default="prove")
+    ap.add_argument("--mode", choices=("prove", "build", "verify", "criterion"), default="prove")
     ap.add_argument("--budget-s", type=float, default=450.0,
                     help="wall budget of the whole process, counted from its start; the timed steps are clamped to fit (>= 3)")
     ap.add_argument("--cpu-budget-s", type=float, default=10.0, help="wall budget of the CPU-baseline leg")
@@ -587,6 +668,8 @@ def main():
         return mode_build(args)
     if args.mode == "verify":
         return mode_verify(args)
+    if args.mode == "criterion":
+        return mode_criterion(args)
     return mode_prove(args)
 
 
