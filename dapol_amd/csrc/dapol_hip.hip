@@ -283,6 +283,7 @@ struct dapol_tree {
     uint64_t n_pad = 0, n_real = 0;
     int index_bits = 0, shard_bits = 0;          // what the tree was built with (dapol_tree_update rebuilds with the same)
     uint8_t pad_seed[32] = {0};
+    DevBuf<LevelView> d_views;         // view(0..height, nullptr) on the device, for kernels that walk several levels
     LevelView view(int k, int32_t* ext) {
         LevelBuf& L = levels[k];
         LevelView lv;
@@ -390,6 +391,10 @@ static int32_t tree_build_device(dapol_ctx* ctx, int index_bits, int shard_bits,
         t->n_real += h_cnt[k];
         if (k < height) t->n_pad += 2 * (uint64_t)h_cnt[k + 1] - h_cnt[k];
     }
+    std::vector<LevelView> hv((size_t)height + 1);
+    for (int k = 0; k <= height; k++) hv[k] = t->view(k, nullptr);
+    HIPCHK(t->d_views.alloc(hv.size()));
+    HIPCHK(hipMemcpy(t->d_views.p, hv.data(), hv.size() * sizeof(LevelView), hipMemcpyHostToDevice));
     return DAPOL_OK;
 }
 
@@ -720,8 +725,8 @@ static int32_t tree_paths_device(dapol_tree* tree, size_t b, const uint64_t* d_l
     HIPCHK(hipMemcpyAsync(&h_missing, missing.p, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (h_missing) return fail(DAPOL_ERR_UNKNOWN_LEAF, "no liability at one of the requested leaves");
-    for (int k = 0; k < tree->height; k++) {
-        hipLaunchKernelGGL(k_tree_path_level, dim3(nblk(b, 256)), dim3(256), 0, st, b, d_pos, tree->view(k, nullptr), k, tree->height, n_upper, g_wire.siblings_leaf_first, out);
+    if (tree->height) {
+        hipLaunchKernelGGL(k_tree_path_walk, dim3(nblk(b, 64)), dim3(64), 0, st, b, d_pos, tree->d_views.p, tree->height, n_upper, g_wire.siblings_leaf_first, out);
         LAUNCH_CHECK();
     }
     return DAPOL_OK;

@@ -336,32 +336,37 @@ __global__ void k_tree_find_leaves(size_t b, const uint64_t* want, size_t n, con
     if (lo < n && idx[lo] == w) pos[t] = (uint32_t)lo;
     else { pos[t] = 0xffffffffu; atomicOr(missing, 1u); }
 }
-// Walk one level for all proofs: writes the sibling of each proof's current node and moves to the parent.
-__global__ void k_tree_path_level(size_t b, uint32_t* pos, LevelView lv, int level, int height, int n_upper, int leaf_first, PathOut out) {
+// Walks each proof's leaf up to the root: writes the sibling met at every level (one launch for the whole path; a lane's
+// chain is `height` dependent gathers, the lanes of a launch cover the proofs).
+__global__ __launch_bounds__(64) void k_tree_path_walk(size_t b, uint32_t* pos, const LevelView* views, int height, int n_upper, int leaf_first, PathOut out) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= b) return;
     uint32_t p = pos[t];
     if (p == 0xffffffffu) return;
-    // sibling order of a proof (dapol_wire_config.siblings_leaf_first): root side first (slot 0 = the root's child) or leaf first
-    size_t slot = t * (size_t)(height + n_upper) + (size_t)(leaf_first ? level : n_upper + height - 1 - level);
-    uint32_t c[8], h[8], r[8];
-    uint64_t v = 0;
-    if (lv.has_pad[p]) {
-        ld8(c, lv.padC + (size_t)p * 8);
-        ld8(h, lv.padH + (size_t)p * 8);
-        ld8(r, lv.padr + (size_t)p * 8);
-    } else {
-        size_t s = (lv.idx[p] & 1ull) ? (size_t)p - 1 : (size_t)p + 1;
-        ld8(c, lv.C + s * 8);
-        ld8(h, lv.H + s * 8);
-        ld8(r, lv.r + s * 8);
-        v = lv.v[s];
+    for (int level = 0; level < height; level++) {
+        const LevelView lv = views[level];
+        // sibling order of a proof (dapol_wire_config.siblings_leaf_first): root side first (slot 0 = the root's child) or leaf first
+        size_t slot = t * (size_t)(height + n_upper) + (size_t)(leaf_first ? level : n_upper + height - 1 - level);
+        uint32_t c[8], h[8], r[8];
+        uint64_t v = 0;
+        if (lv.has_pad[p]) {
+            ld8(c, lv.padC + (size_t)p * 8);
+            ld8(h, lv.padH + (size_t)p * 8);
+            ld8(r, lv.padr + (size_t)p * 8);
+        } else {
+            size_t s = (lv.idx[p] & 1ull) ? (size_t)p - 1 : (size_t)p + 1;
+            ld8(c, lv.C + s * 8);
+            ld8(h, lv.H + s * 8);
+            ld8(r, lv.r + s * 8);
+            v = lv.v[s];
+        }
+        if (out.C) st8(out.C + slot * 8, c);
+        if (out.H) st8(out.H + slot * 8, h);
+        if (out.v) out.v[slot] = v;
+        if (out.r) st8(out.r + slot * 8, r);
+        p = lv.parent[p];
     }
-    if (out.C) st8(out.C + slot * 8, c);
-    if (out.H) st8(out.H + slot * 8, h);
-    if (out.v) out.v[slot] = v;
-    if (out.r) st8(out.r + slot * 8, r);
-    pos[t] = lv.parent[p];
+    pos[t] = p;
 }
 // Siblings above a shard root are the same for every leaf of the shard: broadcast them into slots [0, n_upper).
 __global__ void k_tree_path_upper(size_t b, int height, int n_upper, int leaf_first, const uint32_t* uC, const uint32_t* uH, const uint64_t* uv,

@@ -40,6 +40,7 @@ struct RangeArgs {
     sc* a; sc* b; sc* s1; sc* s2;       // [B][N] each
     dig_t* dig;                         // [B][nwin][TP] signed radix-2^wbits digits
     int nsplit;                         // MSM term-range splits per proof (0/1 = none); partial points at [b * nsplit + s]
+    int use_hi;                         // small calls: the main MSM also walks only TableView::hi_split window steps (two lookups per term)
     ProofState* st;                     // [B]
     int32_t* PA; int32_t* P0; int32_t* P1;   // [B][40] partial points
     int tail_n;                         // T = length of the tail argument (32 / 64 / 128): 2T generators are materialised
@@ -83,16 +84,24 @@ __global__ __launch_bounds__(64) void k_rp_nonce_key(RangeArgs A) {
     for (int i = 0; i < 8; i++) key[i] = w[i];
     seed_wide(w, key, 7u, (uint64_t)A.n, (uint64_t)A.m);
     for (int i = 0; i < 8; i++) key[i] = w[i];
+    // One BLAKE3 chunk per 31 commitments, absorbed a block (= two 32-byte entries: the key, then the V_j) at a time.
     for (int j0 = 0; j0 < A.m; j0 += 31) {
-        Digest d;
-        dg_init(d, DG_BLAKE3);
-        dg_update_words(d, key, 8);
-        for (int j = j0; j < A.m && j < j0 + 31; j++) {
-            uint32_t v[8];
-            ld8(v, A.Vc + (b * A.m + j) * 8);
-            dg_update_words(d, v, 8);
+        const int n_ent = 1 + ((A.m - j0 < 31) ? A.m - j0 : 31);
+        const int n_blk = (n_ent + 1) / 2;
+        uint32_t cv[8], blk[16], o[16];
+        blake3_iv(cv);
+        for (int i = 0; i < n_blk; i++) {
+            for (int h = 0; h < 2; h++) {
+                const int e = 2 * i + h;
+                if (e == 0) { for (int k = 0; k < 8; k++) blk[k] = key[k]; }
+                else if (e < n_ent) ld8(blk + 8 * h, A.Vc + (b * A.m + j0 + e - 1) * 8);
+                else { for (int k = 0; k < 8; k++) blk[8 + k] = 0; }
+            }
+            const bool last = i == n_blk - 1;
+            blake3_compress(o, cv, blk, 0, (last && (n_ent & 1)) ? 32u : 64u, (i == 0 ? B3_CHUNK_START : 0u) | (last ? (B3_CHUNK_END | B3_ROOT) : 0u));
+            for (int k = 0; k < 8; k++) cv[k] = o[k];
         }
-        dg_final(d, key);
+        for (int k = 0; k < 8; k++) key[k] = cv[k];
     }
     for (int i = 0; i < 8; i++) A.st[b].nkey[i] = key[i];
 }
@@ -237,12 +246,16 @@ __global__ __launch_bounds__(64, DAPOL_MSM_OCC) void k_rp_msm(RangeArgs A, Table
     int niter_all = (A.N + LPL - 1) / LPL;
     int i_begin = (int)((long long)niter_all * split / nsplit), niter = (int)((long long)niter_all * (split + 1) / nsplit);
     int i_step = 1;
+    int mat_split = 0;
     if constexpr (MODE == MSM_MATERIALIZE) {
         // Folded generator i of the length-T argument collects the original generators j = i (mod T).  Lane ql owns
         // the terms 32 * i + ql, so the class of term i is ql + 32 * (i mod K), K = T / 32: block c walks i = c (mod K).
+        // Small calls split a block's terms over nsplit wavefronts (k_rp_sum_mat adds the partial sums).
         i_step = A.tail_n >> 5;
-        b = blockIdx.x / i_step;
-        i_begin = (int)(blockIdx.x % i_step);
+        mat_split = (int)(blockIdx.x % nsplit);
+        const size_t blk = blockIdx.x / nsplit;
+        b = blk / i_step;
+        i_begin = (int)(blk % i_step);
         niter = niter_all;
     }
     bool valid = b < A.B;
@@ -251,14 +264,16 @@ __global__ __launch_bounds__(64, DAPOL_MSM_OCC) void k_rp_msm(RangeArgs A, Table
     const dig_t* dig = A.dig + b * A.nwin * (size_t)A.TP + 32 * side;
     const int NW = A.nwin, W = A.wbits;
     // trips of this lane (PLAIN / TAIL): runs of four consecutive terms when the list divides that way, else one term per trip
-    const bool grp4 = (A.N % (4 * LPL)) == 0;
+    // Rows of the high halves (TableView::hi_split): only the low hi_split window steps are walked; a step looks a term up twice,
+    // digit w in the generator's row and digit w + hi_split in its 2^(W hi_split) row.  Always for the materialisation (whose
+    // lanes own few terms), and for the main MSM of small calls (A.use_hi), where the shared doublings are the latency.
+    const int LW = (MODE != MSM_TAIL && tbl.hi_split && (MODE == MSM_MATERIALIZE || A.use_hi)) ? tbl.hi_split : NW;
+    const int halves = LW < NW ? 2 : 1;
+    const bool grp4 = halves == 1 && (A.N % (4 * LPL)) == 0;
     const int trips_all = grp4 ? A.N / LPL : niter_all, unit = grp4 ? 4 : 1;
     const int it_begin = (int)((long long)(trips_all / unit) * split / nsplit) * unit, it_end = (int)((long long)(trips_all / unit) * (split + 1) / nsplit) * unit;
     ge_p3 acc;
     ge_identity(acc);
-    // Materialisation with high-half rows (TableView::hi_split): only the low hi_split window steps are walked; a step looks a
-    // term up twice, digit w in the generator's row and digit w + hi_split in its 2^(W hi_split) row.
-    const int LW = (MODE == MSM_MATERIALIZE && tbl.hi_split) ? tbl.hi_split : NW;
     for (int w = LW - 1; w >= 0; w--) {
         if (w != LW - 1) {
             // ONE inlined copy of the doubling (T under a runtime flag).  Measured (profiles/r01_msm_variants.txt): a
@@ -269,10 +284,11 @@ __global__ __launch_bounds__(64, DAPOL_MSM_OCC) void k_rp_msm(RangeArgs A, Table
         }
         const dig_t* dw = dig + (size_t)w * A.TP;
         if constexpr (MODE == MSM_MATERIALIZE) {
-            const int halves = LW < NW ? 2 : 1;             // ONE copy of the addition: the two lookups of a term are two trips
+            // ONE copy of the addition: the two lookups of a term are two trips
             const int own = (niter - i_begin + i_step - 1) / i_step;        // this block's terms: i = i_begin + k * i_step
+            const int k_begin = (int)((long long)own * mat_split / nsplit), k_end = (int)((long long)own * (mat_split + 1) / nsplit);
 #pragma nounroll
-            for (int it = 0; it < 2 * own; it += (halves == 2 ? 1 : 2)) {
+            for (int it = 2 * k_begin; it < 2 * k_end; it += (halves == 2 ? 1 : 2)) {
                 const int i = i_begin + (it >> 1) * i_step, hi = it & 1;
                 if (hi && w + LW >= NW) continue;
                 int q = LPL * i + ql;                       // (N is a multiple of 32 here: every q is a term)
@@ -290,7 +306,9 @@ __global__ __launch_bounds__(64, DAPOL_MSM_OCC) void k_rp_msm(RangeArgs A, Table
             // trips are not unrolled (instruction cache, see above); the four digits rotate through d4.
             dapol_v4i d4 = {0, 0, 0, 0};
 #pragma nounroll
-            for (int it = it_begin; it < it_end; it++) {
+            for (int it2 = 2 * it_begin; it2 < 2 * it_end; it2 += (halves == 2 ? 1 : 2)) {
+                const int it = it2 >> 1, hi = it2 & 1;
+                if (hi && w + LW >= NW) continue;
                 int q;
                 if (grp4) {
                     q = 4 * (LPL * (it >> 2) + ql) + (it & 3);
@@ -298,7 +316,7 @@ __global__ __launch_bounds__(64, DAPOL_MSM_OCC) void k_rp_msm(RangeArgs A, Table
                 } else {
                     q = LPL * it + ql;
                     if (q >= A.N) continue;
-                    d4.x = dw[64 * (q >> 5) + (q & 31)];
+                    d4.x = (hi ? dw + (size_t)LW * A.TP : dw)[64 * (q >> 5) + (q & 31)];
                 }
                 const int d = d4.x;
                 d4.x = d4.y; d4.y = d4.z; d4.z = d4.w;
@@ -307,7 +325,7 @@ __global__ __launch_bounds__(64, DAPOL_MSM_OCC) void k_rp_msm(RangeArgs A, Table
                 int row;
                 if constexpr (MODE == MSM_TAIL) row = j + (isH ? A.N : 0);
                 else row = gen_row(tbl, A.n, j, isH);
-                tbl_madd(acc, tbl, row, d);
+                tbl_madd(acc, tbl, hi ? tbl.row_hi(row) : row, d);
             }
         }
     }
@@ -317,19 +335,35 @@ __global__ __launch_bounds__(64, DAPOL_MSM_OCC) void k_rp_msm(RangeArgs A, Table
         // row (k_rp_tail_table builds the row).
         static_assert(MODE != MSM_MATERIALIZE || LPL == 32, "materialisation needs one proof per wavefront");
         const int T = A.tail_n;
-        st_p3(A.tailT + (b * (size_t)(2 * T) + (size_t)(side * T + ql + 32 * i_begin)) * TAIL_ROW_WORDS, acc);
+        const size_t g = b * (size_t)(2 * T) + (size_t)(side * T + ql + 32 * i_begin);
+        if (nsplit > 1) st_p3(A.P0 + (g * nsplit + mat_split) * 40, acc);
+        else st_p3(A.tailT + g * TAIL_ROW_WORDS, acc);
     } else {
         wave_reduce_point(acc, LPL);
         if (ql == 0 && valid) st_p3((side ? A.P1 : A.P0) + (b * nsplit + split) * 40, acc);
     }
 }
 
-// Small calls split every proof's term range over several wavefronts (latency): P0 / P1 [b] = sum of the partials.
+// Small calls split every proof's term range over several wavefronts (latency): P0 / P1 [b] = sum of the partials, one wavefront
+// per (proof, side), the partials summed by a shuffle tree (nsplit a power of two <= 64).
 __global__ __launch_bounds__(64) void k_rp_sum_splits(size_t B, int nsplit, const int32_t* PS0, const int32_t* PS1, int32_t* P0, int32_t* P1) {
-    size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
+    const size_t t = blockIdx.x;
     if (t >= 2 * B) return;
-    size_t b = t >> 1;
+    const size_t b = t >> 1;
+    const int l = threadIdx.x;
     const int32_t* src = ((t & 1) ? PS1 : PS0) + b * (size_t)nsplit * 40;
+    ge_p3 acc;
+    if (l < nsplit) ld_p3(acc, src + (size_t)l * 40);
+    else ge_identity(acc);
+    wave_reduce_point(acc, nsplit);
+    if (l == 0) st_p3(((t & 1) ? P1 : P0) + b * 40, acc);
+}
+
+// Split materialisation (small calls): folded generator g = sum of its nsplit partial sums, kept at the head of its table row.
+__global__ __launch_bounds__(64) void k_rp_sum_mat(size_t n_gen, int nsplit, const int32_t* PS, int32_t* tailT) {
+    size_t g = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (g >= n_gen) return;
+    const int32_t* src = PS + g * (size_t)nsplit * 40;
     ge_p3 acc, p, r;
     ld_p3(acc, src);
     for (int s = 1; s < nsplit; s++) {
@@ -337,12 +371,9 @@ __global__ __launch_bounds__(64) void k_rp_sum_splits(size_t B, int nsplit, cons
         ge_add(r, acc, p);
         acc = r;
     }
-    st_p3(((t & 1) ? P1 : P0) + b * 40, acc);
+    st_p3(tailT + g * TAIL_ROW_WORDS, acc);
 }
 
-// Table row of one point P: the multiples 0*P .. (ENTRIES-1)*P in affine niels form (the 128-byte entry format of the
-// context tables).  P waits in extended coordinates at the head of the row; the projective multiples are parked in the
-// row's own entry slots and normalised with ONE inversion (Montgomery's trick).
 template <int ENTRIES>
 __device__ __forceinline__ void build_niels_row(int32_t* row) {
     ge_p3 base, mul;
@@ -425,31 +456,44 @@ __device__ __forceinline__ void append_scalar(Strobe& s, const char* label, int 
 }
 
 // --------------------------------------------------------- F1: finish A and S, transcript up to y, z (lane/proof)
+// PAIR: small calls run the two point computations of a proof (A and S here; T_1, T_2; L_k, R_k) on two neighbouring lanes and
+// hand the second encoding to the first, which owns the transcript -- the lane's serial chain is what a lone proof waits for.
+template <int PAIR>
 __global__ __launch_bounds__(64) void k_rp_finish1(RangeArgs A, TableView tbl) {
-    size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
-    if (b >= A.B) return;
+    const size_t t_ = (size_t)blockIdx.x * 64 + threadIdx.x;
+    size_t b = PAIR ? t_ >> 1 : t_;
+    const bool valid = b < A.B;
+    if (!PAIR && !valid) return;
+    if (!valid) b = A.B - 1;
     ProofState& ps = A.st[b];
     sc a_bl, s_bl, t;
-    sc_zero(a_bl);
-    sc_zero(s_bl);
-    for (int j = 0; j < A.m; j++) {
-        tape_scalar(t, A, b, (uint32_t)(j * (2 * A.n + 2)));
-        sc_add(a_bl, a_bl, t);
-        tape_scalar(t, A, b, (uint32_t)(j * (2 * A.n + 2) + 1));
-        sc_add(s_bl, s_bl, t);
-    }
-    ge_p3 pa, p0, p1, ps_;
     uint32_t c[8], Ac[8], Sc[8];
-    ld_p3(pa, A.PA + b * 40);
-    sc_from_mont(c, a_bl);
-    tbl_fixed_mul_add(pa, tbl, tbl.row_Bb(0), c);
-    ge_compress(Ac, pa);
-    ld_p3(p0, A.P0 + b * 40);
-    ld_p3(p1, A.P1 + b * 40);
-    ge_add(ps_, p0, p1);
-    sc_from_mont(c, s_bl);
-    tbl_fixed_mul_add(ps_, tbl, tbl.row_Bb(0), c);
-    ge_compress(Sc, ps_);
+    for (int h = (PAIR ? (int)(t_ & 1) : 0); h < (PAIR ? (int)(t_ & 1) + 1 : 2); h++) {
+        sc bl;
+        sc_zero(bl);
+        for (int j = 0; j < A.m; j++) {
+            tape_scalar(t, A, b, (uint32_t)(j * (2 * A.n + 2) + h));
+            sc_add(bl, bl, t);
+        }
+        ge_p3 p;
+        if (h == 0) ld_p3(p, A.PA + b * 40);
+        else {
+            ge_p3 p0, p1;
+            ld_p3(p0, A.P0 + b * 40);
+            ld_p3(p1, A.P1 + b * 40);
+            ge_add(p, p0, p1);
+        }
+        sc_from_mont(c, bl);
+        tbl_fixed_mul_add(p, tbl, tbl.row_Bb(0), c);
+        ge_compress(c, p);
+        for (int i = 0; i < 8; i++) { if (h) Sc[i] = c[i]; else Ac[i] = c[i]; }
+        if (h) s_bl = bl; else a_bl = bl;
+    }
+    if (PAIR) {
+        for (int i = 0; i < 8; i++) Sc[i] = __shfl_down(Sc[i], 1);
+        if (t_ & 1) { if (valid) ps.s_bl = s_bl; return; }
+        if (!valid) return;
+    }
     uint32_t* out = A.out + b * A.out_words;
     st8(out, Ac);
     st8(out + 8, Sc);
@@ -468,8 +512,9 @@ __global__ __launch_bounds__(64) void k_rp_finish1(RangeArgs A, TableView tbl) {
     sc y, z, yi;
     challenge_scalar(y, s, LBL_Y);
     challenge_scalar(z, s, LBL_Z);
-    sc_invert_mont(yi, y);
-    ps.y = y; ps.z = z; ps.y_inv = yi; ps.a_bl = a_bl; ps.s_bl = s_bl;
+    sc_invert_vartime_mont(yi, y);                          // y is a public challenge
+    ps.y = y; ps.z = z; ps.y_inv = yi; ps.a_bl = a_bl;
+    if (!PAIR) ps.s_bl = s_bl;
     ps.err = 0;
     st_store(ps, s);
 }
@@ -517,34 +562,39 @@ __global__ __launch_bounds__(64) void k_rp_poly(RangeArgs A) {
 }
 
 // ------------------------------------------------------------- F2: T1, T2 and the challenge x (lane/proof)
+template <int PAIR>
 __global__ __launch_bounds__(64) void k_rp_finish2(RangeArgs A, TableView tbl) {
-    size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
-    if (b >= A.B) return;
+    const size_t t_ = (size_t)blockIdx.x * 64 + threadIdx.x;
+    size_t b = PAIR ? t_ >> 1 : t_;
+    const bool valid = b < A.B;
+    if (!PAIR && !valid) return;
+    if (!valid) b = A.B - 1;
     ProofState& ps = A.st[b];
     sc t1_bl, t2_bl, t;
-    sc_zero(t1_bl);
-    sc_zero(t2_bl);
     uint32_t base = (uint32_t)(A.m * (2 * A.n + 2));
-    for (int j = 0; j < A.m; j++) {
-        tape_scalar(t, A, b, base + 2 * j);
-        sc_add(t1_bl, t1_bl, t);
-        tape_scalar(t, A, b, base + 2 * j + 1);
-        sc_add(t2_bl, t2_bl, t);
-    }
     uint32_t c[8], T1c[8], T2c[8];
-    ge_p3 p;
-    ge_identity(p);
-    sc_from_mont(c, ps.t1);
-    tbl_fixed_mul_add(p, tbl, tbl.row_B(0), c);
-    sc_from_mont(c, t1_bl);
-    tbl_fixed_mul_add(p, tbl, tbl.row_Bb(0), c);
-    ge_compress(T1c, p);
-    ge_identity(p);
-    sc_from_mont(c, ps.t2);
-    tbl_fixed_mul_add(p, tbl, tbl.row_B(0), c);
-    sc_from_mont(c, t2_bl);
-    tbl_fixed_mul_add(p, tbl, tbl.row_Bb(0), c);
-    ge_compress(T2c, p);
+    for (int h = (PAIR ? (int)(t_ & 1) : 0); h < (PAIR ? (int)(t_ & 1) + 1 : 2); h++) {
+        sc bl;
+        sc_zero(bl);
+        for (int j = 0; j < A.m; j++) {
+            tape_scalar(t, A, b, base + 2 * j + h);
+            sc_add(bl, bl, t);
+        }
+        ge_p3 p;
+        ge_identity(p);
+        sc_from_mont(c, h ? ps.t2 : ps.t1);
+        tbl_fixed_mul_add(p, tbl, tbl.row_B(0), c);
+        sc_from_mont(c, bl);
+        tbl_fixed_mul_add(p, tbl, tbl.row_Bb(0), c);
+        ge_compress(c, p);
+        for (int i = 0; i < 8; i++) { if (h) T2c[i] = c[i]; else T1c[i] = c[i]; }
+        if (h) t2_bl = bl; else t1_bl = bl;
+    }
+    if (PAIR) {
+        for (int i = 0; i < 8; i++) T2c[i] = __shfl_down(T2c[i], 1);
+        if (t_ & 1) { if (valid) ps.t2_bl = t2_bl; return; }
+        if (!valid) return;
+    }
     uint32_t* out = A.out + b * A.out_words;
     st8(out + 16, T1c);
     st8(out + 24, T2c);
@@ -555,7 +605,8 @@ __global__ __launch_bounds__(64) void k_rp_finish2(RangeArgs A, TableView tbl) {
     sc x;
     challenge_scalar(x, s, LBL_X);
     if (sc_is_zero(x)) ps.err = 1;                                // ProofError::MaliciousDealer in the crate
-    ps.x = x; ps.t1_bl = t1_bl; ps.t2_bl = t2_bl;
+    ps.x = x; ps.t1_bl = t1_bl;
+    if (!PAIR) ps.t2_bl = t2_bl;
     st_store(ps, s);
 }
 
@@ -685,23 +736,29 @@ __global__ __launch_bounds__(64) void k_rp_round_ip(RangeArgs A, int round) {
 }
 
 // --------------------------------------------------------- F4: L_k, R_k, challenge u_k (lane/proof)
+template <int PAIR>
 __global__ __launch_bounds__(64) void k_rp_round_finish(RangeArgs A, TableView tbl, int round) {
-    size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
-    if (b >= A.B) return;
+    const size_t t_ = (size_t)blockIdx.x * 64 + threadIdx.x;
+    size_t b = PAIR ? t_ >> 1 : t_;
+    const bool valid = b < A.B;
+    if (!PAIR && !valid) return;
+    if (!valid) b = A.B - 1;
     ProofState& ps = A.st[b];
-    ge_p3 p;
-    sc t;
     uint32_t c[8], Lc[8], Rc[8];
-    ld_p3(p, A.P0 + b * 40);
-    sc_montmul(t, ps.cL, ps.w);
-    sc_from_mont(c, t);
-    tbl_fixed_mul_add(p, tbl, tbl.row_B(0), c);               // + c_L * Q,  Q = w * B
-    ge_compress(Lc, p);
-    ld_p3(p, A.P1 + b * 40);
-    sc_montmul(t, ps.cR, ps.w);
-    sc_from_mont(c, t);
-    tbl_fixed_mul_add(p, tbl, tbl.row_B(0), c);
-    ge_compress(Rc, p);
+    for (int h = (PAIR ? (int)(t_ & 1) : 0); h < (PAIR ? (int)(t_ & 1) + 1 : 2); h++) {
+        ge_p3 p;
+        sc t;
+        ld_p3(p, (h ? A.P1 : A.P0) + b * 40);
+        sc_montmul(t, h ? ps.cR : ps.cL, ps.w);
+        sc_from_mont(c, t);
+        tbl_fixed_mul_add(p, tbl, tbl.row_B(0), c);           // + c_L * Q,  Q = w * B
+        ge_compress(c, p);
+        for (int i = 0; i < 8; i++) { if (h) Rc[i] = c[i]; else Lc[i] = c[i]; }
+    }
+    if (PAIR) {
+        for (int i = 0; i < 8; i++) Rc[i] = __shfl_down(Rc[i], 1);
+        if ((t_ & 1) || !valid) return;
+    }
     uint32_t* out = A.out + b * A.out_words + 56 + 16 * (A.out_round0 + round);
     st8(out, Lc);
     st8(out + 8, Rc);
@@ -711,7 +768,7 @@ __global__ __launch_bounds__(64) void k_rp_round_finish(RangeArgs A, TableView t
     merlin_append_words(s, LBL_R, Rc, 8);
     sc u, ui;
     challenge_scalar(u, s, LBL_U);
-    sc_invert_mont(ui, u);
+    sc_invert_vartime_mont(ui, u);                          // u_k is a public challenge
     ps.u = u; ps.u_inv = ui;
     st_store(ps, s);
 }

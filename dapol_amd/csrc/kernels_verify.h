@@ -254,13 +254,13 @@ __global__ __launch_bounds__(64) void k_rv_transcript(VerifyArgs V) {
         sc_montmul(run, run, u);
     }
     if (any_zero) {
-        for (int k = 0; k < A.lgN; k++) sc_invert_mont(vs.u_inv[k], vs.u[k]);
-        sc_invert_mont(vs.y_inv, vs.y);
-        sc_invert_mont(vs.ym1_inv, ym1);
-        sc_invert_mont(vs.zm1_inv, zm1);
+        for (int k = 0; k < A.lgN; k++) sc_invert_vartime_mont(vs.u_inv[k], vs.u[k]);
+        sc_invert_vartime_mont(vs.y_inv, vs.y);
+        sc_invert_vartime_mont(vs.ym1_inv, ym1);
+        sc_invert_vartime_mont(vs.zm1_inv, zm1);
     } else {
         sc inv, t;
-        sc_invert_mont(inv, run);
+        sc_invert_vartime_mont(inv, run);
         for (int k = A.lgN - 1; k >= 0; k--) {
             sc u = vs.u[k];
             t = vs.u_inv[k];
@@ -1030,6 +1030,62 @@ __global__ __launch_bounds__(64) void k_verify_paths(int dg, size_t b, int heigh
     ok[e] = good ? 1 : 0;
 }
 // commitments of one sub-proof from the path (pad parties: commit(0, 1) = B_blinding, src/range/padding.rs:176-180)
+// The same check with ONE WAVEFRONT per proof, for calls of few proofs (a user checking their own inclusion proof): the lane
+// version above is a chain of `height` decompressions, additions and encodings -- 4.9 ms for one height-32 path.  Here lane k
+// decompresses sibling k, an inclusive prefix sum over the lanes (shuffles) gives every ancestor's commitment at once, each lane
+// encodes its own, and only the hash chain stays serial (every lane walks it in step; its inputs come by shuffle).
+__global__ __launch_bounds__(64) void k_verify_paths_wave(int dg, size_t b, int height, const uint64_t* leaf_idx, const uint32_t* leafC,
+                                                         const uint32_t* leafH, const uint32_t* pC, const uint32_t* pH, const uint32_t* rootC,
+                                                         const uint32_t* rootH, int leaf_first, uint8_t* ok) {
+    const size_t e = blockIdx.x;
+    const int l = threadIdx.x;
+    if (e >= b) return;
+    uint32_t c[8], h[8], sc_[8] = {0}, sh[8] = {0}, cn[8];
+    ld8(c, leafC + e * 8);
+    ld8(h, leafH + e * 8);
+    const bool live = l < height;
+    ge_p3 acc, lf;
+    bool good = ge_decompress(lf, c);
+    ge_identity(acc);
+    if (live) {
+        size_t slot = e * (size_t)height + (size_t)(leaf_first ? l : height - 1 - l);
+        ld8(sc_, pC + slot * 8);
+        ld8(sh, pH + slot * 8);
+        good &= ge_decompress(acc, sc_);                     // deserialisation rejects non-canonical points (proof/node.rs:88-94)
+    }
+    {
+        ge_p3 r;
+        ge_add(r, acc, lf);
+        if (l == 0) acc = r;                                 // lane k's prefix sum = leaf + siblings 0..k = the ancestor at level k + 1
+    }
+    for (int off = 1; off < height; off <<= 1) {
+        ge_p3 o, r;
+        for (int i = 0; i < FE_NL; i++) {
+            o.X.v[i] = __shfl_up(acc.X.v[i], off, 64);
+            o.Y.v[i] = __shfl_up(acc.Y.v[i], off, 64);
+            o.Z.v[i] = __shfl_up(acc.Z.v[i], off, 64);
+            o.T.v[i] = __shfl_up(acc.T.v[i], off, 64);
+        }
+        ge_add(r, acc, o);
+        if (l >= off) acc = r;
+    }
+    ge_compress(cn, acc);
+    const uint64_t idx = leaf_idx[e];
+    for (int k = 0; k < height; k++) {
+        uint32_t sk[8], shk[8], nx[8], hn[8];
+        for (int i = 0; i < 8; i++) {
+            sk[i] = (uint32_t)__shfl((int)sc_[i], k, 64);
+            shk[i] = (uint32_t)__shfl((int)sh[i], k, 64);
+            nx[i] = (uint32_t)__shfl((int)cn[i], k, 64);
+        }
+        if ((idx >> k) & 1) node_hash128(dg, hn, sk, c, shk, h);
+        else node_hash128(dg, hn, c, sk, h, shk);
+        for (int i = 0; i < 8; i++) { c[i] = nx[i]; h[i] = hn[i]; }
+    }
+    for (int i = 0; i < 8; i++) good &= (c[i] == rootC[i]) & (h[i] == rootH[i]);
+    const bool all_good = __all(good ? 1 : 0) != 0;
+    if (l == 0) ok[e] = all_good ? 1 : 0;
+}
 __global__ void k_gather_commitments(size_t b, int height, int start, int count, int m, const uint32_t* pC, const uint32_t* Bb_comp, uint32_t* Vc) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= b * (size_t)m) return;

@@ -3,6 +3,7 @@ pure host logic (sizes, policy planning, argument validation) behaves like the r
 import ctypes
 import os
 import re
+import subprocess
 
 from conftest import ROOT
 
@@ -161,3 +162,14 @@ def test_bench_wall_budget_plan():
     prove, tree = bench.algorithmic_bytes(32, 64, 20)
     assert (prove, tree, prove + tree) == (6384, 2752, 9136)
     assert bench.algorithmic_bytes(24, 64, 16) == (5040, 1920)
+
+
+def test_sc_invert_vartime_matches_fermat_ladder(tmp_path):
+    """The divstep inversion used for public challenges (sc.h) equals the Fermat ladder on edge values and 30,000 random scalars
+    (host build of the very header the kernels compile)."""
+    exe = str(tmp_path / "sc_inv")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "dapol_amd", "csrc"), os.path.join(ROOT, "tests", "cpp", "sc_invert_vartime_test.cpp"),
+                    "-o", exe], check=True)
+    r = subprocess.run([exe, "30000"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "30000 tested, 0 bad" in r.stdout
