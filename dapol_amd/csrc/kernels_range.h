@@ -807,6 +807,74 @@ __global__ __launch_bounds__(256) void k_rp_fold(RangeArgs A, int round) {
     }
 }
 
+// K6 + K5 of the NEXT round in one pass (wave per proof): fold a, b by u_k; then, for round k + 1, the inner products c_L, c_R of
+// the folded halves and -- position by position of its digit rows -- the s-vector entry folded by u_k, stored, and multiplied
+// with its a' / b' partner into that position's digits.  Against k_rp_fold + k_rp_round_prep + k_rp_round_ip this reads the
+// s-vectors once instead of twice and finds a', b' in the cache they were just written through.  Opt-in (DAPOL_FUSE_FOLD=1): it
+// measured 1.7 % SLOWER than the three launches at 2^18 proofs and 40 % slower for a lone proof (profiles/r02_fold_fuse_ab.txt).
+__global__ __launch_bounds__(64) void k_rp_fold_next(RangeArgs A, int round) {
+    const size_t b = blockIdx.x;
+    const int l = threadIdx.x;
+    ProofState& ps = A.st[b];
+    const sc u = ps.u, ui = ps.u_inv;
+    const int lgh = A.lgN - 1 - round, half = 1 << lgh;
+    sc* va = A.a + b * A.N;
+    sc* vb = A.b + b * A.N;
+    for (int i = l; i < half; i += 64) {
+        sc lo, hi, r;
+        ld_sc(lo, va + i);
+        ld_sc(hi, va + half + i);
+        sc_montmul(lo, lo, u);
+        sc_montmul(hi, hi, ui);
+        sc_add(r, lo, hi);
+        st_sc(va + i, r);                         // a' = a_L u + a_R u^-1
+        ld_sc(lo, vb + i);
+        ld_sc(hi, vb + half + i);
+        sc_montmul(lo, lo, ui);
+        sc_montmul(hi, hi, u);
+        sc_add(r, lo, hi);
+        st_sc(vb + i, r);                         // b' = b_L u^-1 + b_R u
+    }
+    __syncthreads();                              // a', b' are read across lanes below
+    const int lgh1 = lgh - 1, half1 = half >> 1;
+    {
+        sc cL, cR;
+        sc_zero(cL);
+        sc_zero(cR);
+        for (int i = l; i < half1; i += 64) {
+            sc aL, aR, bL, bR, t;
+            ld_sc(aL, va + i);
+            ld_sc(aR, va + half1 + i);
+            ld_sc(bL, vb + i);
+            ld_sc(bR, vb + half1 + i);
+            sc_montmul(t, aL, bR);
+            sc_add(cL, cL, t);
+            sc_montmul(t, aR, bL);
+            sc_add(cR, cR, t);
+        }
+        wave_reduce_sc(cL);
+        wave_reduce_sc(cR);
+        if (l == 0) { ps.cL = cL; ps.cR = cR; }
+    }
+    for (int pos = l; pos < A.TP; pos += 64) {
+        const int ch = pos >> 6, side = (pos & 63) >> 5, q = 32 * ch + (pos & 31);
+        if (q >= A.N) { zero_digits(A, b, pos); continue; }
+        bool isH;
+        const int j = term_generator(round + 1, A.N, A.lgN, side, q, isH);
+        const bool upper = (j >> lgh) & 1;        // round k: G' = u^-1 G_L + u G_R, H' = u H_L + u^-1 H_R
+        sc* sp = (isH ? A.s2 : A.s1) + b * A.N + j;
+        sc s, t, v, p;
+        ld_sc(s, sp);
+        sc_montmul(t, s, (upper != isH) ? u : ui);
+        st_sc(sp, t);
+        const int off = j & (half1 - 1);          // round k + 1: G_R pairs with a_L, G_L with a_R; H'_L with b_R, H'_R with b_L
+        const int vi = ((j >> lgh1) & 1) ? off : off + half1;
+        ld_sc(v, (isH ? vb : va) + vi);
+        sc_montmul(p, v, t);                      // Montgomery x plain = the canonical product
+        write_digits_plain(A, b, pos, p.v);
+    }
+}
+
 // ------------------------------------------------------------------------------ F5: final a, b (lane/proof)
 __global__ __launch_bounds__(64) void k_rp_final(RangeArgs A, uint32_t* err_flag) {
     size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;

@@ -605,6 +605,16 @@ def test_prove_then_verify_entities(gpu_ctx, hip_lib, height, policy, agg):
     swapped[[4, 5]] = swapped[[5, 4]]                                     # proofs presented for the wrong positions
     okp = gpu_ctx.verify_entities(height, swapped, lC, lH, pC, pH, rC, rH, policy, agg, 8, proofs, verify_seed=SEED)
     assert okp[:4].all() and okp[6:].all()
+    # calls of many proofs check a path per LANE (k_verify_paths) instead of per wavefront: the same verdicts
+    import os
+    os.environ["DAPOL_PATHS_LANE"] = "1"
+    try:
+        assert gpu_ctx.verify_entities(height, idx, lC, lH, pC, pH, rC, rH, policy, agg, 8, proofs, verify_seed=SEED).all()
+        assert list(gpu_ctx.verify_entities(height, idx, lC, lH, pC, bad_hash, rC, rH, policy, agg, 8, proofs, verify_seed=SEED)) == [0] + [1] * 11
+        assert list(gpu_ctx.verify_entities(height, idx, wrong_leaf, lH, pC, pH, rC, rH, policy, agg, 8, proofs, verify_seed=SEED)) == [1, 1, 0] + [1] * 9
+        assert list(gpu_ctx.verify_entities(height, swapped, lC, lH, pC, pH, rC, rH, policy, agg, 8, proofs, verify_seed=SEED)) == list(okp)
+    finally:
+        os.environ.pop("DAPOL_PATHS_LANE", None)
 
 
 @pytest.mark.parametrize("height,policy,agg,pick", [(6, 0, 4, [0, 2, 3]), (7, 1, 7, [1, 4]), (5, 0, 0, [0, 1, 2, 3, 4]), (8, 1, 3, [2]), (6, 0, None, [0, 4])])
@@ -949,7 +959,11 @@ def test_every_proving_strategy_gives_the_same_bytes(gpu_ctx, n_bits, m):
     for env in ({"DAPOL_NO_TAIL": "1"}, {"DAPOL_TAIL_N": "32"}, {"DAPOL_TAIL_N": "128"}, {"DAPOL_TAIL_LPL": "4"}, {"DAPOL_TAIL_LPL": "1"},
                 {"DAPOL_LPL": "32"}, {"DAPOL_LPL": "4"}, {"DAPOL_LPL": "2"}, {"DAPOL_LPL": "2", "DAPOL_MSM_OCC_CAP": "3"}, {"DAPOL_CHUNK": "64"}, {"DAPOL_TAIL_N": "256", "DAPOL_LPL": "16"},
                 {"DAPOL_CHUNK": "8"}, {"DAPOL_CHUNK": "5", "DAPOL_STREAMS": "4"}, {"DAPOL_CHUNK": "16", "DAPOL_STREAMS": "1"},
-                {"DAPOL_CHUNK": "36", "DAPOL_STREAMS": "3"}, {"DAPOL_NO_SPLIT": "1"}, {"DAPOL_NO_SPLIT": "1", "DAPOL_TAIL_LPL": "32"}):
+                {"DAPOL_CHUNK": "36", "DAPOL_STREAMS": "3"}, {"DAPOL_NO_SPLIT": "1"}, {"DAPOL_NO_SPLIT": "1", "DAPOL_TAIL_LPL": "32"},
+                # the small-call (latency) arrangements and the opt-in fused fold
+                {"DAPOL_SMALL_TAIL": "1"}, {"DAPOL_SMALL_TAIL": "1", "DAPOL_NO_SPLIT_MAT": "1"}, {"DAPOL_SMALL_SPLIT": "16"}, {"DAPOL_SMALL_SPLIT": "2"},
+                {"DAPOL_NO_SMALL_HI": "1"}, {"DAPOL_NO_PAIR": "1"}, {"DAPOL_FUSE_FOLD": "1"}, {"DAPOL_FUSE_FOLD": "1", "DAPOL_SMALL_TAIL": "1"},
+                {"DAPOL_FUSE_FOLD": "1", "DAPOL_NO_SPLIT": "1"}):
         os.environ.update(env)
         try:
             got = gpu_ctx.range_prove_batch(n_bits, m, v, r, nonce_seed=SEED, stream_id=sid).tobytes()
