@@ -307,53 +307,158 @@ DAPOL_HD uint8_t strobe_squeeze_byte(Strobe& st) {
     if (++st.pos == STROBE_R) strobe_run_f(st);
     return b;
 }
-DAPOL_HD void strobe_begin_op(Strobe& st, uint8_t flags) {
+DAPOL_HD void strobe_reset(Strobe& st) {                   // the state before Strobe128::new's permutation
+    for (int i = 0; i < 25; i++) st.s[i] = 0;
+    st.pos = 0;
+    st.pos_begin = 0;
+}
+
+#if defined(__HIPCC__)
+// The same STROBE state held by ONE WAVEFRONT: lane x + 5 y keeps word (x, y) of the Keccak state, the permutation is nine lane
+// permutations and a dozen ALU operations per round instead of ~500 instructions on a lane (kernels_verify.h, k_rv_absorb_V),
+// and every lane follows the byte stream in step (all 64 lanes call every function below with the same arguments).  Used by the
+// calls of few proofs, where a lane's 23 us per permutation is what the caller waits for.
+__device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) {
+    uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src, 64), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+struct KeccakLanes {                 // per-lane source lanes of the round's permutations
+    int th1, th2, th3, th4, xp1, xp2, pi_src, cm_src, cp_src, rot_src;
+};
+__device__ __forceinline__ void keccak_lanes_init(KeccakLanes& K, int l) {
+    const int ROT[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+    if (l >= 25) { K.th1 = K.th2 = K.th3 = K.th4 = K.xp1 = K.xp2 = K.pi_src = K.cm_src = K.cp_src = l; K.rot_src = 0; return; }
+    int x = l % 5, y = l / 5, row = 5 * y;
+    K.th1 = (l + 5) % 25; K.th2 = (l + 10) % 25; K.th3 = (l + 15) % 25; K.th4 = (l + 20) % 25;
+    K.xp1 = row + (x + 1) % 5; K.xp2 = row + (x + 2) % 5;
+    // pi: B[x'][y'] = rot(A[x][y]) with (x', y') = (y, 2x + 3y): lane (x', y') pulls from y = x', x = 3 (y' - 3 x') mod 5
+    int sy = x, sx = (3 * ((y - 3 * x) % 5 + 5)) % 5;
+    K.pi_src = sx + 5 * sy;
+    K.cm_src = (sx + 4) % 5;         // any lane of column sx - 1 / sx + 1 holds that column's parity: row 0
+    K.cp_src = (sx + 1) % 5;
+    int r = 0;
+    for (int i = 0; i < 25; i++) r = (i == K.pi_src) ? ROT[i] : r;
+    K.rot_src = r;
+}
+// Three dependent permutation stages per round: (1) the column parities and, alongside, every lane's pi source word;
+// (2) the two parities theta needs for the SOURCE's column -- theta, rho and pi are then applied at the destination;
+// (3) chi's two row neighbours.
+__device__ __forceinline__ uint64_t keccak_f1600_wave(uint64_t a, const KeccakLanes& K, int l) {
+    const uint64_t RC[24] = {0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808Aull, 0x8000000080008000ull,
+                             0x000000000000808Bull, 0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull,
+                             0x000000000000008Aull, 0x0000000000000088ull, 0x0000000080008009ull, 0x000000008000000Aull,
+                             0x000000008000808Bull, 0x800000000000008Bull, 0x8000000000008089ull, 0x8000000000008003ull,
+                             0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800Aull, 0x800000008000000Aull,
+                             0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+    for (int r = 0; r < 24; r++) {
+        uint64_t as = shfl64(a, K.pi_src);
+        uint64_t c = a ^ shfl64(a, K.th1) ^ shfl64(a, K.th2) ^ shfl64(a, K.th3) ^ shfl64(a, K.th4);    // C[x] on every lane of column x
+        uint64_t cm = shfl64(c, K.cm_src), cp = shfl64(c, K.cp_src);
+        as ^= cm ^ ((cp << 1) | (cp >> 63));
+        uint64_t b = K.rot_src ? ((as << K.rot_src) | (as >> (64 - K.rot_src))) : as;
+        uint64_t b1 = shfl64(b, K.xp1), b2 = shfl64(b, K.xp2);
+        a = b ^ (~b1 & b2);
+        if (l == 0) a ^= RC[r];
+    }
+    return a;
+}
+struct WStrobe {
+    uint64_t a;                      // this lane's state word (lanes 25-63 carry zeros that nothing reads)
+    uint32_t pos, pos_begin;
+    int l;
+    KeccakLanes K;
+};
+__device__ __forceinline__ void wstrobe_lanes(WStrobe& st, int lane) {
+    st.l = lane;
+    keccak_lanes_init(st.K, lane);
+}
+__device__ __forceinline__ void wstrobe_xor(WStrobe& st, uint32_t at, uint64_t byte) {
+    if ((uint32_t)st.l == (at >> 3)) st.a ^= byte << (8 * (at & 7));
+}
+__device__ __forceinline__ void strobe_run_f(WStrobe& st) {
+    wstrobe_xor(st, st.pos, st.pos_begin);
+    wstrobe_xor(st, st.pos + 1, 0x04);
+    wstrobe_xor(st, STROBE_R + 1, 0x80);
+    st.a = keccak_f1600_wave(st.a, st.K, st.l);
+    st.pos = 0;
+    st.pos_begin = 0;
+}
+__device__ __forceinline__ void strobe_absorb_byte(WStrobe& st, uint8_t b) {
+    wstrobe_xor(st, st.pos, b);
+    if (++st.pos == STROBE_R) strobe_run_f(st);
+}
+__device__ __forceinline__ uint8_t strobe_squeeze_byte(WStrobe& st) {
+    const uint32_t sh = 8 * (st.pos & 7);
+    const uint8_t b = (uint8_t)(shfl64(st.a, (int)(st.pos >> 3)) >> sh);
+    if ((uint32_t)st.l == (st.pos >> 3)) st.a &= ~(0xffull << sh);
+    if (++st.pos == STROBE_R) strobe_run_f(st);
+    return b;
+}
+__device__ __forceinline__ void strobe_reset(WStrobe& st) {
+    st.a = 0;
+    st.pos = 0;
+    st.pos_begin = 0;
+}
+__device__ __forceinline__ void strobe_permute_raw(WStrobe& st) { st.a = keccak_f1600_wave(st.a, st.K, st.l); }
+#endif
+DAPOL_HD void strobe_permute_raw(Strobe& st) { keccak_f1600(st.s); }
+
+// Everything above the byte level is written once for both holders of the state (S = Strobe: one lane; S = WStrobe: a wavefront).
+template <class S>
+DAPOL_HD void strobe_begin_op(S& st, uint8_t flags) {
     uint8_t old_begin = (uint8_t)st.pos_begin;
     st.pos_begin = st.pos + 1;
     strobe_absorb_byte(st, old_begin);
     strobe_absorb_byte(st, flags);
     if ((flags & (SF_C | SF_K)) && st.pos != 0) strobe_run_f(st);
 }
-DAPOL_HD void strobe_init(Strobe& st, const char* label, int n) {  // Strobe128::new
-    for (int i = 0; i < 25; i++) st.s[i] = 0;
+template <class S>
+DAPOL_HD void strobe_init(S& st, const char* label, int n) {  // Strobe128::new
+    strobe_reset(st);
     const uint8_t hdr[18] = {1, STROBE_R + 2, 1, 0, 1, 96, 'S', 'T', 'R', 'O', 'B', 'E', 'v', '1', '.', '0', '.', '2'};
-    for (int i = 0; i < 18; i++) st.s[i >> 3] ^= (uint64_t)hdr[i] << (8 * (i & 7));
-    keccak_f1600(st.s);
+    for (int i = 0; i < 18; i++) { strobe_absorb_byte(st, hdr[i]); }      // (18 < R: plain XORs into the zero state)
     st.pos = 0;
+    strobe_permute_raw(st);
     st.pos_begin = 0;
     strobe_begin_op(st, SF_M | SF_A);
     for (int i = 0; i < n; i++) strobe_absorb_byte(st, (uint8_t)label[i]);
 }
 
 // Merlin: label framing shared by append_message / challenge_bytes.
-DAPOL_HD void merlin_frame(Strobe& st, const char* label, int label_len, uint32_t data_len) {
+template <class S>
+DAPOL_HD void merlin_frame(S& st, const char* label, int label_len, uint32_t data_len) {
     strobe_begin_op(st, SF_M | SF_A);
     for (int i = 0; i < label_len; i++) strobe_absorb_byte(st, (uint8_t)label[i]);
     for (int i = 0; i < 4; i++) strobe_absorb_byte(st, (uint8_t)(data_len >> (8 * i)));   // meta_ad(len, more=true)
 }
-DAPOL_HD void merlin_init(Strobe& st, const char* app_label, int n) {  // Transcript::new(label)
+template <class S>
+DAPOL_HD void merlin_init(S& st, const char* app_label, int n) {  // Transcript::new(label)
     strobe_init(st, LBL_STROBE_PROTO);
     merlin_frame(st, LBL_DOM_SEP, (uint32_t)n);
     strobe_begin_op(st, SF_A);
     for (int i = 0; i < n; i++) strobe_absorb_byte(st, (uint8_t)app_label[i]);
 }
-DAPOL_HD void merlin_append_bytes(Strobe& st, const char* label, int label_len, const char* msg, int n) {
+template <class S>
+DAPOL_HD void merlin_append_bytes(S& st, const char* label, int label_len, const char* msg, int n) {
     merlin_frame(st, label, label_len, (uint32_t)n);
     strobe_begin_op(st, SF_A);
     for (int i = 0; i < n; i++) strobe_absorb_byte(st, (uint8_t)msg[i]);
 }
-DAPOL_HD void merlin_append_words(Strobe& st, const char* label, int label_len, const uint32_t* w, int nwords) {
+template <class S>
+DAPOL_HD void merlin_append_words(S& st, const char* label, int label_len, const uint32_t* w, int nwords) {
     merlin_frame(st, label, label_len, (uint32_t)(4 * nwords));
     strobe_begin_op(st, SF_A);
     for (int i = 0; i < nwords; i++)
         for (int k = 0; k < 4; k++) strobe_absorb_byte(st, (uint8_t)(w[i] >> (8 * k)));
 }
-DAPOL_HD void merlin_append_u64(Strobe& st, const char* label, int label_len, uint64_t x) {
+template <class S>
+DAPOL_HD void merlin_append_u64(S& st, const char* label, int label_len, uint64_t x) {
     uint32_t w[2] = {(uint32_t)x, (uint32_t)(x >> 32)};
     merlin_append_words(st, label, label_len, w, 2);
 }
 // challenge_bytes(label, 64) as sixteen little-endian words (input of Scalar::from_bytes_mod_order_wide)
-DAPOL_HD void merlin_challenge_wide(Strobe& st, const char* label, int label_len, uint32_t* w16) {
+template <class S>
+DAPOL_HD void merlin_challenge_wide(S& st, const char* label, int label_len, uint32_t* w16) {
     merlin_frame(st, label, label_len, 64);
     strobe_begin_op(st, SF_I | SF_A | SF_C);
     for (int i = 0; i < 16; i++) {

@@ -10,6 +10,7 @@
 //   * Q = w*B is never materialised: c_L*Q = (c_L*w)*B is one more fixed-base term.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "kernels_ctx_tree.h"
 
 namespace dapol {
@@ -446,35 +447,94 @@ __device__ __forceinline__ void st_store(ProofState& p, const Strobe& s) {
     p.pos = s.pos;
     p.pos_begin = s.pos_begin;
 }
-__device__ __forceinline__ void challenge_scalar(sc& r, Strobe& s, const char* label, int n) {
+__device__ __forceinline__ void st_load(WStrobe& s, const ProofState& p) {
+    s.a = s.l < 25 ? p.strobe[s.l < 25 ? s.l : 0] : 0;
+    s.pos = p.pos;
+    s.pos_begin = p.pos_begin;
+}
+__device__ __forceinline__ void st_store(ProofState& p, const WStrobe& s) {
+    if (s.l < 25) p.strobe[s.l] = s.a;
+    if (s.l == 0) { p.pos = s.pos; p.pos_begin = s.pos_begin; }
+}
+template <class S>
+__device__ __forceinline__ void challenge_scalar(sc& r, S& s, const char* label, int n) {
     uint32_t w[16];
     merlin_challenge_wide(s, label, n, w);
     sc_from_wide(r, w);
 }
-__device__ __forceinline__ void append_scalar(Strobe& s, const char* label, int n, const uint32_t* canon8) {
+template <class S>
+__device__ __forceinline__ void append_scalar(S& s, const char* label, int n, const uint32_t* canon8) {
     merlin_append_words(s, label, n, canon8, 8);
+}
+// The lane-per-proof Fiat-Shamir kernels come in three shapes (template MODE):
+//   0  one lane per proof (throughput: tens of thousands of proofs per launch);
+//   1  PAIR: the two point computations of a proof (A and S; T_1, T_2; L_k, R_k) on two neighbouring lanes, the second encoding
+//      handed to the first, which owns the transcript -- the lane's serial chain is what a small call waits for;
+//   2  one WAVEFRONT per proof (a handful of proofs): the two point computations on lanes 0 and 32, the blinding sums spread over
+//      the lanes, the transcript held by the wavefront (WStrobe, hash.h: 4 us per Keccak permutation instead of 23).
+template <int MODE> struct FsShape {
+    using strobe_t = typename std::conditional<MODE == 2, WStrobe, Strobe>::type;
+    const int l;                 // lane in the block
+    size_t b;                    // proof
+    bool valid;
+    int h_lo, h_hi;              // the halves (0: first point, 1: second) this lane computes
+    __device__ FsShape(const RangeArgs& A) : l((int)threadIdx.x) {
+        const size_t t_ = (size_t)blockIdx.x * 64 + threadIdx.x;
+        b = MODE == 2 ? (size_t)blockIdx.x : (MODE == 1 ? t_ >> 1 : t_);
+        valid = b < A.B;
+        if (!valid) b = A.B - 1;
+        if (MODE == 0) { h_lo = 0; h_hi = 2; }
+        else if (MODE == 1) { h_lo = (int)(t_ & 1); h_hi = h_lo + 1; }
+        else { h_lo = l >> 5; h_hi = (l & 31) == 0 ? h_lo + 1 : h_lo; }       // lanes 0 and 32
+    }
+    // second encoding -> the lane that owns the transcript (MODE 1), or both -> every lane (MODE 2)
+    __device__ void share(uint32_t* first8, uint32_t* second8) const {
+        if (MODE == 1) { for (int i = 0; i < 8; i++) second8[i] = (uint32_t)__shfl_down((int)second8[i], 1, 64); }
+        if (MODE == 2) {
+            for (int i = 0; i < 8; i++) { first8[i] = (uint32_t)__shfl((int)first8[i], 0, 64); second8[i] = (uint32_t)__shfl((int)second8[i], 32, 64); }
+        }
+    }
+    __device__ bool owns_transcript() const { return MODE == 2 ? true : (MODE == 1 ? ((l & 1) == 0 && valid) : valid); }
+    __device__ bool writes() const { return MODE == 2 ? l == 0 : true; }     // (among the lanes that own the transcript)
+    __device__ void begin(strobe_t& s) const { if constexpr (MODE == 2) wstrobe_lanes(s, l); }
+};
+// Sum over the parties of one blinding stream (slot0 + j * stride): serial on a lane, or (MODE 2) spread over the 32 lanes of the
+// half-wavefront and summed by shuffles; the result is valid on the lane that computes the point (lane 0 / 32).
+template <int MODE>
+__device__ __forceinline__ void blinding_sum(sc& bl, const RangeArgs& A, size_t b, uint32_t slot0, uint32_t stride, int lane) {
+    sc t;
+    sc_zero(bl);
+    if (MODE == 2) {
+        for (int j = lane & 31; j < A.m; j += 32) {
+            tape_scalar(t, A, b, slot0 + (uint32_t)j * stride);
+            sc_add(bl, bl, t);
+        }
+        for (int off = 16; off >= 1; off >>= 1) {
+            sc o, r;
+            for (int i = 0; i < 8; i++) o.v[i] = (uint32_t)__shfl_down((int)bl.v[i], off, 64);
+            sc_add(r, bl, o);
+            bl = r;
+        }
+    } else {
+        for (int j = 0; j < A.m; j++) {
+            tape_scalar(t, A, b, slot0 + (uint32_t)j * stride);
+            sc_add(bl, bl, t);
+        }
+    }
 }
 
 // --------------------------------------------------------- F1: finish A and S, transcript up to y, z (lane/proof)
-// PAIR: small calls run the two point computations of a proof (A and S here; T_1, T_2; L_k, R_k) on two neighbouring lanes and
-// hand the second encoding to the first, which owns the transcript -- the lane's serial chain is what a lone proof waits for.
-template <int PAIR>
+template <int MODE>
 __global__ __launch_bounds__(64) void k_rp_finish1(RangeArgs A, TableView tbl) {
-    const size_t t_ = (size_t)blockIdx.x * 64 + threadIdx.x;
-    size_t b = PAIR ? t_ >> 1 : t_;
-    const bool valid = b < A.B;
-    if (!PAIR && !valid) return;
-    if (!valid) b = A.B - 1;
+    FsShape<MODE> F(A);
+    if (MODE == 0 && !F.valid) return;
+    const size_t b = F.b;
     ProofState& ps = A.st[b];
-    sc a_bl, s_bl, t;
-    uint32_t c[8], Ac[8], Sc[8];
-    for (int h = (PAIR ? (int)(t_ & 1) : 0); h < (PAIR ? (int)(t_ & 1) + 1 : 2); h++) {
+    uint32_t c[8], Ac[8] = {0}, Sc[8] = {0};
+    for (int h = (MODE == 2 ? F.l >> 5 : F.h_lo); h < (MODE == 2 ? (F.l >> 5) + 1 : F.h_hi); h++) {
         sc bl;
-        sc_zero(bl);
-        for (int j = 0; j < A.m; j++) {
-            tape_scalar(t, A, b, (uint32_t)(j * (2 * A.n + 2) + h));
-            sc_add(bl, bl, t);
-        }
+        blinding_sum<MODE>(bl, A, b, (uint32_t)h, (uint32_t)(2 * A.n + 2), F.l);       // a_blinding (h = 0) / s_blinding of every party
+        if (h >= F.h_hi) continue;                                                      // (MODE 2: only lanes 0 and 32 go on)
         ge_p3 p;
         if (h == 0) ld_p3(p, A.PA + b * 40);
         else {
@@ -487,17 +547,14 @@ __global__ __launch_bounds__(64) void k_rp_finish1(RangeArgs A, TableView tbl) {
         tbl_fixed_mul_add(p, tbl, tbl.row_Bb(0), c);
         ge_compress(c, p);
         for (int i = 0; i < 8; i++) { if (h) Sc[i] = c[i]; else Ac[i] = c[i]; }
-        if (h) s_bl = bl; else a_bl = bl;
+        if (F.valid) { if (h) ps.s_bl = bl; else ps.a_bl = bl; }
     }
-    if (PAIR) {
-        for (int i = 0; i < 8; i++) Sc[i] = __shfl_down(Sc[i], 1);
-        if (t_ & 1) { if (valid) ps.s_bl = s_bl; return; }
-        if (!valid) return;
-    }
+    F.share(Ac, Sc);
+    if (!F.owns_transcript()) return;
     uint32_t* out = A.out + b * A.out_words;
-    st8(out, Ac);
-    st8(out + 8, Sc);
-    Strobe s;
+    if (F.writes()) { st8(out, Ac); st8(out + 8, Sc); }
+    typename FsShape<MODE>::strobe_t s;
+    F.begin(s);
     merlin_init(s, LBL_APP_TRANSCRIPT);                                       // Transcript::new(&[])  (src/range/mod.rs:51,67)
     merlin_append_bytes(s, LBL_DOM_SEP, LBL_RANGEPROOF_DOMAIN);
     merlin_append_u64(s, LBL_N, (uint64_t)A.n);
@@ -513,9 +570,7 @@ __global__ __launch_bounds__(64) void k_rp_finish1(RangeArgs A, TableView tbl) {
     challenge_scalar(y, s, LBL_Y);
     challenge_scalar(z, s, LBL_Z);
     sc_invert_vartime_mont(yi, y);                          // y is a public challenge
-    ps.y = y; ps.z = z; ps.y_inv = yi; ps.a_bl = a_bl;
-    if (!PAIR) ps.s_bl = s_bl;
-    ps.err = 0;
+    if (F.writes()) { ps.y = y; ps.z = z; ps.y_inv = yi; ps.err = 0; }
     st_store(ps, s);
 }
 
@@ -562,24 +617,18 @@ __global__ __launch_bounds__(64) void k_rp_poly(RangeArgs A) {
 }
 
 // ------------------------------------------------------------- F2: T1, T2 and the challenge x (lane/proof)
-template <int PAIR>
+template <int MODE>
 __global__ __launch_bounds__(64) void k_rp_finish2(RangeArgs A, TableView tbl) {
-    const size_t t_ = (size_t)blockIdx.x * 64 + threadIdx.x;
-    size_t b = PAIR ? t_ >> 1 : t_;
-    const bool valid = b < A.B;
-    if (!PAIR && !valid) return;
-    if (!valid) b = A.B - 1;
+    FsShape<MODE> F(A);
+    if (MODE == 0 && !F.valid) return;
+    const size_t b = F.b;
     ProofState& ps = A.st[b];
-    sc t1_bl, t2_bl, t;
-    uint32_t base = (uint32_t)(A.m * (2 * A.n + 2));
-    uint32_t c[8], T1c[8], T2c[8];
-    for (int h = (PAIR ? (int)(t_ & 1) : 0); h < (PAIR ? (int)(t_ & 1) + 1 : 2); h++) {
+    const uint32_t base = (uint32_t)(A.m * (2 * A.n + 2));
+    uint32_t c[8], T1c[8] = {0}, T2c[8] = {0};
+    for (int h = (MODE == 2 ? F.l >> 5 : F.h_lo); h < (MODE == 2 ? (F.l >> 5) + 1 : F.h_hi); h++) {
         sc bl;
-        sc_zero(bl);
-        for (int j = 0; j < A.m; j++) {
-            tape_scalar(t, A, b, base + 2 * j + h);
-            sc_add(bl, bl, t);
-        }
+        blinding_sum<MODE>(bl, A, b, base + (uint32_t)h, 2u, F.l);            // t_1_blinding (h = 0) / t_2_blinding of every party
+        if (h >= F.h_hi) continue;
         ge_p3 p;
         ge_identity(p);
         sc_from_mont(c, h ? ps.t2 : ps.t1);
@@ -588,25 +637,23 @@ __global__ __launch_bounds__(64) void k_rp_finish2(RangeArgs A, TableView tbl) {
         tbl_fixed_mul_add(p, tbl, tbl.row_Bb(0), c);
         ge_compress(c, p);
         for (int i = 0; i < 8; i++) { if (h) T2c[i] = c[i]; else T1c[i] = c[i]; }
-        if (h) t2_bl = bl; else t1_bl = bl;
+        if (F.valid) { if (h) ps.t2_bl = bl; else ps.t1_bl = bl; }
     }
-    if (PAIR) {
-        for (int i = 0; i < 8; i++) T2c[i] = __shfl_down(T2c[i], 1);
-        if (t_ & 1) { if (valid) ps.t2_bl = t2_bl; return; }
-        if (!valid) return;
-    }
+    F.share(T1c, T2c);
+    if (!F.owns_transcript()) return;
     uint32_t* out = A.out + b * A.out_words;
-    st8(out + 16, T1c);
-    st8(out + 24, T2c);
-    Strobe s;
+    if (F.writes()) { st8(out + 16, T1c); st8(out + 24, T2c); }
+    typename FsShape<MODE>::strobe_t s;
+    F.begin(s);
     st_load(s, ps);
     merlin_append_words(s, LBL_T1, T1c, 8);
     merlin_append_words(s, LBL_T2, T2c, 8);
     sc x;
     challenge_scalar(x, s, LBL_X);
-    if (sc_is_zero(x)) ps.err = 1;                                // ProofError::MaliciousDealer in the crate
-    ps.x = x; ps.t1_bl = t1_bl;
-    if (!PAIR) ps.t2_bl = t2_bl;
+    if (F.writes()) {
+        if (sc_is_zero(x)) ps.err = 1;                            // ProofError::MaliciousDealer in the crate
+        ps.x = x;
+    }
     st_store(ps, s);
 }
 
@@ -650,9 +697,11 @@ __global__ __launch_bounds__(64) void k_rp_lr(RangeArgs A) {
 }
 
 // ------------------------------- F3: t_x, tau_x, mu; challenge w; inner-product domain separator (lane/proof)
+template <int MODE>                     // 0: a lane per proof; 2: a wavefront per proof (every lane computes the same scalars)
 __global__ __launch_bounds__(64) void k_rp_finish3(RangeArgs A) {
-    size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
+    size_t b = MODE == 2 ? (size_t)blockIdx.x : (size_t)blockIdx.x * 64 + threadIdx.x;
     if (b >= A.B) return;
+    const bool writes = MODE == 2 ? threadIdx.x == 0 : true;
     ProofState& ps = A.st[b];
     sc x = ps.x, z = ps.z, xx, zz, tau, mu, t, bl;
     sc_montmul(xx, x, x);
@@ -677,10 +726,13 @@ __global__ __launch_bounds__(64) void k_rp_finish3(RangeArgs A) {
     sc_from_mont(c_tau, tau);
     sc_from_mont(c_mu, mu);
     uint32_t* out = A.out + b * A.out_words;
-    st8(out + 32, c_tx);
-    st8(out + 40, c_tau);
-    st8(out + 48, c_mu);
-    Strobe s;
+    if (writes) {
+        st8(out + 32, c_tx);
+        st8(out + 40, c_tau);
+        st8(out + 48, c_mu);
+    }
+    typename std::conditional<MODE == 2, WStrobe, Strobe>::type s;
+    if constexpr (MODE == 2) wstrobe_lanes(s, (int)threadIdx.x);
     st_load(s, ps);
     append_scalar(s, LBL_TX, c_tx);
     append_scalar(s, LBL_TX_BLINDING, c_tau);
@@ -689,7 +741,7 @@ __global__ __launch_bounds__(64) void k_rp_finish3(RangeArgs A) {
     challenge_scalar(w, s, LBL_W);
     merlin_append_bytes(s, LBL_DOM_SEP, LBL_IPP_DOMAIN);
     merlin_append_u64(s, LBL_N, (uint64_t)A.N);
-    ps.w = w;
+    if (writes) ps.w = w;
     st_store(ps, s);
 }
 
@@ -736,16 +788,14 @@ __global__ __launch_bounds__(64) void k_rp_round_ip(RangeArgs A, int round) {
 }
 
 // --------------------------------------------------------- F4: L_k, R_k, challenge u_k (lane/proof)
-template <int PAIR>
+template <int MODE>
 __global__ __launch_bounds__(64) void k_rp_round_finish(RangeArgs A, TableView tbl, int round) {
-    const size_t t_ = (size_t)blockIdx.x * 64 + threadIdx.x;
-    size_t b = PAIR ? t_ >> 1 : t_;
-    const bool valid = b < A.B;
-    if (!PAIR && !valid) return;
-    if (!valid) b = A.B - 1;
+    FsShape<MODE> F(A);
+    if (MODE == 0 && !F.valid) return;
+    const size_t b = F.b;
     ProofState& ps = A.st[b];
-    uint32_t c[8], Lc[8], Rc[8];
-    for (int h = (PAIR ? (int)(t_ & 1) : 0); h < (PAIR ? (int)(t_ & 1) + 1 : 2); h++) {
+    uint32_t c[8], Lc[8] = {0}, Rc[8] = {0};
+    for (int h = F.h_lo; h < F.h_hi; h++) {
         ge_p3 p;
         sc t;
         ld_p3(p, (h ? A.P1 : A.P0) + b * 40);
@@ -755,21 +805,19 @@ __global__ __launch_bounds__(64) void k_rp_round_finish(RangeArgs A, TableView t
         ge_compress(c, p);
         for (int i = 0; i < 8; i++) { if (h) Rc[i] = c[i]; else Lc[i] = c[i]; }
     }
-    if (PAIR) {
-        for (int i = 0; i < 8; i++) Rc[i] = __shfl_down(Rc[i], 1);
-        if ((t_ & 1) || !valid) return;
-    }
+    F.share(Lc, Rc);
+    if (!F.owns_transcript()) return;
     uint32_t* out = A.out + b * A.out_words + 56 + 16 * (A.out_round0 + round);
-    st8(out, Lc);
-    st8(out + 8, Rc);
-    Strobe s;
+    if (F.writes()) { st8(out, Lc); st8(out + 8, Rc); }
+    typename FsShape<MODE>::strobe_t s;
+    F.begin(s);
     st_load(s, ps);
     merlin_append_words(s, LBL_L, Lc, 8);
     merlin_append_words(s, LBL_R, Rc, 8);
     sc u, ui;
     challenge_scalar(u, s, LBL_U);
     sc_invert_vartime_mont(ui, u);                          // u_k is a public challenge
-    ps.u = u; ps.u_inv = ui;
+    if (F.writes()) { ps.u = u; ps.u_inv = ui; }
     st_store(ps, s);
 }
 

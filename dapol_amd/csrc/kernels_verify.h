@@ -77,51 +77,6 @@ __device__ __forceinline__ bool words_zero(const uint32_t* w) {
 //  * the permutation runs with one 64-bit state word per lane (lane = x + 5 y): theta, rho/pi and chi are nine lane
 //    permutations (ds_bpermute) and a dozen ALU operations per round instead of ~500.
 // The state it leaves in vs.st / st_pos / st_pos_begin is bit for bit what the lane-per-proof loop would hold.
-__device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) {
-    uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src, 64), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64);
-    return ((uint64_t)hi << 32) | lo;
-}
-struct KeccakLanes {                 // per-lane source lanes of the round's permutations
-    int th1, th2, th3, th4, xp1, xp2, pi_src, cm_src, cp_src, rot_src;
-};
-__device__ __forceinline__ void keccak_lanes_init(KeccakLanes& K, int l) {
-    const int ROT[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
-    if (l >= 25) { K.th1 = K.th2 = K.th3 = K.th4 = K.xp1 = K.xp2 = K.pi_src = K.cm_src = K.cp_src = l; K.rot_src = 0; return; }
-    int x = l % 5, y = l / 5, row = 5 * y;
-    K.th1 = (l + 5) % 25; K.th2 = (l + 10) % 25; K.th3 = (l + 15) % 25; K.th4 = (l + 20) % 25;
-    K.xp1 = row + (x + 1) % 5; K.xp2 = row + (x + 2) % 5;
-    // pi: B[x'][y'] = rot(A[x][y]) with (x', y') = (y, 2x + 3y): lane (x', y') pulls from y = x', x = 3 (y' - 3 x') mod 5
-    int sy = x, sx = (3 * ((y - 3 * x) % 5 + 5)) % 5;
-    K.pi_src = sx + 5 * sy;
-    K.cm_src = (sx + 4) % 5;         // any lane of column sx - 1 / sx + 1 holds that column's parity: row 0
-    K.cp_src = (sx + 1) % 5;
-    int r = 0;
-    for (int i = 0; i < 25; i++) r = (i == K.pi_src) ? ROT[i] : r;
-    K.rot_src = r;
-}
-// Three dependent permutation stages per round: (1) the column parities and, alongside, every lane's pi source word;
-// (2) the two parities theta needs for the SOURCE's column -- theta, rho and pi are then applied at the destination;
-// (3) chi's two row neighbours.
-__device__ __forceinline__ uint64_t keccak_f1600_wave(uint64_t a, const KeccakLanes& K, int l) {
-    const uint64_t RC[24] = {0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808Aull, 0x8000000080008000ull,
-                             0x000000000000808Bull, 0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull,
-                             0x000000000000008Aull, 0x0000000000000088ull, 0x0000000080008009ull, 0x000000008000000Aull,
-                             0x000000008000808Bull, 0x800000000000008Bull, 0x8000000000008089ull, 0x8000000000008003ull,
-                             0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800Aull, 0x800000008000000Aull,
-                             0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
-    for (int r = 0; r < 24; r++) {
-        uint64_t as = shfl64(a, K.pi_src);
-        uint64_t c = a ^ shfl64(a, K.th1) ^ shfl64(a, K.th2) ^ shfl64(a, K.th3) ^ shfl64(a, K.th4);    // C[x] on every lane of column x
-        uint64_t cm = shfl64(c, K.cm_src), cp = shfl64(c, K.cp_src);
-        as ^= cm ^ ((cp << 1) | (cp >> 63));
-        uint64_t b = K.rot_src ? ((as << K.rot_src) | (as >> (64 - K.rot_src))) : as;
-        uint64_t b1 = shfl64(b, K.xp1), b2 = shfl64(b, K.xp2);
-        a = b ^ (~b1 & b2);
-        if (l == 0) a ^= RC[r];
-    }
-    return a;
-}
-
 enum { RV_V_BYTES = 41 };            // stream bytes per commitment
 __global__ __launch_bounds__(64) void k_rv_absorb_V(VerifyArgs V) {
     __shared__ uint64_t sh[25];
@@ -192,17 +147,25 @@ __global__ __launch_bounds__(64) void k_rv_absorb_V(VerifyArgs V) {
 }
 
 // V1: parse + replay the transcript (lane per proof).
+// WAVE = 1 (calls of a few proofs): one wavefront per proof, every lane replaying the same transcript with the state spread over
+// the lanes (WStrobe, hash.h) -- 4 us per Keccak permutation instead of 23; all lanes compute, and store, the same values.
+__device__ __forceinline__ void rv_state_from_absorb(Strobe& s, const VerifyState& vs) {
+    for (int i = 0; i < 25; i++) s.s[i] = vs.st[i];
+}
+__device__ __forceinline__ void rv_state_from_absorb(WStrobe& s, const VerifyState& vs) { s.a = s.l < 25 ? vs.st[s.l < 25 ? s.l : 0] : 0; }
+template <int WAVE>
 __global__ __launch_bounds__(64) void k_rv_transcript(VerifyArgs V) {
     const RangeArgs& A = V.R;
-    size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
+    size_t b = WAVE ? (size_t)blockIdx.x : (size_t)blockIdx.x * 64 + threadIdx.x;
     if (b >= A.B) return;
     VerifyState& vs = V.vs[b];
     const uint32_t* pr = A.out + b * A.out_words;
     bool ok = true;
     uint32_t w8[8];
-    Strobe s;
+    typename std::conditional<WAVE != 0, WStrobe, Strobe>::type s;
+    if constexpr (WAVE != 0) wstrobe_lanes(s, (int)threadIdx.x);
     if (V.wave_transcript) {                                     // k_rv_absorb_V has done the head and the commitments
-        for (int i = 0; i < 25; i++) s.s[i] = vs.st[i];
+        rv_state_from_absorb(s, vs);
         s.pos = vs.st_pos;
         s.pos_begin = vs.st_pos_begin;
     } else {

@@ -835,9 +835,14 @@ def test_wavefront_transcript_equals_lane_transcript(gpu_ctx, n_bits, m, b):
                     else:
                         os.environ.pop("DAPOL_VERIFY_NO_RLC", None)
                     out.append(list(gpu_ctx.range_verify_batch(n_bits, m, p, vv, verify_seed=SEED)))
+                    if rlc:                     # per-proof path of a small call: the whole replay by a wavefront (default) or by a lane
+                        os.environ["DAPOL_VERIFY_LANE_TRANSCRIPT"] = "1"
+                        out.append(list(gpu_ctx.range_verify_batch(n_bits, m, p, vv, verify_seed=SEED)))
+                        os.environ.pop("DAPOL_VERIFY_LANE_TRANSCRIPT", None)
         finally:
             os.environ.pop("DAPOL_VERIFY_WAVE_TRANSCRIPT", None)
             os.environ.pop("DAPOL_VERIFY_NO_RLC", None)
+            os.environ.pop("DAPOL_VERIFY_LANE_TRANSCRIPT", None)
         assert all(o == out[0] for o in out), out
         return out[0]
 
@@ -963,7 +968,7 @@ def test_every_proving_strategy_gives_the_same_bytes(gpu_ctx, n_bits, m):
                 # the small-call (latency) arrangements and the opt-in fused fold
                 {"DAPOL_SMALL_TAIL": "1"}, {"DAPOL_SMALL_TAIL": "1", "DAPOL_NO_SPLIT_MAT": "1"}, {"DAPOL_SMALL_SPLIT": "16"}, {"DAPOL_SMALL_SPLIT": "2"},
                 {"DAPOL_NO_SMALL_HI": "1"}, {"DAPOL_NO_PAIR": "1"}, {"DAPOL_FUSE_FOLD": "1"}, {"DAPOL_FUSE_FOLD": "1", "DAPOL_SMALL_TAIL": "1"},
-                {"DAPOL_FUSE_FOLD": "1", "DAPOL_NO_SPLIT": "1"}):
+                {"DAPOL_FUSE_FOLD": "1", "DAPOL_NO_SPLIT": "1"}, {"DAPOL_FS_SHAPE": "0"}, {"DAPOL_FS_SHAPE": "1"}, {"DAPOL_FS_SHAPE": "2", "DAPOL_NO_SPLIT": "1"}):
         os.environ.update(env)
         try:
             got = gpu_ctx.range_prove_batch(n_bits, m, v, r, nonce_seed=SEED, stream_id=sid).tobytes()
