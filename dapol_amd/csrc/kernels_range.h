@@ -190,6 +190,25 @@ __device__ __forceinline__ void wave_reduce_sc(sc& acc) {
     }
 }
 
+// s * Base by the 32 lanes of a half-wavefront (s the same on all of them): the base points have one table row per window, so
+// lane `sub` looks its window's digit up and a shuffle tree adds the (at most 32) entries -- one lookup and five additions deep
+// instead of a chain of nwin.  The sum is valid on the lane with sub == 0.
+__device__ __forceinline__ void tbl_fixed_mul_wave(ge_p3& out, const TableView& t, int row0, const uint32_t* s8, int sub) {
+    int carry = 0, mine = 0;
+    const int W = t.wbits, NW = t.nwin();
+    for (int i = 0; i < NW; i++) {
+        int o = i * W, wd = o >> 5, sh = o & 31;
+        uint32_t lo = wd < 8 ? s8[wd] >> sh : 0u;
+        uint32_t hi = (sh && wd + 1 < 8) ? (s8[wd + 1] << (32 - sh)) : 0u;
+        int b = (int)((lo | hi) & ((1u << W) - 1)) + carry;
+        carry = (b >= (1 << (W - 1)) && i < NW - 1) ? 1 : 0;
+        if (i == sub) mine = b - (carry << W);
+    }
+    ge_identity(out);
+    if (sub < NW) tbl_madd(out, t, row0 + sub, mine);
+    wave_reduce_point(out, 32);
+}
+
 // ---------------------------------------------------------------------------- K0: nonces s_L, s_R + S digits
 // grid = B * (TP/64) blocks of 64.  Lane (side, q): draws s_L[q] (side 0) or s_R[q] (side 1) from the tape in
 // the crate's slot order, stores it (Montgomery) and writes its signed radix-256 digits for the S MSM.
@@ -470,8 +489,9 @@ __device__ __forceinline__ void append_scalar(S& s, const char* label, int n, co
 //   0  one lane per proof (throughput: tens of thousands of proofs per launch);
 //   1  PAIR: the two point computations of a proof (A and S; T_1, T_2; L_k, R_k) on two neighbouring lanes, the second encoding
 //      handed to the first, which owns the transcript -- the lane's serial chain is what a small call waits for;
-//   2  one WAVEFRONT per proof (a handful of proofs): the two point computations on lanes 0 and 32, the blinding sums spread over
-//      the lanes, the transcript held by the wavefront (WStrobe, hash.h: 4 us per Keccak permutation instead of 23).
+//   2  one WAVEFRONT per proof (a handful of proofs): the two point computations by the two half-wavefronts (blinding sums and the
+//      windows of the fixed-base products spread over the lanes, lanes 0 and 32 add up and encode), the transcript held by the
+//      wavefront (WStrobe, hash.h: 4 us per Keccak permutation instead of 23).
 template <int MODE> struct FsShape {
     using strobe_t = typename std::conditional<MODE == 2, WStrobe, Strobe>::type;
     const int l;                 // lane in the block
@@ -485,7 +505,7 @@ template <int MODE> struct FsShape {
         if (!valid) b = A.B - 1;
         if (MODE == 0) { h_lo = 0; h_hi = 2; }
         else if (MODE == 1) { h_lo = (int)(t_ & 1); h_hi = h_lo + 1; }
-        else { h_lo = l >> 5; h_hi = (l & 31) == 0 ? h_lo + 1 : h_lo; }       // lanes 0 and 32
+        else { h_lo = l >> 5; h_hi = h_lo + 1; }                               // half-wavefront h; its lane 0 ends with the point
     }
     // second encoding -> the lane that owns the transcript (MODE 1), or both -> every lane (MODE 2)
     __device__ void share(uint32_t* first8, uint32_t* second8) const {
@@ -494,12 +514,13 @@ template <int MODE> struct FsShape {
             for (int i = 0; i < 8; i++) { first8[i] = (uint32_t)__shfl((int)first8[i], 0, 64); second8[i] = (uint32_t)__shfl((int)second8[i], 32, 64); }
         }
     }
+    __device__ bool point_lane() const { return MODE == 2 ? (l & 31) == 0 : true; }
     __device__ bool owns_transcript() const { return MODE == 2 ? true : (MODE == 1 ? ((l & 1) == 0 && valid) : valid); }
     __device__ bool writes() const { return MODE == 2 ? l == 0 : true; }     // (among the lanes that own the transcript)
     __device__ void begin(strobe_t& s) const { if constexpr (MODE == 2) wstrobe_lanes(s, l); }
 };
 // Sum over the parties of one blinding stream (slot0 + j * stride): serial on a lane, or (MODE 2) spread over the 32 lanes of the
-// half-wavefront and summed by shuffles; the result is valid on the lane that computes the point (lane 0 / 32).
+// half-wavefront and summed by shuffles (every lane of the half ends with the sum).
 template <int MODE>
 __device__ __forceinline__ void blinding_sum(sc& bl, const RangeArgs& A, size_t b, uint32_t slot0, uint32_t stride, int lane) {
     sc t;
@@ -515,6 +536,7 @@ __device__ __forceinline__ void blinding_sum(sc& bl, const RangeArgs& A, size_t 
             sc_add(r, bl, o);
             bl = r;
         }
+        for (int i = 0; i < 8; i++) bl.v[i] = (uint32_t)__shfl((int)bl.v[i], lane & 32, 64);       // every lane of the half
     } else {
         for (int j = 0; j < A.m; j++) {
             tape_scalar(t, A, b, slot0 + (uint32_t)j * stride);
@@ -531,11 +553,13 @@ __global__ __launch_bounds__(64) void k_rp_finish1(RangeArgs A, TableView tbl) {
     const size_t b = F.b;
     ProofState& ps = A.st[b];
     uint32_t c[8], Ac[8] = {0}, Sc[8] = {0};
-    for (int h = (MODE == 2 ? F.l >> 5 : F.h_lo); h < (MODE == 2 ? (F.l >> 5) + 1 : F.h_hi); h++) {
+    for (int h = F.h_lo; h < F.h_hi; h++) {
         sc bl;
         blinding_sum<MODE>(bl, A, b, (uint32_t)h, (uint32_t)(2 * A.n + 2), F.l);       // a_blinding (h = 0) / s_blinding of every party
-        if (h >= F.h_hi) continue;                                                      // (MODE 2: only lanes 0 and 32 go on)
-        ge_p3 p;
+        sc_from_mont(c, bl);
+        ge_p3 p, q;
+        if (MODE == 2) tbl_fixed_mul_wave(q, tbl, tbl.row_Bb(0), c, F.l & 31);
+        if (!F.point_lane()) continue;
         if (h == 0) ld_p3(p, A.PA + b * 40);
         else {
             ge_p3 p0, p1;
@@ -543,8 +567,8 @@ __global__ __launch_bounds__(64) void k_rp_finish1(RangeArgs A, TableView tbl) {
             ld_p3(p1, A.P1 + b * 40);
             ge_add(p, p0, p1);
         }
-        sc_from_mont(c, bl);
-        tbl_fixed_mul_add(p, tbl, tbl.row_Bb(0), c);
+        if (MODE == 2) { ge_p3 r; ge_add(r, p, q); p = r; }
+        else tbl_fixed_mul_add(p, tbl, tbl.row_Bb(0), c);
         ge_compress(c, p);
         for (int i = 0; i < 8; i++) { if (h) Sc[i] = c[i]; else Ac[i] = c[i]; }
         if (F.valid) { if (h) ps.s_bl = bl; else ps.a_bl = bl; }
@@ -625,16 +649,27 @@ __global__ __launch_bounds__(64) void k_rp_finish2(RangeArgs A, TableView tbl) {
     ProofState& ps = A.st[b];
     const uint32_t base = (uint32_t)(A.m * (2 * A.n + 2));
     uint32_t c[8], T1c[8] = {0}, T2c[8] = {0};
-    for (int h = (MODE == 2 ? F.l >> 5 : F.h_lo); h < (MODE == 2 ? (F.l >> 5) + 1 : F.h_hi); h++) {
+    for (int h = F.h_lo; h < F.h_hi; h++) {
         sc bl;
         blinding_sum<MODE>(bl, A, b, base + (uint32_t)h, 2u, F.l);            // t_1_blinding (h = 0) / t_2_blinding of every party
-        if (h >= F.h_hi) continue;
         ge_p3 p;
-        ge_identity(p);
-        sc_from_mont(c, h ? ps.t2 : ps.t1);
-        tbl_fixed_mul_add(p, tbl, tbl.row_B(0), c);
-        sc_from_mont(c, bl);
-        tbl_fixed_mul_add(p, tbl, tbl.row_Bb(0), c);
+        if (MODE == 2) {
+            ge_p3 q;
+            sc_from_mont(c, h ? ps.t2 : ps.t1);
+            tbl_fixed_mul_wave(p, tbl, tbl.row_B(0), c, F.l & 31);
+            sc_from_mont(c, bl);
+            tbl_fixed_mul_wave(q, tbl, tbl.row_Bb(0), c, F.l & 31);
+            if (!F.point_lane()) continue;
+            ge_p3 r;
+            ge_add(r, p, q);
+            p = r;
+        } else {
+            ge_identity(p);
+            sc_from_mont(c, h ? ps.t2 : ps.t1);
+            tbl_fixed_mul_add(p, tbl, tbl.row_B(0), c);
+            sc_from_mont(c, bl);
+            tbl_fixed_mul_add(p, tbl, tbl.row_Bb(0), c);
+        }
         ge_compress(c, p);
         for (int i = 0; i < 8; i++) { if (h) T2c[i] = c[i]; else T1c[i] = c[i]; }
         if (F.valid) { if (h) ps.t2_bl = bl; else ps.t1_bl = bl; }
@@ -796,12 +831,15 @@ __global__ __launch_bounds__(64) void k_rp_round_finish(RangeArgs A, TableView t
     ProofState& ps = A.st[b];
     uint32_t c[8], Lc[8] = {0}, Rc[8] = {0};
     for (int h = F.h_lo; h < F.h_hi; h++) {
-        ge_p3 p;
+        ge_p3 p, q;
         sc t;
-        ld_p3(p, (h ? A.P1 : A.P0) + b * 40);
         sc_montmul(t, h ? ps.cR : ps.cL, ps.w);
         sc_from_mont(c, t);
-        tbl_fixed_mul_add(p, tbl, tbl.row_B(0), c);           // + c_L * Q,  Q = w * B
+        if (MODE == 2) tbl_fixed_mul_wave(q, tbl, tbl.row_B(0), c, F.l & 31);
+        if (!F.point_lane()) continue;
+        ld_p3(p, (h ? A.P1 : A.P0) + b * 40);
+        if (MODE == 2) { ge_p3 r; ge_add(r, p, q); p = r; }
+        else tbl_fixed_mul_add(p, tbl, tbl.row_B(0), c);      // + c_L * Q,  Q = w * B
         ge_compress(c, p);
         for (int i = 0; i < 8; i++) { if (h) Rc[i] = c[i]; else Lc[i] = c[i]; }
     }
