@@ -359,11 +359,53 @@ static int32_t tree_build_device(dapol_ctx* ctx, int index_bits, int shard_bits,
             pad_off += align_up(bound[k], 256);
         }
     }
-    HIPCHK(flag.alloc(n)); HIPCHK(pos.alloc(n)); HIPCHK(head.alloc(n)); HIPCHK(bsums.alloc(nblk(n, 1024) + 1));
-    DevBuf<int32_t> ext_a, ext_b;
-    HIPCHK(ext_a.alloc(n * 40)); HIPCHK(ext_b.alloc(n * 40));
     const uint32_t n32 = (uint32_t)n;
     HIPCHK(hipMemcpyAsync(cnt.p, &n32, 4, hipMemcpyHostToDevice, st));
+    DevBuf<int32_t> ext_a, ext_b;
+    const bool phased = n <= (size_t)TREE_SMALL_MAX && height >= 1 && !getenv("DAPOL_TREE_LEVELWISE");
+    if (phased) {
+        // Small trees, by phases (kernels_ctx_tree.h, "small trees"): structure, all padding nodes, point sums level by level, all
+        // encodings, hashes level by level.  The extended points of every level are kept until the encodings are done.
+        std::vector<uint32_t> h_off((size_t)height + 2);
+        size_t tot = 0;
+        for (int k = 0; k <= height; k++) { h_off[k] = (uint32_t)tot; tot += bound[k]; }
+        h_off[(size_t)height + 1] = (uint32_t)tot;
+        std::vector<LevelView> hv((size_t)height + 1);
+        for (int k = 0; k <= height; k++) hv[k] = t->view(k, nullptr);
+        // temporaries from the context's scratch (a fresh hipMalloc of a few MB costs more than the whole build)
+        const size_t b_ext = align_up(tot * 160, 256), b_pad = align_up((size_t)h_off[height] * 160, 256), b_off = align_up(h_off.size() * 4, 256);
+        HIPCHK(ctx->scratch.ensure(b_ext + b_pad + b_off));
+        int32_t* const ext_all = (int32_t*)ctx->scratch.p;
+        int32_t* const extpad_all = (int32_t*)((uint8_t*)ctx->scratch.p + b_ext);
+        uint32_t* const d_off = (uint32_t*)((uint8_t*)ctx->scratch.p + b_ext + b_pad);
+        if (t->d_views.n != hv.size()) HIPCHK(t->d_views.alloc(hv.size()));
+        HIPCHK(hipMemcpyAsync(t->d_views.p, hv.data(), hv.size() * sizeof(LevelView), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(d_off, h_off.data(), h_off.size() * 4, hipMemcpyHostToDevice, st));
+        // the leaves' commitments do not depend on the structure: they run on a side stream beside S and P
+        HIPCHK(hipEventRecord(ctx->ev_fork, st));
+        HIPCHK(hipStreamWaitEvent(ctx->side[0], ctx->ev_fork, 0));
+        hipLaunchKernelGGL(k_commit_hash, dim3(nblk(n, 64)), dim3(64), 0, ctx->side[0], ctx->tv, n, d_v, d_r, t->levels[0].C.p, t->levels[0].H.p, ext_all);
+        LAUNCH_CHECK();
+        HIPCHK(hipEventRecord(ctx->ev_join[0], ctx->side[0]));
+        hipLaunchKernelGGL(k_tree_structure_small, dim3(1), dim3(1024), 0, st, height, t->d_views.p, cnt.p);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_tree_padding_all, dim3(nblk(h_off[height], 64)), dim3(64), 0, st, ctx->tv, t->d_views.p, height, cnt.p, d_off, seed.p, extpad_all);
+        LAUNCH_CHECK();
+        HIPCHK(hipStreamWaitEvent(st, ctx->ev_join[0], 0));
+        for (int k = 0; k < height; k++) {
+            hipLaunchKernelGGL(k_tree_sum_level, dim3(nblk(bound[k], 64)), dim3(64), 0, st, hv[k], hv[k + 1], k, cnt.p, ext_all + (size_t)h_off[k] * 40,
+                               extpad_all + (size_t)h_off[k] * 40, ext_all + (size_t)h_off[k + 1] * 40);
+            LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(k_tree_compress_all, dim3(nblk(tot - h_off[1], 64)), dim3(64), 0, st, t->d_views.p, height, cnt.p, d_off, ext_all);
+        LAUNCH_CHECK();
+        for (int k = 0; k < height; k++) {
+            hipLaunchKernelGGL(k_tree_hash_level, dim3(nblk(bound[k], 64)), dim3(64), 0, st, ctx->tv.digest, hv[k], hv[k + 1], k, cnt.p);
+            LAUNCH_CHECK();
+        }
+    } else {
+    HIPCHK(flag.alloc(n)); HIPCHK(pos.alloc(n)); HIPCHK(head.alloc(n)); HIPCHK(bsums.alloc(nblk(n, 1024) + 1));
+    HIPCHK(ext_a.alloc(n * 40)); HIPCHK(ext_b.alloc(n * 40));
     hipLaunchKernelGGL(k_commit_hash, dim3(nblk(n, 256)), dim3(256), 0, st, ctx->tv, n, d_v, d_r, t->levels[0].C.p, t->levels[0].H.p, ext_a.p);
     LAUNCH_CHECK();
     int32_t* ext_cur = ext_a.p;
@@ -383,6 +425,7 @@ static int32_t tree_build_device(dapol_ctx* ctx, int index_bits, int shard_bits,
         LAUNCH_CHECK();
         std::swap(ext_cur, ext_nxt);
     }
+    }
     std::vector<uint32_t> h_cnt((size_t)height + 1);
     HIPCHK(hipMemcpyAsync(h_cnt.data(), cnt.p, ((size_t)height + 1) * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -393,7 +436,7 @@ static int32_t tree_build_device(dapol_ctx* ctx, int index_bits, int shard_bits,
     }
     std::vector<LevelView> hv((size_t)height + 1);
     for (int k = 0; k <= height; k++) hv[k] = t->view(k, nullptr);
-    HIPCHK(t->d_views.alloc(hv.size()));
+    if (t->d_views.n != hv.size()) HIPCHK(t->d_views.alloc(hv.size()));
     HIPCHK(hipMemcpy(t->d_views.p, hv.data(), hv.size() * sizeof(LevelView), hipMemcpyHostToDevice));
     return DAPOL_OK;
 }

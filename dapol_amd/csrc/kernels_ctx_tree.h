@@ -308,6 +308,163 @@ __global__ __launch_bounds__(256) void k_tree_merge(TableView tbl, LevelView cur
     if (nxt.ext) st_p3(nxt.ext + q * 40, pp);
 }
 
+// ------------------------------------------------------------------------------------- small trees, by phases
+// k_tree_merge makes a level in one pass, which is right for millions of nodes (one trip through HBM) and wrong for a tree of a
+// few thousand (the reference's `build` criterion group, benches/dapol.rs:24-57; dapol_tree_update): a level is then ONE lane's
+// chain -- a padding node's fixed-base product and encoding, the parent's encoding, the hashes: 0.16 ms -- times `height`.  Only
+// three things really are sequential over the levels: who is whose parent (integers), the parents' POINTS (one addition per
+// level) and the hash chain; the fixed-base products and the inverse square roots of all levels can run side by side.  So:
+//   S  k_tree_structure_small   one block walks all levels: parent slots, pairs, index of every parent          (integers)
+//   P  k_tree_padding_all       every padding node of every level: blinding, point, encoding, hash              (one launch)
+//   M  k_tree_sum_level         level by level: v, r and the extended point of every parent                     (height launches)
+//   C  k_tree_compress_all      the encodings of all parents of all levels                                      (one launch)
+//   H  k_tree_hash_level        level by level: the parents' hashes                                             (height launches)
+// The arrays they leave are exactly k_tree_merge's.
+enum { TREE_SMALL_MAX = 8192, TREE_SMALL_PER = 8 };   // leaves; nodes per thread of the structure block (1024 threads)
+
+__global__ __launch_bounds__(1024) void k_tree_structure_small(int height, const LevelView* views, uint32_t* cnt) {
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint64_t sidx[2][TREE_SMALL_MAX];                     // the level's node indexes and the next level's (128 KB of LDS)
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    uint32_t cur_n = cnt[0];
+    {
+        const uint64_t* idx0 = views[0].idx;
+        for (uint32_t i = (uint32_t)t; i < cur_n; i += 1024) sidx[0][i] = idx0[i];
+    }
+    __syncthreads();
+    for (int k = 0; k < height; k++) {
+        const LevelView cur = views[k], nxt = views[k + 1];
+        const uint64_t* src = sidx[k & 1];
+        uint64_t* dst = sidx[(k + 1) & 1];
+        const uint32_t base = (uint32_t)t * TREE_SMALL_PER;
+        uint64_t v[TREE_SMALL_PER + 1];
+        for (int e = 0; e <= TREE_SMALL_PER; e++) v[e] = (base + e < cur_n) ? src[base + e] : ~0ull;
+        const uint64_t prev = (base > 0 && base <= cur_n) ? src[base - 1] : ~0ull;
+        uint32_t f = 0, local = 0;                                   // bit e: node base + e starts a new parent
+        for (int e = 0; e < TREE_SMALL_PER; e++) {
+            const uint32_t i = base + e;
+            const uint64_t before = e ? v[e - 1] : prev;
+            if (i < cur_n && (i == 0 || (v[e] >> 1) != (before >> 1))) { f |= 1u << e; local++; }
+        }
+        uint32_t x = local;
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t y = __shfl_up(x, off);
+            if (lane >= off) x += y;
+        }
+        if (lane == 63) wave_tot[wv] = x;
+        __syncthreads();
+        uint32_t add = 0, all = 0;
+        for (int w = 0; w < 16; w++) { if (w < wv) add += wave_tot[w]; all += wave_tot[w]; }
+        uint32_t q = x - local + add;                                // parents started before this thread's nodes
+        for (int e = 0; e < TREE_SMALL_PER; e++) {
+            const uint32_t i = base + e;
+            if (i >= cur_n) break;
+            if ((f >> e) & 1u) {
+                const bool pair = (i + 1 < cur_n) && v[e + 1] == (v[e] ^ 1ull);
+                cur.parent[i] = q;
+                cur.has_pad[i] = pair ? 0 : 1;
+                nxt.idx[q] = v[e] >> 1;
+                dst[q] = v[e] >> 1;
+                q++;
+            } else {                                                 // the second node of a pair: its sibling's parent
+                cur.parent[i] = q - 1;
+                cur.has_pad[i] = 0;
+            }
+        }
+        cur_n = all;
+        if (t == 0) cnt[k + 1] = all;
+        __syncthreads();                                             // dst is the next level's src; wave_tot is reused
+    }
+}
+// Which level a flattened node number belongs to (lvl_off[k] = nodes below level k by the host-side bounds).
+__device__ __forceinline__ int tree_level_of(size_t t, const uint32_t* lvl_off, int nlev) {
+    int k = 0;
+    while (k + 1 < nlev && t >= lvl_off[k + 1]) k++;
+    return k;
+}
+__global__ __launch_bounds__(64) void k_tree_padding_all(TableView tbl, const LevelView* views, int height, const uint32_t* cnt, const uint32_t* lvl_off,
+                                                        const uint32_t* pad_seed, int32_t* extpad) {
+    const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (t >= lvl_off[height]) return;                                // (the root level has no sibling)
+    const int level = tree_level_of(t, lvl_off, height);
+    const size_t i = t - lvl_off[level];
+    const LevelView cur = views[level];
+    if (i >= cnt[level] || !cur.has_pad[i]) return;
+    uint32_t seed[8], wide[16], rB[8], cB[8], hB[8];
+    for (int k = 0; k < 8; k++) seed[k] = pad_seed[k];
+    seed_wide(wide, seed, 1u, (uint64_t)level, cur.idx[i] ^ 1ull);  // Paddable::padding with the positional blinding (k_tree_merge)
+    sc rm;
+    sc_from_wide(rm, wide);
+    sc_from_mont(rB, rm);
+    ge_p3 pB;
+    ge_identity(pB);
+    tbl_fixed_mul_add(pB, tbl, tbl.row_Bb(0), rB);
+    ge_compress(cB, pB);
+    node_hash32(tbl.digest, hB, cB);
+    st8(cur.padC + i * 8, cB);
+    st8(cur.padH + i * 8, hB);
+    st8(cur.padr + i * 8, rB);
+    st_p3(extpad + t * 40, pB);
+}
+__global__ __launch_bounds__(64) void k_tree_sum_level(LevelView cur, LevelView nxt, int level, const uint32_t* cnt, const int32_t* ext_cur,
+                                                      const int32_t* extpad_cur, int32_t* ext_nxt) {
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= cnt[level]) return;
+    const uint32_t q = cur.parent[i];
+    if (i > 0 && cur.parent[i - 1] == q) return;                    // the second node of a pair
+    const bool pair = !cur.has_pad[i];
+    uint32_t rA[8], rB[8], rp[8];
+    ge_p3 pA, pB, pp;
+    ld8(rA, cur.r + i * 8);
+    ld_p3(pA, ext_cur + i * 40);
+    uint64_t vB = 0;
+    if (pair) {
+        ld8(rB, cur.r + (i + 1) * 8);
+        ld_p3(pB, ext_cur + (i + 1) * 40);
+        vB = cur.v[i + 1];
+    } else {
+        ld8(rB, cur.padr + i * 8);
+        ld_p3(pB, extpad_cur + i * 40);
+    }
+    sc ma, mb, ms;                                                   // r = (r_L + r_R) mod l  (node.rs:75)
+    sc_to_mont(ma, rA);
+    sc_to_mont(mb, rB);
+    sc_add(ms, ma, mb);
+    sc_from_mont(rp, ms);
+    ge_add(pp, pA, pB);
+    nxt.v[q] = cur.v[i] + vB;                                        // u64 wrap == release-mode Rust (node.rs:72)
+    st8(nxt.r + (size_t)q * 8, rp);
+    st_p3(ext_nxt + (size_t)q * 40, pp);
+}
+__global__ __launch_bounds__(64) void k_tree_compress_all(const LevelView* views, int height, const uint32_t* cnt, const uint32_t* lvl_off,
+                                                         const int32_t* ext_all) {
+    const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x + lvl_off[1];       // levels 1 .. height
+    if (t >= lvl_off[height + 1]) return;
+    const int level = tree_level_of(t, lvl_off, height + 1);
+    const size_t q = t - lvl_off[level];
+    if (q >= cnt[level]) return;
+    ge_p3 p;
+    uint32_t c[8];
+    ld_p3(p, ext_all + t * 40);
+    ge_compress(c, p);
+    st8(views[level].C + q * 8, c);
+}
+__global__ __launch_bounds__(64) void k_tree_hash_level(int digest, LevelView cur, LevelView nxt, int level, const uint32_t* cnt) {
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= cnt[level]) return;
+    const uint32_t q = cur.parent[i];
+    if (i > 0 && cur.parent[i - 1] == q) return;
+    const bool pair = !cur.has_pad[i];
+    uint32_t cA[8], hA[8], cB[8], hB[8], hp[8];
+    ld8(cA, cur.C + i * 8);
+    ld8(hA, cur.H + i * 8);
+    if (pair) { ld8(cB, cur.C + (i + 1) * 8); ld8(hB, cur.H + (i + 1) * 8); }
+    else { ld8(cB, cur.padC + i * 8); ld8(hB, cur.padH + i * 8); }
+    if (pair || (cur.idx[i] & 1ull) == 0) node_hash128(digest, hp, cA, cB, hA, hB);       // Mergeable::merge (node.rs:64-80)
+    else node_hash128(digest, hp, cB, cA, hB, hA);
+    st8(nxt.H + (size_t)q * 8, hp);
+}
+
 // Validation of the leaf index array: strictly increasing and below 2^height (smtree panics otherwise).
 __global__ void k_tree_check_leaves(size_t n, const uint64_t* idx, int index_bits, int levels, uint32_t* bad) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
