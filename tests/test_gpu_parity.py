@@ -1355,3 +1355,38 @@ def test_high_half_rows_do_not_change_bytes(hip_lib, ref):
     p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
     assert ref.ref_range_prove(n_bits, m, p(v[0]), p(r[0]), SEED, ctypes.c_uint64(int(sid[0])), ctypes.c_uint64(0), None, 0, out) == 0
     assert out.raw == outs[0][:ps]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("height,n", [(1, 1), (1, 2), (3, 8), (5, 1), (9, 300), (13, 8192), (16, 1024), (20, 5000), (32, 1500), (64, 700), (14, 8193)])
+def test_phased_and_levelwise_tree_builds_agree(gpu_ctx, hip_lib, height, n):
+    """Trees of at most 8,192 leaves are built by phases (structure in one block, all padding nodes at once, sums and hashes level by
+    level); larger ones level by level in one merge kernel per level.  Both must leave the same tree: root, node counts and every
+    Merkle path with its secrets -- full trees, a single leaf, sibling pairs, 64-bit indexes, the switch-over sizes."""
+    import os
+    rng = np.random.default_rng(1000 * height + n)
+    if n == 1 << height:
+        idx = np.arange(n, dtype=np.uint64)
+        v = rng.integers(0, 2**32, size=n, dtype=np.uint64)
+        r = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+        r[:, 31] &= 0x0F
+    else:
+        idx, v, r = _rand_leaves(rng, height, n)
+        if len(idx) > 3 and height >= 2:                       # make sure real sibling pairs occur
+            idx[1] = idx[0] ^ np.uint64(1)
+            idx = np.unique(idx)
+            v, r = v[:len(idx)], r[:len(idx)]
+    pick = idx if len(idx) <= 64 else np.sort(np.unique(idx[rng.integers(0, len(idx), size=64)]))
+    got = []
+    for env in ({}, {"DAPOL_TREE_LEVELWISE": "1"}):
+        os.environ.update(env)
+        try:
+            tr = hip_lib.Tree(gpu_ctx, height, idx, v, r, SEED)
+            levels = [[a.tobytes() for a in tr.level_nodes(k)] for k in range(height + 1)]       # every node of every level, padding included
+            got.append((tr.root(), tr.node_count(), levels, [a.tobytes() for a in tr.paths(pick)]))
+            tr.close()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    for part in range(4):
+        assert got[0][part] == got[1][part], part
