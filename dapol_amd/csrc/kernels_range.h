@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include "kernels_ctx_tree.h"
+#include "ge_quad.h"
 
 namespace dapol {
 
@@ -364,8 +365,64 @@ __global__ __launch_bounds__(64, DAPOL_MSM_OCC) void k_rp_msm(RangeArgs A, Table
     }
 }
 
+// The main MSM of a call of a FEW proofs, one point per four lanes (ge_quad.h): a wavefront holds 16 accumulators -- 8 per list --
+// each walking the window steps for its terms (one term per group when the proof is split over N / 8 wavefronts): the W shared
+// doublings per window step and the two lookups per term (high-half rows) are two field products deep each instead of seven or
+// eight.  PLAIN mode only; same digit matrix, same term -> generator map, partial points in the same records as k_rp_msm's
+// (summed by k_rp_sum_splits).  A lone 64-bit, 32-party MSM: 0.25 -> see profiles/README.md.
+__global__ __launch_bounds__(64) void k_rp_msm_quad(RangeArgs A, TableView tbl, int round) {
+    const int l = threadIdx.x, ql = l & 3, grp = l >> 2, side = grp >> 3, sub = grp & 7;
+    const int nsplit = A.nsplit > 1 ? A.nsplit : 1;
+    const int split = (int)(blockIdx.x % nsplit);
+    const size_t b = blockIdx.x / nsplit;                            // (the grid is exactly B * nsplit blocks)
+    const dig_t* dig = A.dig + b * A.nwin * (size_t)A.TP + 32 * side;
+    const int NW = A.nwin, W = A.wbits;
+    const int LW = (tbl.hi_split && A.use_hi) ? tbl.hi_split : NW, halves = LW < NW ? 2 : 1;
+    const int per = (A.N + 8 * nsplit - 1) / (8 * nsplit);           // terms per group
+    fe c;
+    quad_identity(c, ql);
+    for (int w = LW - 1; w >= 0; w--) {
+        if (w != LW - 1) {
+#pragma nounroll
+            for (int d = 0; d < W; d++) quad_dbl(c, ql);
+        }
+        const dig_t* dw = dig + (size_t)w * A.TP;
+#pragma nounroll
+        for (int it2 = 0; it2 < 2 * per; it2 += (halves == 2 ? 1 : 2)) {
+            const int it = it2 >> 1, hi = it2 & 1;
+            if (hi && w + LW >= NW) continue;
+            const int q = 8 * (split + nsplit * it) + sub;
+            int d = 0, row = 0;                                      // (no term left for this group: entry 0 of a row is the identity)
+            if (q < A.N) {
+                d = (hi ? dw + (size_t)LW * A.TP : dw)[64 * (q >> 5) + (q & 31)];
+                bool isH;
+                const int j = term_generator(round, A.N, A.lgN, side, q, isH);
+                row = gen_row(tbl, A.n, j, isH);
+                if (hi) row = tbl.row_hi(row);
+            }
+            const bool neg = d < 0;
+            const int ad = neg ? -d : d;
+            // this lane's element of the entry: lane 0 multiplies by y-x (y+x for a negative digit), lane 1 by y+x (y-x), lane 3 by 2dxy
+            const int el = ql == 0 ? (neg ? 0 : 1) : ql == 1 ? (neg ? 1 : 0) : 2;
+            const int32_t* e = tbl.base + ((uint64_t)(uint32_t)row * (uint32_t)tbl.row_words() + (uint32_t)(ad * TBL_ENTRY_WORDS)) + FE_NL * el;
+            fe qel;
+            for (int i = 0; i < FE_NL; i++) qel.v[i] = e[i];
+            quad_madd(c, ql, qel, neg);
+        }
+    }
+    for (int off = 16; off >= 4; off >>= 1) {                        // the 8 groups of a list -> its first
+        fe o;
+        for (int i = 0; i < FE_NL; i++) o.v[i] = __shfl_down(c.v[i], off, 64);
+        quad_add(c, ql, o);
+    }
+    if (sub == 0) {
+        int32_t* dst = (side ? A.P1 : A.P0) + (b * nsplit + split) * 40 + FE_NL * ql;
+        for (int i = 0; i < FE_NL; i++) dst[i] = c.v[i];
+    }
+}
+
 // Small calls split every proof's term range over several wavefronts (latency): P0 / P1 [b] = sum of the partials, one wavefront
-// per (proof, side), the partials summed by a shuffle tree (nsplit a power of two <= 64).
+// per (proof, side), the partials summed by a shuffle tree (nsplit a power of two).
 __global__ __launch_bounds__(64) void k_rp_sum_splits(size_t B, int nsplit, const int32_t* PS0, const int32_t* PS1, int32_t* P0, int32_t* P1) {
     const size_t t = blockIdx.x;
     if (t >= 2 * B) return;
@@ -375,7 +432,13 @@ __global__ __launch_bounds__(64) void k_rp_sum_splits(size_t B, int nsplit, cons
     ge_p3 acc;
     if (l < nsplit) ld_p3(acc, src + (size_t)l * 40);
     else ge_identity(acc);
-    wave_reduce_point(acc, nsplit);
+    for (int s = l + 64; s < nsplit; s += 64) {                      // (k_rp_msm_quad: up to 256 partials)
+        ge_p3 p, r;
+        ld_p3(p, src + (size_t)s * 40);
+        ge_add(r, acc, p);
+        acc = r;
+    }
+    wave_reduce_point(acc, nsplit < 64 ? nsplit : 64);
     if (l == 0) st_p3(((t & 1) ? P1 : P0) + b * 40, acc);
 }
 
