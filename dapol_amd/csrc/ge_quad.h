@@ -105,5 +105,44 @@ __device__ __forceinline__ void quad_add(fe& c, int ql, const fe& d) {
     quad_finish(c, ql, E, F, G, H);
 }
 
+// The group's point as the multiplier of later additions ("cached" form, ge.h): lane 0 y-x, lane 1 y+x, lane 2 Z, lane 3 2dT.
+__device__ __forceinline__ void quad_to_cached(fe& q, const fe& c, int ql) {
+    fe X, Y, a, s, t;
+    quad_bcast_fe<0>(X, c);
+    quad_bcast_fe<1>(Y, c);
+    fe_sub(a, Y, X);
+    fe_carry(a, a);
+    fe_addc(s, Y, X);
+    fe_mul(t, c, FE_D2);
+    for (int i = 0; i < FE_NL; i++) q.v[i] = ql == 0 ? a.v[i] : ql == 1 ? s.v[i] : ql == 2 ? c.v[i] : t.v[i];
+}
+// group's point += (neg ? -q : q), q in the cached form above, one element per lane (ge_add_cached's formulas)
+__device__ __forceinline__ void quad_add_cached(fe& c, int ql, const fe& q, bool neg) {
+    fe X, Y, ypx, ymx, qs, f, g, r1, A, B, C, D, nC, E, F, G, H;
+    quad_bcast_fe<0>(X, c);
+    quad_bcast_fe<1>(Y, c);
+    fe_add(ypx, Y, X);              // loose(2)
+    fe_sub(ymx, Y, X);              // tight
+    for (int i = 0; i < FE_NL; i++) qs.v[i] = __builtin_amdgcn_update_dpp(0, q.v[i], 0xE1 /* quad_perm 1,0,2,3 */, 0xf, 0xf, false);
+    for (int i = 0; i < FE_NL; i++) {
+        f.v[i] = ql == 0 ? ymx.v[i] : ql == 1 ? ypx.v[i] : c.v[i];
+        g.v[i] = neg ? qs.v[i] : q.v[i];                             // -q swaps y-x <-> y+x (and negates 2dT, below)
+    }
+    fe_mul(r1, f, g);
+    quad_bcast_fe<0>(A, r1);
+    quad_bcast_fe<1>(B, r1);
+    quad_bcast_fe<2>(D, r1);
+    quad_bcast_fe<3>(C, r1);
+    fe_neg(nC, C);
+    fe_cmov(C, nC, neg);
+    fe_add(D, D, D);                // loose(2)
+    fe_sub(E, B, A);
+    fe_add(H, B, A);
+    fe_sub(F, D, C);                // loose(3)
+    fe_add(G, D, C);
+    fe_carry(G, G);
+    quad_finish(c, ql, E, F, G, H);
+}
+
 #endif
 }  // namespace dapol

@@ -498,6 +498,91 @@ __global__ __launch_bounds__(64) void k_rv_varpoints(VerifyArgs V) {
     if (!ok) atomicAnd(&V.vs[b].ok, 0u);
 }
 
+// The same sum for calls of a few proofs, one point per FOUR lanes (ge_quad.h): 16 points per wavefront, ceil(K / 16) wavefronts
+// per proof, the ladder's doublings and additions two field products deep; the table of a group's multiples holds one
+// cached-form element per lane ([entry][limb][lane] in LDS, 18 KB).  Partial sums per wavefront -> k_rv_sum_parts.
+__global__ __launch_bounds__(64) void k_rv_varpoints_quad(VerifyArgs V, int32_t* parts /*[B][nw][40]*/, int nw) {
+    const RangeArgs& A = V.R;
+    const size_t b = blockIdx.x / nw;
+    const int wv = (int)(blockIdx.x % nw), l = threadIdx.x, ql = l & 3, grp = l >> 2;
+    const int K = 4 + 2 * A.lgN + A.m, t = 16 * wv + grp;
+    __shared__ int32_t tab[VP_ENTRIES * FE_NL * 64];
+    const bool live = t < K;
+    uint32_t w8[8], k8[8] = {0};
+    fe c;
+    bool ok = true;
+    quad_identity(c, ql);
+    if (live) {                                                      // (the four lanes of a group decode the same point)
+        sc sm;
+        rv_own_point(w8, sm, V, b, t);
+        ge_p3 p;
+        ok = ge_decompress(p, w8);
+        sc_from_mont(k8, sm);
+        for (int i = 0; i < FE_NL; i++) c.v[i] = ql == 0 ? p.X.v[i] : ql == 1 ? p.Y.v[i] : ql == 2 ? p.Z.v[i] : p.T.v[i];
+    }
+    // table: e * P, e = 1..8, cached form
+    fe q1, q, m = c;
+    quad_to_cached(q1, c, ql);
+    for (int i = 0; i < FE_NL; i++) tab[(0 * FE_NL + i) * 64 + l] = q1.v[i];
+#pragma nounroll
+    for (int e = 1; e < VP_ENTRIES; e++) {
+        quad_add_cached(m, ql, q1, false);
+        quad_to_cached(q, m, ql);
+        for (int i = 0; i < FE_NL; i++) tab[(e * FE_NL + i) * 64 + l] = q.v[i];
+    }
+    uint32_t r8[8], carry = 0;                                       // signed nibbles in [-8, 7], as in ge_scalarmul_vartime
+    for (int w = 0; w < 8; w++) {
+        uint32_t word = 0;
+        for (int j = 0; j < 8; j++) {
+            const uint32_t nib = ((k8[w] >> (4 * j)) & 15u) + carry;
+            carry = nib >= 8u ? 1u : 0u;
+            word |= (nib & 15u) << (4 * j);
+        }
+        r8[w] = word;
+    }
+    fe acc;
+    quad_identity(acc, ql);
+#pragma nounroll
+    for (int i = 63; i >= 0; i--) {
+        if (i != 63)
+            for (int d = 0; d < 4; d++) quad_dbl(acc, ql);
+        uint32_t word = r8[0];
+        for (int j = 1; j < 8; j++) word = ((i >> 3) == j) ? r8[j] : word;
+        const int nib = (int)((word >> (4 * (i & 7))) & 15u), dg = nib >= 8 ? nib - 16 : nib, mag = dg < 0 ? -dg : dg;
+        const int e = mag ? mag - 1 : 0;
+        for (int k = 0; k < FE_NL; k++) q.v[k] = tab[(e * FE_NL + k) * 64 + l];
+        fe nx = acc;
+        quad_add_cached(nx, ql, q, dg < 0);
+        for (int k = 0; k < FE_NL; k++) acc.v[k] = mag ? nx.v[k] : acc.v[k];
+    }
+    for (int off = 32; off >= 4; off >>= 1) {                        // the 16 groups -> the first
+        fe o;
+        for (int i = 0; i < FE_NL; i++) o.v[i] = __shfl_down(acc.v[i], off, 64);
+        quad_add(acc, ql, o);
+    }
+    if (grp == 0) {
+        int32_t* dst = parts + (b * nw + wv) * 40 + FE_NL * ql;
+        for (int i = 0; i < FE_NL; i++) dst[i] = acc.v[i];
+    }
+    if (!ok) atomicAnd(&V.vs[b].ok, 0u);
+}
+// PA[b] = sum of the nw partial sums of proof b (one wavefront per proof)
+__global__ __launch_bounds__(64) void k_rv_sum_parts(size_t B, int nw, const int32_t* parts, int32_t* PA) {
+    const size_t b = blockIdx.x;
+    const int l = threadIdx.x;
+    if (b >= B) return;
+    ge_p3 acc;
+    ge_identity(acc);
+    for (int s = l; s < nw; s += 64) {
+        ge_p3 p, r;
+        ld_p3(p, parts + (b * nw + s) * 40);
+        ge_add(r, acc, p);
+        acc = r;
+    }
+    wave_reduce_point(acc, 64);
+    if (l == 0) st_p3(PA + b * 40, acc);
+}
+
 // The scalars of B_blinding and B in one proof's check:  -mu - c tau   and   w (t_x - a b) + c (delta(y, z) - t_x).
 __device__ __forceinline__ void rv_base_scalars(sc& bb, sc& bs, const VerifyState& vs, const RangeArgs& A) {
     sc one, zz, sumy, py, sumz, pz, sum2, delta, s1, s2;

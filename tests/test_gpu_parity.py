@@ -968,7 +968,7 @@ def test_every_proving_strategy_gives_the_same_bytes(gpu_ctx, n_bits, m):
                 # the small-call (latency) arrangements and the opt-in fused fold
                 {"DAPOL_SMALL_TAIL": "1"}, {"DAPOL_SMALL_TAIL": "1", "DAPOL_NO_SPLIT_MAT": "1"}, {"DAPOL_SMALL_SPLIT": "16"}, {"DAPOL_SMALL_SPLIT": "2"},
                 {"DAPOL_NO_SMALL_HI": "1"}, {"DAPOL_NO_PAIR": "1"}, {"DAPOL_FUSE_FOLD": "1"}, {"DAPOL_FUSE_FOLD": "1", "DAPOL_SMALL_TAIL": "1"},
-                {"DAPOL_FUSE_FOLD": "1", "DAPOL_NO_SPLIT": "1"}, {"DAPOL_FS_SHAPE": "0"}, {"DAPOL_FS_SHAPE": "1"}, {"DAPOL_FS_SHAPE": "2", "DAPOL_NO_SPLIT": "1"}):
+                {"DAPOL_FUSE_FOLD": "1", "DAPOL_NO_SPLIT": "1"}, {"DAPOL_FS_SHAPE": "0"}, {"DAPOL_FS_SHAPE": "1"}, {"DAPOL_FS_SHAPE": "2", "DAPOL_NO_SPLIT": "1"}, {"DAPOL_NO_QUAD": "1"}, {"DAPOL_NO_QUAD": "1", "DAPOL_SMALL_TAIL": "1"}, {"DAPOL_SMALL_SPLIT": "4"}):
         os.environ.update(env)
         try:
             got = gpu_ctx.range_prove_batch(n_bits, m, v, r, nonce_seed=SEED, stream_id=sid).tobytes()
