@@ -363,7 +363,8 @@ def mode_prove(args):
         for k in acc:
             acc[k] += getattr(stats, k)
         if rank == 0:
-            log("step %d/%d done (%.1f s since the timed region began)" % (s + 1, steps, time.perf_counter() - t0))
+            log("step %d/%d done (%.1f s since the timed region began; tree %.1f ms, proofs %.0f ms)" %
+                (s + 1, steps, time.perf_counter() - t0, stats.tree_ms, stats.prove_ms))
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
