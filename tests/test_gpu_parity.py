@@ -832,8 +832,10 @@ def test_wavefront_transcript_equals_lane_transcript(gpu_ctx, n_bits, m, b):
                     os.environ["DAPOL_VERIFY_WAVE_TRANSCRIPT"] = wave
                     if rlc:
                         os.environ["DAPOL_VERIFY_NO_RLC"] = rlc
-                    else:
+                        os.environ.pop("DAPOL_VERIFY_RLC_MIN", None)
+                    else:                       # the batched check even for a handful of proofs (by default they go one by one)
                         os.environ.pop("DAPOL_VERIFY_NO_RLC", None)
+                        os.environ["DAPOL_VERIFY_RLC_MIN"] = "2"
                     out.append(list(gpu_ctx.range_verify_batch(n_bits, m, p, vv, verify_seed=SEED)))
                     if rlc:                     # per-proof path of a small call: the whole replay by a wavefront (default) or by a lane
                         os.environ["DAPOL_VERIFY_LANE_TRANSCRIPT"] = "1"
@@ -843,6 +845,8 @@ def test_wavefront_transcript_equals_lane_transcript(gpu_ctx, n_bits, m, b):
             os.environ.pop("DAPOL_VERIFY_WAVE_TRANSCRIPT", None)
             os.environ.pop("DAPOL_VERIFY_NO_RLC", None)
             os.environ.pop("DAPOL_VERIFY_LANE_TRANSCRIPT", None)
+            os.environ.pop("DAPOL_VERIFY_RLC_MIN", None)
+        out.append(list(gpu_ctx.range_verify_batch(n_bits, m, p, vv, verify_seed=SEED)))        # the default routing
         assert all(o == out[0] for o in out), out
         return out[0]
 
@@ -919,13 +923,18 @@ def test_cross_proof_batching_gives_the_per_proof_verdicts(gpu_ctx, n_bits, m, b
 
     def both(p, vv):
         os.environ.pop("DAPOL_VERIFY_NO_RLC", None)
-        a = gpu_ctx.range_verify_batch(n_bits, m, p, vv, verify_seed=SEED)
+        d = gpu_ctx.range_verify_batch(n_bits, m, p, vv, verify_seed=SEED)                       # default routing
+        os.environ["DAPOL_VERIFY_RLC_MIN"] = "2"                                                 # batched whatever the count
+        try:
+            a = gpu_ctx.range_verify_batch(n_bits, m, p, vv, verify_seed=SEED)
+        finally:
+            os.environ.pop("DAPOL_VERIFY_RLC_MIN", None)
         os.environ["DAPOL_VERIFY_NO_RLC"] = "1"
         try:
             c = gpu_ctx.range_verify_batch(n_bits, m, p, vv, verify_seed=SEED)
         finally:
             os.environ.pop("DAPOL_VERIFY_NO_RLC", None)
-        assert list(a) == list(c)
+        assert list(a) == list(c) == list(d)
         return list(a)
 
     assert both(proofs, V) == [1] * b
@@ -968,7 +977,9 @@ def test_every_proving_strategy_gives_the_same_bytes(gpu_ctx, n_bits, m):
                 # the small-call (latency) arrangements and the opt-in fused fold
                 {"DAPOL_SMALL_TAIL": "1"}, {"DAPOL_SMALL_TAIL": "1", "DAPOL_NO_SPLIT_MAT": "1"}, {"DAPOL_SMALL_SPLIT": "16"}, {"DAPOL_SMALL_SPLIT": "2"},
                 {"DAPOL_NO_SMALL_HI": "1"}, {"DAPOL_NO_PAIR": "1"}, {"DAPOL_FUSE_FOLD": "1"}, {"DAPOL_FUSE_FOLD": "1", "DAPOL_SMALL_TAIL": "1"},
-                {"DAPOL_FUSE_FOLD": "1", "DAPOL_NO_SPLIT": "1"}, {"DAPOL_FS_SHAPE": "0"}, {"DAPOL_FS_SHAPE": "1"}, {"DAPOL_FS_SHAPE": "2", "DAPOL_NO_SPLIT": "1"}, {"DAPOL_NO_QUAD": "1"}, {"DAPOL_NO_QUAD": "1", "DAPOL_SMALL_TAIL": "1"}, {"DAPOL_SMALL_SPLIT": "4"}):
+                {"DAPOL_FUSE_FOLD": "1", "DAPOL_NO_SPLIT": "1"}, {"DAPOL_FS_SHAPE": "0"}, {"DAPOL_FS_SHAPE": "1"}, {"DAPOL_FS_SHAPE": "2", "DAPOL_NO_SPLIT": "1"}, {"DAPOL_NO_QUAD": "1"}, {"DAPOL_NO_QUAD": "1", "DAPOL_SMALL_TAIL": "1"}, {"DAPOL_SMALL_SPLIT": "4"},
+                # four lanes per point for all 37 proofs (the default keeps it to calls of up to 8)
+                {"DAPOL_QUAD_MAX_WAVES": "1000000"}, {"DAPOL_QUAD_MAX_WAVES": "1000000", "DAPOL_SMALL_TAIL": "1"}, {"DAPOL_QUAD_MAX_WAVES": "1000000", "DAPOL_SMALL_SPLIT": "8"}):
         os.environ.update(env)
         try:
             got = gpu_ctx.range_prove_batch(n_bits, m, v, r, nonce_seed=SEED, stream_id=sid).tobytes()
@@ -1003,10 +1014,16 @@ def test_cancelling_pair_is_rejected(hip_lib, pyref):
     (the round-1 library returns [1, 1] for this pair: profiles/r02_forged_pair_old_vs_new.txt).  The weights are now derived
     from the digest of every proof and commitment of the batch, so the pair is rejected under the seed it was crafted for,
     under any other seed, under the library's own OS-random seed, and inside a larger batch of honest proofs."""
+    import os
     ctx = hip_lib.Context(0, 1)
     proofs, V = _forged_cancelling_pair(pyref, SEED)
     for vs in (SEED, bytes(32), None):
-        assert ctx.range_verify_batch(8, 1, proofs, V, verify_seed=vs).tolist() == [0, 0]
+        assert ctx.range_verify_batch(8, 1, proofs, V, verify_seed=vs).tolist() == [0, 0]         # default: a pair is checked one by one
+        os.environ["DAPOL_VERIFY_RLC_MIN"] = "2"                                                  # the batched check, which the pair attacks
+        try:
+            assert ctx.range_verify_batch(8, 1, proofs, V, verify_seed=vs).tolist() == [0, 0]
+        finally:
+            os.environ.pop("DAPOL_VERIFY_RLC_MIN", None)
     rng = np.random.default_rng(11)
     b = 70
     v = rng.integers(0, 256, size=(b, 1), dtype=np.uint64)
@@ -1016,9 +1033,13 @@ def test_cancelling_pair_is_rejected(hip_lib, pyref):
     C, _ = ctx.commit_hash_batch(v.reshape(-1), r.reshape(-1, 32))
     allp = np.concatenate([proofs, honest])
     allV = np.concatenate([V, C.reshape(b, 1, 32)])
-    for vs in (SEED, None):
-        ok = ctx.range_verify_batch(8, 1, allp, allV, verify_seed=vs)
-        assert ok[:2].tolist() == [0, 0] and ok[2:].all()
+    os.environ["DAPOL_VERIFY_RLC_MIN"] = "2"
+    try:
+        for vs in (SEED, None):
+            ok = ctx.range_verify_batch(8, 1, allp, allV, verify_seed=vs)
+            assert ok[:2].tolist() == [0, 0] and ok[2:].all()
+    finally:
+        os.environ.pop("DAPOL_VERIFY_RLC_MIN", None)
 
 
 @pytest.mark.gpu

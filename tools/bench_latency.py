@@ -23,7 +23,7 @@ tree = capi.Tree(ctx, height, idx, v, r, seed)
 rC, rH, _, _ = tree.root()
 lC, lH = ctx.commit_hash_batch(v, r)
 out = {}
-for b in (1, 4, 16, 64, 256, 1024, 4096):
+for b in (1, 2, 4, 8, 16, 32, 64, 65, 128, 256, 512, 1024, 1025, 2048, 4096, 16384):
     sel = idx[:: n // b][:b]
     pos = np.searchsorted(idx, sel)
     tree.prove_entities(sel, capi.POLICY_PADDING, height, 64, seed)

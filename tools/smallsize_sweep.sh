@@ -1,0 +1,7 @@
+cd /root/repo
+for b in 2 4 8 16 32 64; do
+  for cfg in "-" "DAPOL_NO_QUAD=1" "DAPOL_SMALL_TAIL=1" "DAPOL_SMALL_TAIL=1 DAPOL_NO_QUAD=1" "DAPOL_FS_SHAPE=1" "DAPOL_SMALL_TAIL=1 DAPOL_NO_QUAD=1 DAPOL_FS_SHAPE=1"; do
+    if [ "$cfg" = "-" ]; then e=""; else e="$cfg"; fi
+    echo "$b [$cfg] $(env $e python tools/bench_midsize_one.py $b 2>&1 | tail -1)"
+  done
+done
