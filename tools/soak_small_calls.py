@@ -61,6 +61,18 @@ for case in range(cases):
                 out = ctypes.create_string_buffer(ref.ref_range_proof_size(n_bits, m))
                 assert ref.ref_range_prove(n_bits, m, p(pv), p(pr), SEED, ctypes.c_uint64(int(idx[pick[e]])), ctypes.c_uint64(0), None, 0, out) == 0
                 assert out.raw == proofs[e].tobytes(), (case, height, n_bits, n, "proof bytes differ from the oracle's")
+    if case % 4 == 0 and n >= 4:
+        # a call of several proofs takes other shapes (no quad above 8 proofs, the tail argument above 32, lane pairs above 256): its
+        # proofs must be the bytes the one-proof calls give, which the oracle has just checked for this tree
+        kb = int(rng.integers(4, min(n, 90) + 1))
+        pk = np.sort(rng.choice(n, size=kb, replace=False))
+        pol = capi.POLICY_PADDING if case % 8 == 0 else capi.POLICY_SPLITTING
+        pC, pH, together = tree.prove_entities(idx[pk], pol, height, n_bits, SEED)
+        for e in (0, kb // 2, kb - 1):
+            _, _, alone = tree.prove_entities(idx[pk[e]:pk[e] + 1] if False else idx[[pk[e]]], pol, height, n_bits, SEED)
+            assert alone[0].tobytes() == together[e].tobytes(), (case, kb, e, "a proof depends on the size of the call")
+        ok = ctx.verify_entities(height, idx[pk], lC[pk], lH[pk], pC, pH, rC, rH, pol, height, n_bits, together)
+        assert ok.all(), (case, kb, "batch of proofs not verified")
     tree.close()
     done += 1
     if done % 10 == 0:
