@@ -260,18 +260,22 @@ __global__ __launch_bounds__(64) void k_rv_transcript(VerifyArgs V) {
 __global__ __launch_bounds__(64) void k_rv_digest_level(size_t n, int level, const uint32_t* in, size_t stride, uint32_t* out) {
     size_t g = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (g >= (n + 30) / 31) return;
-    Digest d;
-    dg_init(d, DG_BLAKE3);
-    uint32_t head[8] = {(uint32_t)level, (uint32_t)n, (uint32_t)((uint64_t)n >> 32), (uint32_t)g, (uint32_t)((uint64_t)g >> 32), 0x6c6f7061u, 0, 0};
-    dg_update_words(d, head, 8);
-    for (size_t i = g * 31; i < n && i < g * 31 + 31; i++) {
-        uint32_t w[8];
-        for (int k = 0; k < 8; k++) w[k] = in[i * stride + k];
-        dg_update_words(d, w, 8);
+    // one BLAKE3 chunk = the head and up to 31 digests, absorbed a 64-byte block (two 32-byte entries) at a time
+    const uint32_t head[8] = {(uint32_t)level, (uint32_t)n, (uint32_t)((uint64_t)n >> 32), (uint32_t)g, (uint32_t)((uint64_t)g >> 32), 0x6c6f7061u, 0, 0};
+    const size_t first = g * 31, cnt = (n - first < 31) ? n - first : 31;
+    const int n_ent = 1 + (int)cnt, n_blk = (n_ent + 1) / 2;
+    uint32_t cv[8], blk[16], o[16];
+    blake3_iv(cv);
+    for (int i = 0; i < n_blk; i++) {
+        for (int h = 0; h < 2; h++) {
+            const int e = 2 * i + h;
+            for (int k = 0; k < 8; k++) blk[8 * h + k] = e == 0 ? head[k] : (e < n_ent ? in[(first + e - 1) * stride + k] : 0u);
+        }
+        const bool last = i == n_blk - 1;
+        blake3_compress(o, cv, blk, 0, (last && (n_ent & 1)) ? 32u : 64u, (i == 0 ? B3_CHUNK_START : 0u) | (last ? (B3_CHUNK_END | B3_ROOT) : 0u));
+        for (int k = 0; k < 8; k++) cv[k] = o[k];
     }
-    uint32_t o[8];
-    dg_final(d, o);
-    for (int k = 0; k < 8; k++) out[g * 8 + k] = o[k];
+    for (int k = 0; k < 8; k++) out[g * 8 + k] = cv[k];
 }
 // The verifier's random scalars (lane per proof): c combines the two equations of one proof (Scalar::random(thread_rng) in
 // the crate's verify_multiple), rho weighs the proof inside a cross-proof batch (not in the reference).  SOUNDNESS: a weight
