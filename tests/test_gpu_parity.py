@@ -837,10 +837,10 @@ def test_wavefront_transcript_equals_lane_transcript(gpu_ctx, n_bits, m, b):
                         os.environ.pop("DAPOL_VERIFY_NO_RLC", None)
                         os.environ["DAPOL_VERIFY_RLC_MIN"] = "2"
                     out.append(list(gpu_ctx.range_verify_batch(n_bits, m, p, vv, verify_seed=SEED)))
-                    if rlc:                     # per-proof path of a small call: the whole replay by a wavefront (default) or by a lane
-                        os.environ["DAPOL_VERIFY_LANE_TRANSCRIPT"] = "1"
-                        out.append(list(gpu_ctx.range_verify_batch(n_bits, m, p, vv, verify_seed=SEED)))
-                        os.environ.pop("DAPOL_VERIFY_LANE_TRANSCRIPT", None)
+                    # calls of up to a few thousand proofs replay each transcript on a wavefront (default); larger ones on a lane
+                    os.environ["DAPOL_VERIFY_LANE_TRANSCRIPT"] = "1"
+                    out.append(list(gpu_ctx.range_verify_batch(n_bits, m, p, vv, verify_seed=SEED)))
+                    os.environ.pop("DAPOL_VERIFY_LANE_TRANSCRIPT", None)
         finally:
             os.environ.pop("DAPOL_VERIFY_WAVE_TRANSCRIPT", None)
             os.environ.pop("DAPOL_VERIFY_NO_RLC", None)
