@@ -43,6 +43,8 @@ struct RangeArgs {
     dig_t* dig;                         // [B][nwin][TP] signed radix-2^wbits digits
     int nsplit;                         // MSM term-range splits per proof (0/1 = none); partial points at [b * nsplit + s]
     int use_hi;                         // small calls: the main MSM also walks only TableView::hi_split window steps (two lookups per term)
+    int fs_parts;                       // small calls: wavefronts per proof in k_rp_poly / k_rp_lr (0 / 1 = one); partial sums in fs_part
+    sc* fs_part;                        // [B][fs_parts][3]: t1, t2 (k_rp_poly), t_x (k_rp_lr) of each wavefront's share of the positions
     ProofState* st;                     // [B]
     int32_t* PA; int32_t* P0; int32_t* P1;   // [B][40] partial points
     int tail_n;                         // T = length of the tail argument (32 / 64 / 128): 2T generators are materialised
@@ -548,6 +550,20 @@ template <class S>
 __device__ __forceinline__ void append_scalar(S& s, const char* label, int n, const uint32_t* canon8) {
     merlin_append_words(s, label, n, canon8, 8);
 }
+// t1 / t2 / t_x (which = 0 / 1 / 2) of proof b: the value k_rp_poly / k_rp_lr left in the state, or the sum of the wavefronts' shares
+__device__ __forceinline__ void fs_scalar(sc& r, const RangeArgs& A, size_t b, int which) {
+    const ProofState& ps = A.st[b];
+    if (A.fs_parts > 1) {
+        sc_zero(r);
+        for (int w = 0; w < A.fs_parts; w++) {
+            sc t;
+            ld_sc(t, A.fs_part + (b * A.fs_parts + w) * 3 + which);
+            sc_add(r, r, t);
+        }
+    } else {
+        r = which == 0 ? ps.t1 : which == 1 ? ps.t2 : ps.t_x;
+    }
+}
 // The lane-per-proof Fiat-Shamir kernels come in three shapes (template MODE):
 //   0  one lane per proof (throughput: tens of thousands of proofs per launch);
 //   1  PAIR: the two point computations of a proof (A and S; T_1, T_2; L_k, R_k) on two neighbouring lanes, the second encoding
@@ -664,12 +680,16 @@ __global__ __launch_bounds__(64) void k_rp_finish1(RangeArgs A, TableView tbl) {
 // ------------------------------------------------- K3: l0, l1, r0, r1 and t1, t2 (wave per proof)
 // Party::apply_challenge_with_rng restated over the concatenated vectors: position i = (party j, bit ii).
 __global__ __launch_bounds__(64) void k_rp_poly(RangeArgs A) {
-    size_t b = blockIdx.x;
+    // small calls: fs_parts wavefronts per proof, wavefront w taking the positions [i_lo, i_hi) (whole multiples of 64)
+    const int parts = A.fs_parts > 1 ? A.fs_parts : 1, part = (int)(blockIdx.x % parts);
+    size_t b = blockIdx.x / parts;
     int l = threadIdx.x;
+    const int iters = (A.N + 63) / 64, per = (iters + parts - 1) / parts;
+    const int i_lo = 64 * per * part, i_hi = (64 * per * (part + 1) < A.N) ? 64 * per * (part + 1) : A.N;
     const ProofState& ps = A.st[b];
     sc y = ps.y, z = ps.z, one, yi, y64, t1, t2;
     sc_one_mont(one);
-    sc_pow_mont(yi, y, (uint32_t)l);
+    sc_pow_mont(yi, y, (uint32_t)(i_lo + l));
     sc_pow_mont(y64, y, 64u);
     sc_zero(t1);
     sc_zero(t2);
@@ -678,11 +698,11 @@ __global__ __launch_bounds__(64) void k_rp_poly(RangeArgs A) {
     // A lane's positions i = l + 64 k share the bit index ii = l mod n (n divides 64) and step the party by 64 / n: z^(2+j) 2^ii
     // is a recurrence, not a power per position (a power is ~10 products; this loop was 0.28 ms of a lone proof's 6.4).
     sc zz, zstep, two;
-    sc_pow_mont(zz, z, (uint32_t)(2 + l / A.n));
+    sc_pow_mont(zz, z, (uint32_t)(2 + (i_lo + l) / A.n));
     sc_pow_mont(zstep, z, (uint32_t)(64 / A.n));
     sc_from_u64_mont(two, 1ull << (l % A.n));
     sc_montmul(zz, zz, two);                                       // z^(2+j) 2^ii for this lane's first position
-    for (int i = l; i < A.N; i += 64) {
+    for (int i = i_lo + l; i < i_hi; i += 64) {
         int j = i / A.n, ii = i - j * A.n;
         int bit = (int)((A.vals[b * A.m + j] >> ii) & 1ull);
         sc l0, l1, sR, r0, r1, t;
@@ -706,7 +726,10 @@ __global__ __launch_bounds__(64) void k_rp_poly(RangeArgs A) {
     }
     wave_reduce_sc(t1);
     wave_reduce_sc(t2);
-    if (l == 0) { A.st[b].t1 = t1; A.st[b].t2 = t2; }
+    if (l == 0) {
+        if (parts > 1) { st_sc(A.fs_part + (b * parts + part) * 3 + 0, t1); st_sc(A.fs_part + (b * parts + part) * 3 + 1, t2); }
+        else { A.st[b].t1 = t1; A.st[b].t2 = t2; }
+    }
 }
 
 // ------------------------------------------------------------- F2: T1, T2 and the challenge x (lane/proof)
@@ -724,7 +747,9 @@ __global__ __launch_bounds__(64) void k_rp_finish2(RangeArgs A, TableView tbl) {
         ge_p3 p;
         if (MODE == 2) {
             ge_p3 q;
-            sc_from_mont(c, h ? ps.t2 : ps.t1);
+            sc tq;
+            fs_scalar(tq, A, b, h);
+            sc_from_mont(c, tq);
             tbl_fixed_mul_wave(p, tbl, tbl.row_B(0), c, F.l & 31);
             sc_from_mont(c, bl);
             tbl_fixed_mul_wave(q, tbl, tbl.row_Bb(0), c, F.l & 31);
@@ -734,7 +759,9 @@ __global__ __launch_bounds__(64) void k_rp_finish2(RangeArgs A, TableView tbl) {
             p = r;
         } else {
             ge_identity(p);
-            sc_from_mont(c, h ? ps.t2 : ps.t1);
+            sc tq;
+            fs_scalar(tq, A, b, h);
+            sc_from_mont(c, tq);
             tbl_fixed_mul_add(p, tbl, tbl.row_B(0), c);
             sc_from_mont(c, bl);
             tbl_fixed_mul_add(p, tbl, tbl.row_Bb(0), c);
@@ -763,15 +790,18 @@ __global__ __launch_bounds__(64) void k_rp_finish2(RangeArgs A, TableView tbl) {
 
 // ------------------------------------- K4: l = l0 + l1 x, r = r0 + r1 x, t_x = <l, r>, s-vector init (wave/proof)
 __global__ __launch_bounds__(64) void k_rp_lr(RangeArgs A) {
-    size_t b = blockIdx.x;
+    const int parts = A.fs_parts > 1 ? A.fs_parts : 1, part = (int)(blockIdx.x % parts);      // (as k_rp_poly)
+    size_t b = blockIdx.x / parts;
     int l = threadIdx.x;
+    const int iters = (A.N + 63) / 64, per = (iters + parts - 1) / parts;
+    const int i_lo = 64 * per * part, i_hi = (64 * per * (part + 1) < A.N) ? 64 * per * (part + 1) : A.N;
     const ProofState& ps = A.st[b];
     sc x = ps.x, z = ps.z, yinv = ps.y_inv, one, yi, y64, tx;
     sc_one_mont(one);
-    sc_pow_mont(yi, yinv, (uint32_t)l);
+    sc_pow_mont(yi, yinv, (uint32_t)(i_lo + l));
     sc_pow_mont(y64, yinv, 64u);
     sc_zero(tx);
-    for (int i = l; i < A.N; i += 64) {
+    for (int i = i_lo + l; i < i_hi; i += 64) {
         int j = i / A.n, ii = i - j * A.n;
         int bit = (int)((A.vals[b * A.m + j] >> ii) & 1ull);
         sc l0, l1, r0, r1, lv, rv, t;
@@ -797,7 +827,10 @@ __global__ __launch_bounds__(64) void k_rp_lr(RangeArgs A) {
         sc_montmul(yi, yi, y64);
     }
     wave_reduce_sc(tx);
-    if (l == 0) A.st[b].t_x = tx;
+    if (l == 0) {
+        if (parts > 1) st_sc(A.fs_part + (b * parts + part) * 3 + 2, tx);
+        else A.st[b].t_x = tx;
+    }
 }
 
 // ------------------------------- F3: t_x, tau_x, mu; challenge w; inner-product domain separator (lane/proof)
@@ -826,7 +859,9 @@ __global__ __launch_bounds__(64) void k_rp_finish3(RangeArgs A) {
     sc_montmul(t, ps.s_bl, x);
     sc_add(mu, ps.a_bl, t);
     uint32_t c_tx[8], c_tau[8], c_mu[8];
-    sc_from_mont(c_tx, ps.t_x);
+    sc t_x;
+    fs_scalar(t_x, A, b, 2);
+    sc_from_mont(c_tx, t_x);
     sc_from_mont(c_tau, tau);
     sc_from_mont(c_mu, mu);
     uint32_t* out = A.out + b * A.out_words;

@@ -979,6 +979,7 @@ def test_every_proving_strategy_gives_the_same_bytes(gpu_ctx, n_bits, m):
                 {"DAPOL_NO_SMALL_HI": "1"}, {"DAPOL_NO_PAIR": "1"}, {"DAPOL_FUSE_FOLD": "1"}, {"DAPOL_FUSE_FOLD": "1", "DAPOL_SMALL_TAIL": "1"},
                 {"DAPOL_FUSE_FOLD": "1", "DAPOL_NO_SPLIT": "1"}, {"DAPOL_FS_SHAPE": "0"}, {"DAPOL_FS_SHAPE": "1"}, {"DAPOL_FS_SHAPE": "2", "DAPOL_NO_SPLIT": "1"}, {"DAPOL_NO_QUAD": "1"}, {"DAPOL_NO_QUAD": "1", "DAPOL_SMALL_TAIL": "1"}, {"DAPOL_SMALL_SPLIT": "4"},
                 # four lanes per point for all 37 proofs (the default keeps it to calls of up to 8)
+                {"DAPOL_NO_FS_PARTS": "1"}, {"DAPOL_NO_SIDE_A": "1"},
                 {"DAPOL_QUAD_MAX_WAVES": "1000000"}, {"DAPOL_QUAD_MAX_WAVES": "1000000", "DAPOL_SMALL_TAIL": "1"}, {"DAPOL_QUAD_MAX_WAVES": "1000000", "DAPOL_SMALL_SPLIT": "8"}):
         os.environ.update(env)
         try:
