@@ -15,6 +15,7 @@
 #include "../../include/dapol_hip.h"
 #include "kernels_ctx_tree.h"
 #include "kernels_range.h"
+#include "kernels_range_gs.h"
 #include "kernels_verify.h"
 #include "kernels_leaf.h"
 

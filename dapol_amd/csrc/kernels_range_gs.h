@@ -1,0 +1,159 @@
+// Generator-stationary form of the prover's fixed-base MSM (large calls).  Same group elements as k_rp_msm, other order:
+//
+//   k_rp_msm (proof-stationary): a lane owns a slice of ONE proof's list and walks window-outer / term-inner; every lookup of
+//   every lane is a random 128-byte line somewhere in the 35 GB of tables -- an HBM gather.
+//
+//   here: a lane owns ONE accumulator -- (proof p, window w) of the list being swept -- and the whole chip sweeps the list's
+//   generators in the same order, a tile of rows per launch.  All lanes of all wavefronts of a launch read the SAME few rows
+//   (2^(W-1)+1 lines of 128 B each: 8.4 MB at 17 bits), cb * nwin lookups per row, so the tile sits in the Infinity Cache
+//   (256 MB) and a row comes from HBM once per MSM instead of once per lookup.  No doubling in the loop: the nwin window sums
+//   of a list are combined afterwards (k_rp_gs_combine: W (nwin-1) doublings + nwin-1 additions per list, 0.8 % of the
+//   additions of a 2,048-term list).  The accumulators are carried between the tiles in HBM (coalesced 36-word SoA records:
+//   288 B of traffic per lane and tile against 128 B per lookup).
+//   Measured before it was built into the library (tools/ubench_msm_order.hip, profiles/r03_msm_order_ubench.txt): 2,118 ns
+//   of SIMD time per wavefront-addition in 32-row tiles against 2,445 for the proof-stationary order (-13 %) -- the chip is
+//   held at its power cap either way, and the sweep spends less of the budget on HBM (shader clock 2.1 GHz against 1.72).
+//
+// Digit layout of this form (written by the *_gs producers below): sweep position sp = side * N + q (q = term of the list,
+// term_generator's q) -- four consecutive positions of one accumulator lane are one 16-byte element:
+//     dig4[(sp >> 2) * L + lane][sp & 3],   L = cb * nwin,   lane = w * cb + p
+// so a wavefront's digit load is 1 KB contiguous and so is every store of a producer (lanes run over the proofs).
+#pragma once
+#include "kernels_range.h"
+
+namespace dapol {
+
+// W-bit field of a 256-bit integer (eight words) at bit offset o
+__device__ __forceinline__ uint32_t sc_bits(const uint32_t* x, int o, int W) {
+    const int wd = o >> 5, sh = o & 31;
+    const uint32_t lo = wd < 8 ? x[wd] >> sh : 0u;
+    const uint32_t hi = (sh && wd + 1 < 8) ? (x[wd + 1] << (32 - sh)) : 0u;
+    return (lo | hi) & ((1u << W) - 1);
+}
+// Signed radix-2^W digits of FOUR canonical scalars (the terms at sweep positions 4 * sp4 .. 4 * sp4 + 3 of proof p), one
+// 16-byte store per window.  Same recoding as sc_recode_w.
+__device__ __forceinline__ void write_digits_gs4(const RangeArgs& A, size_t p, size_t sp4, const uint32_t (*c)[8]) {
+    const size_t L = A.B * (size_t)A.nwin;
+    dapol_v4i* out = reinterpret_cast<dapol_v4i*>(A.dig) + sp4 * L + p;
+    const int W = A.wbits, NW = A.nwin, half = 1 << (W - 1);
+    int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    for (int w = 0; w < NW; w++) {
+        const int o = w * W;
+        const bool last = w == NW - 1;
+        int b0 = (int)sc_bits(c[0], o, W) + c0, b1 = (int)sc_bits(c[1], o, W) + c1, b2 = (int)sc_bits(c[2], o, W) + c2, b3 = (int)sc_bits(c[3], o, W) + c3;
+        c0 = (b0 >= half && !last) ? 1 : 0; c1 = (b1 >= half && !last) ? 1 : 0; c2 = (b2 >= half && !last) ? 1 : 0; c3 = (b3 >= half && !last) ? 1 : 0;
+        dapol_v4i d = {b0 - (c0 << W), b1 - (c1 << W), b2 - (c2 << W), b3 - (c3 << W)};
+        out[(size_t)w * A.B] = d;
+    }
+}
+
+// Thread -> (proof p, sweep quad): p runs fastest so that the stores above are contiguous over a wavefront.
+// grid = ceil(cb * (2N / 4) / 64) blocks of 64.
+__device__ __forceinline__ bool gs_thread(const RangeArgs& A, size_t& p, size_t& sp4) {
+    const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
+    sp4 = t / A.B;
+    p = t - sp4 * A.B;
+    return sp4 < (size_t)(2 * A.N) / 4;
+}
+
+// K0 (generator-stationary layout): nonces s_L, s_R + the S commitment's digits
+__global__ __launch_bounds__(64) void k_rp_nonces_gs(RangeArgs A) {
+    size_t p, sp4;
+    if (!gs_thread(A, p, sp4)) return;
+    const int sp = (int)(4 * sp4), side = sp >= A.N ? 1 : 0, q0 = sp - side * A.N;
+    uint32_t c[4][8];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int q = q0 + k, j = q / A.n, ii = q - j * A.n;
+        const uint32_t slot = (uint32_t)(j * (2 * A.n + 2) + 2 + ii + (side ? A.n : 0));
+        sc s;
+        tape_scalar(s, A, p, slot);
+        st_sc((side ? A.s2 : A.s1) + p * A.N + q, s);
+        sc_from_mont(c[k], s);
+    }
+    write_digits_gs4(A, p, sp4, c);
+}
+
+// K5 (generator-stationary layout): round-k MSM scalars -> digits
+__global__ __launch_bounds__(64) void k_rp_round_prep_gs(RangeArgs A, int round) {
+    size_t p, sp4;
+    if (!gs_thread(A, p, sp4)) return;
+    const int sp = (int)(4 * sp4), side = sp >= A.N ? 1 : 0, q0 = sp - side * A.N;
+    const int lgh = A.lgN - 1 - round, half = 1 << lgh;
+    uint32_t c[4][8];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        bool isH;
+        const int j = term_generator(round, A.N, A.lgN, side, q0 + k, isH);
+        const int off = j & (half - 1);
+        const bool upper = (j >> lgh) & 1;
+        const int vi = upper ? off : off + half;       // G_R pairs with a_L, G_L with a_R; H'_L with b_R, H'_R with b_L
+        sc v, s, pr;
+        ld_sc(v, (isH ? A.b : A.a) + p * A.N + vi);
+        ld_sc(s, (isH ? A.s2 : A.s1) + p * A.N + j);   // plain form (k_rp_lr)
+        sc_montmul(pr, v, s);                          // Montgomery x plain = the canonical product
+        for (int i = 0; i < 8; i++) c[k][i] = pr.v[i];
+    }
+    write_digits_gs4(A, p, sp4, c);
+}
+
+// The sweep: rows q0 .. q0 + nq - 1 (terms of list `side`, nq a multiple of 4) added into every accumulator lane.
+// first: the accumulators start at the identity; else they are loaded from acc (SoA: word k of lane l at acc[k * L + l]).
+__global__ __launch_bounds__(64, 4) void k_rp_msm_gs(RangeArgs A, TableView tbl, int round, int side, int q0, int nq, int first, int32_t* __restrict__ accs) {
+    const size_t L = A.B * (size_t)A.nwin;
+    const size_t lane = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (lane >= L) return;
+    ge_p3 acc;
+    int32_t* ap = accs + lane;
+    if (first) ge_identity(acc);
+    else {
+#pragma unroll
+        for (int i = 0; i < FE_NL; i++) {
+            acc.X.v[i] = ap[(size_t)i * L]; acc.Y.v[i] = ap[(size_t)(FE_NL + i) * L];
+            acc.Z.v[i] = ap[(size_t)(2 * FE_NL + i) * L]; acc.T.v[i] = ap[(size_t)(3 * FE_NL + i) * L];
+        }
+    }
+    const dapol_v4i* dg = reinterpret_cast<const dapol_v4i*>(A.dig) + ((size_t)(side * A.N + q0) >> 2) * L + lane;
+    dapol_v4i d4 = {0, 0, 0, 0};
+#pragma nounroll
+    for (int i = 0; i < nq; i++) {
+        if ((i & 3) == 0) d4 = dg[(size_t)(i >> 2) * L];
+        const int d = d4.x;
+        d4.x = d4.y; d4.y = d4.z; d4.z = d4.w;
+        bool isH;
+        const int j = term_generator(round, A.N, A.lgN, side, q0 + i, isH);      // (uniform over the launch)
+        tbl_madd(acc, tbl, gen_row(tbl, A.n, j, isH), d);
+    }
+#pragma unroll
+    for (int i = 0; i < FE_NL; i++) {
+        ap[(size_t)i * L] = acc.X.v[i]; ap[(size_t)(FE_NL + i) * L] = acc.Y.v[i];
+        ap[(size_t)(2 * FE_NL + i) * L] = acc.Z.v[i]; ap[(size_t)(3 * FE_NL + i) * L] = acc.T.v[i];
+    }
+}
+
+// P_side[p] = sum_w 2^(W w) * acc[w * cb + p]: Horner from the top window, one lane per proof.
+__global__ __launch_bounds__(64) void k_rp_gs_combine(RangeArgs A, int side, const int32_t* __restrict__ accs) {
+    const size_t L = A.B * (size_t)A.nwin;
+    const size_t p = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (p >= A.B) return;
+    auto load = [&](ge_p3& r, int w) {
+        const int32_t* ap = accs + (size_t)w * A.B + p;
+        for (int i = 0; i < FE_NL; i++) {
+            r.X.v[i] = ap[(size_t)i * L]; r.Y.v[i] = ap[(size_t)(FE_NL + i) * L];
+            r.Z.v[i] = ap[(size_t)(2 * FE_NL + i) * L]; r.T.v[i] = ap[(size_t)(3 * FE_NL + i) * L];
+        }
+    };
+    ge_p3 acc, t, r;
+    load(acc, A.nwin - 1);
+#pragma nounroll
+    for (int w = A.nwin - 2; w >= 0; w--) {
+#pragma nounroll
+        for (int d = 0; d < A.wbits; d++) ge_dbl(acc, acc, d == A.wbits - 1);
+        load(t, w);
+        ge_add(r, acc, t);
+        acc = r;
+    }
+    st_p3((side ? A.P1 : A.P0) + p * 40, acc);
+}
+
+}  // namespace dapol
