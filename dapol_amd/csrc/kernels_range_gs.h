@@ -156,4 +156,97 @@ __global__ __launch_bounds__(64) void k_rp_gs_combine(RangeArgs A, int side, con
     st_p3((side ? A.P1 : A.P0) + p * 40, acc);
 }
 
+// ------------------------------------------------------------------------------------------------ materialisation
+// The hybrid argument's 2T folded generators (k_rp_msm<MSM_MATERIALIZE>: G'_i = sum over q = i (mod T) of s_q G_q, H'_i alike)
+// in the same order of work: the terms of one folded generator ("class" i of a side) are one tile of N / T rows -- plus the tile
+// of their high-half rows when the context has them (TableView::hi_split: window w and window w + hi_split in the same lane) --
+// and a lane owns (proof, window) of that class.  A class's LW window sums are combined by k_rp_mat_gs_horner, MAT_GROUP classes
+// per launch so that the Horner chains (W (LW - 1) doublings, the same work the proof-stationary kernel does) fill the chip.
+// Digits: sweep position sp = side * N + i * (N / T) + k  <->  term q = i + k T, same dig4 layout as above.
+enum { MAT_GROUP = 16 };
+
+// grid = ceil(cb * (2N / 4) / 64) blocks of 64
+__global__ __launch_bounds__(64) void k_rp_mat_prep_gs(RangeArgs A) {
+    size_t p, sp4;
+    if (!gs_thread(A, p, sp4)) return;
+    const int sp = (int)(4 * sp4), side = sp >= A.N ? 1 : 0, rem = sp - side * A.N;
+    const int per = A.N / A.tail_n, cls = rem / per, k0 = rem - cls * per;
+    uint32_t c[4][8];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        sc s;
+        ld_sc(s, (side ? A.s2 : A.s1) + p * A.N + cls + (k0 + k) * A.tail_n);     // plain form already
+        for (int i = 0; i < 8; i++) c[k][i] = s.v[i];
+    }
+    write_digits_gs4(A, p, sp4, c);
+}
+
+// One class, one half (0: the generators' own rows, digits of window w; 1: their high-half rows, digits of window w + LW).
+// accs: this class's slot, SoA over LM = cb * LW lanes (lane = w * cb + p).
+__global__ __launch_bounds__(64, 4) void k_rp_mat_gs(RangeArgs A, TableView tbl, int side, int cls, int hi, int LW, int32_t* __restrict__ accs) {
+    const size_t LM = A.B * (size_t)LW, L = A.B * (size_t)A.nwin;
+    const size_t lane = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (lane >= LM) return;
+    const int w = (int)(lane / A.B);
+    const size_t p = lane - (size_t)w * A.B;
+    const int wd = w + (hi ? LW : 0);
+    if (wd >= A.nwin) return;                          // (no such window: the accumulator stays as the first half left it)
+    ge_p3 acc;
+    int32_t* ap = accs + lane;
+    if (!hi) ge_identity(acc);
+    else {
+#pragma unroll
+        for (int i = 0; i < FE_NL; i++) {
+            acc.X.v[i] = ap[(size_t)i * LM]; acc.Y.v[i] = ap[(size_t)(FE_NL + i) * LM];
+            acc.Z.v[i] = ap[(size_t)(2 * FE_NL + i) * LM]; acc.T.v[i] = ap[(size_t)(3 * FE_NL + i) * LM];
+        }
+    }
+    const int per = A.N / A.tail_n;
+    const dapol_v4i* dg = reinterpret_cast<const dapol_v4i*>(A.dig) + ((size_t)(side * A.N + cls * per) >> 2) * L + (size_t)wd * A.B + p;
+    dapol_v4i d4 = {0, 0, 0, 0};
+#pragma nounroll
+    for (int k = 0; k < per; k++) {
+        if ((k & 3) == 0) d4 = dg[(size_t)(k >> 2) * L];
+        const int d = d4.x;
+        d4.x = d4.y; d4.y = d4.z; d4.z = d4.w;
+        const int row = gen_row(tbl, A.n, cls + k * A.tail_n, side != 0);
+        tbl_madd(acc, tbl, hi ? tbl.row_hi(row) : row, d);
+    }
+#pragma unroll
+    for (int i = 0; i < FE_NL; i++) {
+        ap[(size_t)i * LM] = acc.X.v[i]; ap[(size_t)(FE_NL + i) * LM] = acc.Y.v[i];
+        ap[(size_t)(2 * FE_NL + i) * LM] = acc.Z.v[i]; ap[(size_t)(3 * FE_NL + i) * LM] = acc.T.v[i];
+    }
+}
+
+// Folded generator of (proof p, class cls0 + c) = sum_w 2^(W w) * (window sum w): Horner, one lane per (class, proof); the point
+// goes to the head of its row of the proof's tail table (k_rp_tail_table builds the row), as the proof-stationary kernel leaves it.
+__global__ __launch_bounds__(64) void k_rp_mat_gs_horner(RangeArgs A, int side, int cls0, int ncls, int LW, const int32_t* __restrict__ accs) {
+    const size_t LM = A.B * (size_t)LW;
+    const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (t >= (size_t)ncls * A.B) return;
+    const int c = (int)(t / A.B);
+    const size_t p = t - (size_t)c * A.B;
+    const int32_t* slot = accs + (size_t)c * 4 * FE_NL * LM;
+    auto load = [&](ge_p3& r, int w) {
+        const int32_t* ap = slot + (size_t)w * A.B + p;
+        for (int i = 0; i < FE_NL; i++) {
+            r.X.v[i] = ap[(size_t)i * LM]; r.Y.v[i] = ap[(size_t)(FE_NL + i) * LM];
+            r.Z.v[i] = ap[(size_t)(2 * FE_NL + i) * LM]; r.T.v[i] = ap[(size_t)(3 * FE_NL + i) * LM];
+        }
+    };
+    ge_p3 acc, q, r;
+    load(acc, LW - 1);
+#pragma nounroll
+    for (int w = LW - 2; w >= 0; w--) {
+#pragma nounroll
+        for (int d = 0; d < A.wbits; d++) ge_dbl(acc, acc, d == A.wbits - 1);
+        load(q, w);
+        ge_add(r, acc, q);
+        acc = r;
+    }
+    const int T = A.tail_n;
+    st_p3(A.tailT + (p * (size_t)(2 * T) + (size_t)(side * T + cls0 + c)) * TAIL_ROW_WORDS, acc);
+}
+
 }  // namespace dapol
