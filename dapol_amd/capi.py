@@ -22,7 +22,8 @@ class DapolError(RuntimeError):
 class WorkloadStats(ctypes.Structure):
     _fields_ = [("tree_ms", ctypes.c_double), ("prove_ms", ctypes.c_double), ("msm_ms", ctypes.c_double),
                 ("msm_launches", ctypes.c_uint64), ("proofs", ctypes.c_uint64), ("proof_bytes", ctypes.c_uint64),
-                ("checksum", ctypes.c_uint64), ("root_C", ctypes.c_uint8 * 32), ("root_H", ctypes.c_uint8 * 32)]
+                ("checksum", ctypes.c_uint64), ("root_C", ctypes.c_uint8 * 32), ("root_H", ctypes.c_uint8 * 32),
+                ("mat_ms", ctypes.c_double), ("mat_launches", ctypes.c_uint64), ("msm_kernels", ctypes.c_uint64), ("mat_kernels", ctypes.c_uint64)]
 
 
 _lib = None
@@ -57,6 +58,10 @@ _SIG = {
     "dapol_range_proofs_deserialize": (ctypes.c_int32, [ctypes.c_int32, ctypes.c_int32, _P, ctypes.c_size_t, _P, ctypes.c_size_t, _P, _P, _P, _P]),
     "dapol_verify_entities": (ctypes.c_int32, [_P, ctypes.c_int32, ctypes.c_size_t, _P, _P, _P, _P, _P, _P, _P, ctypes.c_int32, ctypes.c_int32,
                                                ctypes.c_int32, _P, _P, _P]),
+    "dapol_verify_entities_checked": (ctypes.c_int32, [_P, ctypes.c_int32, ctypes.c_size_t, _P, _P, _P, ctypes.c_size_t, _P, _P, _P, _P, ctypes.c_int32,
+                                                       ctypes.c_int32, ctypes.c_int32, _P, ctypes.c_size_t, _P, _P]),
+    "dapol_verify_batch_checked": (ctypes.c_int32, [_P, ctypes.c_int32, ctypes.c_size_t, _P, _P, _P, ctypes.c_size_t, _P, _P, _P, _P, ctypes.c_int32,
+                                                    ctypes.c_int32, ctypes.c_int32, _P, ctypes.c_size_t, _P, _P]),
     "dapol_batch_siblings": (ctypes.c_int32, [ctypes.c_int32, ctypes.c_size_t, _P, _P, _P, _P]),
     "dapol_prove_batch": (ctypes.c_int32, [_P, _P, ctypes.c_size_t, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P, _P, _P, _P]),
     "dapol_verify_batch": (ctypes.c_int32, [_P, ctypes.c_int32, ctypes.c_size_t, _P, _P, _P, ctypes.c_size_t, _P, _P, _P, _P, ctypes.c_int32,
@@ -69,6 +74,8 @@ _SIG = {
     "dapol_workload_build": (ctypes.c_int32, [_P, _P, _P, _P, _P, _P, ctypes.POINTER(WorkloadStats)]),
     "dapol_workload_prove": (ctypes.c_int32, [_P, _P, ctypes.c_int32, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int32, _P, _P, _P, _P,
                                               ctypes.POINTER(WorkloadStats)]),
+    "dapol_workload_prove_policy": (ctypes.c_int32, [_P, _P, ctypes.c_int32, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                                     _P, _P, _P, _P, ctypes.POINTER(WorkloadStats)]),
     "dapol_workload_paths": (ctypes.c_int32, [_P, ctypes.c_size_t, _P, ctypes.c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dapol_workload_destroy": (ctypes.c_int32, [_P]),
     "dapol_workload_run": (ctypes.c_int32, [_P, _P, _P, ctypes.c_int32, ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(WorkloadStats)]),
@@ -80,7 +87,10 @@ _SIG = {
     "dapol_workload_tree": (ctypes.c_int32, [_P, ctypes.POINTER(_P)]),
     "dapol_comm_unique_id": (ctypes.c_int32, [_P]),
     "dapol_comm_create": (ctypes.c_int32, [_P, _P, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(_P)]),
+    "dapol_comm_create_timeout": (ctypes.c_int32, [_P, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.POINTER(_P)]),
     "dapol_comm_destroy": (ctypes.c_int32, [_P]),
+    "dapol_comm_abort": (ctypes.c_int32, [_P]),
+    "dapol_comm_count": (ctypes.c_int32, [_P, _P]),
     "dapol_shard_exchange": (ctypes.c_int32, [_P, _P, _P, ctypes.c_uint64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dapol_shard_top_levels": (ctypes.c_int32, [_P, ctypes.c_int32, ctypes.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dapol_comm_allreduce_u64": (ctypes.c_int32, [_P, ctypes.c_int32, _P, ctypes.c_size_t]),
@@ -315,13 +325,17 @@ class Context:
         leaf_idx = _u64(leaf_idx)
         b = leaf_idx.shape[0]
         lC, lH = _u8(leaf_C, b, 32), _u8(leaf_H, b, 32)
-        pC, pH = _u8(path_C).reshape(b, height, 32), _u8(path_H).reshape(b, height, 32)
-        rp = _u8(range_proofs).reshape(b, -1)
+        # the length-checked entry point: arrays whose sizes do not fit (height, policy, aggregation factor) -- proofs decoded from
+        # hostile bytes -- come back as invalid instead of being over-read
+        pC, pH = _u8(path_C).reshape(-1, 32), _u8(path_H).reshape(-1, 32)
+        rp = _u8(range_proofs).reshape(-1)
         rC, rH = _u8(np.frombuffer(root_C, np.uint8)), _u8(np.frombuffer(root_H, np.uint8))
         seed = _u8(np.frombuffer(verify_seed, np.uint8)) if verify_seed is not None else None   # None: the library draws one from the OS
         ok = np.zeros(b, np.uint8)
-        _chk(lib().dapol_verify_entities(self.h, height, b, _ptr(leaf_idx), _ptr(lC), _ptr(lH), _ptr(pC), _ptr(pH), _ptr(rC), _ptr(rH), policy,
-                                         aggregation_factor, n_bits, _ptr(rp), _ptr(seed), _ptr(ok)))
+        if pH.shape[0] != pC.shape[0]:
+            return ok
+        _chk(lib().dapol_verify_entities_checked(self.h, height, b, _ptr(leaf_idx), _ptr(lC), _ptr(lH), pC.shape[0], _ptr(pC), _ptr(pH), _ptr(rC), _ptr(rH),
+                                                 policy, aggregation_factor, n_bits, _ptr(rp), rp.shape[0], _ptr(seed), _ptr(ok)))
         return ok
 
     def verify_batch(self, height, leaf_idx, leaf_C, leaf_H, sib_C, sib_H, root_C, root_H, policy, aggregation_factor, n_bits, range_proofs,
@@ -335,8 +349,10 @@ class Context:
         rC, rH = _u8(np.frombuffer(root_C, np.uint8)), _u8(np.frombuffer(root_H, np.uint8))
         seed = _u8(np.frombuffer(verify_seed, np.uint8)) if verify_seed is not None else None   # None: the library draws one from the OS
         ok = np.zeros(1, np.uint8)
-        _chk(lib().dapol_verify_batch(self.h, height, k, _ptr(leaf_idx), _ptr(lC), _ptr(lH), sC.shape[0], _ptr(sC), _ptr(sH), _ptr(rC), _ptr(rH),
-                                      policy, aggregation_factor, n_bits, _ptr(rp), _ptr(seed), _ptr(ok)))
+        if sH.shape[0] != sC.shape[0]:
+            return False
+        _chk(lib().dapol_verify_batch_checked(self.h, height, k, _ptr(leaf_idx), _ptr(lC), _ptr(lH), sC.shape[0], _ptr(sC), _ptr(sH), _ptr(rC), _ptr(rH),
+                                              policy, aggregation_factor, n_bits, _ptr(rp), rp.shape[0], _ptr(seed), _ptr(ok)))
         return bool(ok[0])
 
     def range_verify_batch(self, n_bits, m, proofs, V32, verify_seed=None):
@@ -384,17 +400,29 @@ def _top_result(o, bits):
 class Comm:
     """dapol_comm: the RCCL communicator of the sharded path (one rank per GPU), created inside the library."""
 
-    def __init__(self, ctx, unique_id, rank, world):
+    def __init__(self, ctx, unique_id, rank, world, timeout_s=0.0):
+        """timeout_s > 0: the communicator is aborted (ncclCommAbort) and DapolError raised if it has not come up by then."""
         self.ctx, self.rank, self.world = ctx, rank, world
         self.bits = world.bit_length() - 1
         uid = _u8(np.frombuffer(unique_id, np.uint8))
         self.h = _P()
-        _chk(lib().dapol_comm_create(ctx.h, _ptr(uid), rank, world, ctypes.byref(self.h)))
+        _chk(lib().dapol_comm_create_timeout(ctx.h, _ptr(uid), rank, world, int(timeout_s * 1000), ctypes.byref(self.h)))
 
     def close(self):
         if self.h:
             lib().dapol_comm_destroy(self.h)
             self.h = _P()
+
+    def abort(self):
+        """The failure path: ncclCommAbort, without waiting for the peers."""
+        if self.h:
+            lib().dapol_comm_abort(self.h)
+            self.h = _P()
+
+    def count(self):
+        n = ctypes.c_int32(0)
+        _chk(lib().dapol_comm_count(self.h, ctypes.byref(n)))
+        return int(n.value)
 
     def __del__(self):
         try:
@@ -588,16 +616,20 @@ class Workload:
         _chk(lib().dapol_workload_build(self.h, _ptr(ps), _ptr(C), _ptr(H), _ptr(v), _ptr(r), ctypes.byref(st)))
         return (C.tobytes(), H.tobytes(), int(v[0]), r.tobytes()), st
 
-    def prove(self, nonce_seed, n_bits=64, first=0, count=None, upper=None, stats=None):
+    def prove(self, nonce_seed, n_bits=64, first=0, count=None, upper=None, stats=None, policy=POLICY_PADDING, aggregation_factor=None):
+        """One inclusion proof per entity of [first, first + count): padding policy with aggregation_factor = total height by default
+        (the headline workload); policy / aggregation_factor select the reference's other shapes (dapol_workload_prove_policy)."""
         st = stats if stats is not None else WorkloadStats()
         count = self.n - first if count is None else count
         ns = _u8(np.frombuffer(nonce_seed, np.uint8))
+        agg = self.height if aggregation_factor is None else aggregation_factor
         if upper is None or len(upper[2]) == 0:
-            _chk(lib().dapol_workload_prove(self.h, _ptr(ns), n_bits, first, count, 0, None, None, None, None, ctypes.byref(st)))
+            _chk(lib().dapol_workload_prove_policy(self.h, _ptr(ns), n_bits, first, count, policy, agg, 0, None, None, None, None, ctypes.byref(st)))
         else:
             nu = len(upper[2])
             uC, uH, uv, ur = _u8(upper[0], nu, 32), _u8(upper[1], nu, 32), _u64(upper[2]), _u8(upper[3], nu, 32)
-            _chk(lib().dapol_workload_prove(self.h, _ptr(ns), n_bits, first, count, nu, _ptr(uC), _ptr(uH), _ptr(uv), _ptr(ur), ctypes.byref(st)))
+            _chk(lib().dapol_workload_prove_policy(self.h, _ptr(ns), n_bits, first, count, policy, agg, nu, _ptr(uC), _ptr(uH), _ptr(uv), _ptr(ur),
+                                                   ctypes.byref(st)))
         return st
 
     def run(self, pad_seed, nonce_seed, n_bits=64, first=0, count=None):

@@ -26,6 +26,11 @@ static int32_t fail_hip(hipError_t e, const char* what, int line) {
     char buf[256];
     snprintf(buf, sizeof buf, "%s failed at dapol_hip.hip:%d: %s", what, line, hipGetErrorString(e));
     g_last_error = buf;
+    // Several entry points fork work onto the context's side streams (chunks in flight, the verifier's own-point ladders, the
+    // leaves' commitments of a small tree) and join it later; an error return in between must not leave that work running on the
+    // context's scratch, which the next call re-uses without any ordering against those streams.  Errors are rare: drain the device.
+    (void)hipDeviceSynchronize();
+    (void)hipGetLastError();
     return e == hipErrorOutOfMemory ? DAPOL_ERR_OUT_OF_MEMORY : DAPOL_ERR_HIP;
 }
 static int32_t fail(int32_t code, const char* msg) {
@@ -64,7 +69,25 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 // The assumptions about smtree 0.1.2 that nothing in the reference repository pins (include/dapol_hip.h, dapol_wire_config):
 // byte order and widths of the wire integers, path width, and the order of a proof's siblings.  One field each; the
 // defaults are the believed ones.  Set / read through dapol_wire_config_set / _get (host_wire.inc).
-static dapol_wire_config g_wire = {1, 8, 8, 2, 0, 0};
+// The stored configuration is process-wide and mutable (dapol_wire_config_set); a call must not see it change under its feet
+// (sizes computed in one pass, bytes written in the next; the sibling order between the prover's gather and its range proofs).
+// Every public entry point that depends on it therefore opens a WIRE_SCOPE(): the outermost scope of a thread copies the stored
+// configuration under the mutex into a thread-local snapshot, and everything below reads the snapshot (`g_wire`).
+static dapol_wire_config g_wire_store = {1, 8, 8, 2, 0, 0};
+static std::mutex g_wire_mu;
+static thread_local dapol_wire_config t_wire = {1, 8, 8, 2, 0, 0};
+static thread_local int t_wire_depth = 0;
+struct WireScope {
+    WireScope() {
+        if (t_wire_depth++ == 0) {
+            std::lock_guard<std::mutex> g(g_wire_mu);
+            t_wire = g_wire_store;
+        }
+    }
+    ~WireScope() { --t_wire_depth; }
+};
+#define WIRE_SCOPE() WireScope wire_scope_
+#define g_wire t_wire
 
 // ------------------------------------------------------------------------------------------------ context
 struct dapol_ctx {
@@ -448,6 +471,7 @@ struct OwnedLeaves {
 };
 struct dapol_tree_owned : dapol_tree {
     OwnedLeaves leaves;          // empty when level 0 borrows the caller's device arrays (workload trees)
+    DevBuf<uint8_t> upd_scratch; // dapol_tree_update's incremental path (kept: an update must not pay for an allocation)
     bool holds_ctx = false;      // API-created trees keep their context alive (workload trees live inside a workload that does)
 };
 
@@ -503,6 +527,54 @@ int32_t dapol_tree_build_shard(dapol_ctx* ctx, int32_t total_height, int32_t sha
 // one already at its index.  Padding nodes are keyed by position, so the updated tree is exactly what
 // dapol_tree_build gives for the resulting leaf set; the host merges the (small) update into the sorted leaf arrays
 // and the level-parallel build runs again -- one pass for the whole batch instead of k root-to-leaf walks.
+// The incremental path of dapol_tree_update (kernels_ctx_tree.h, "incremental update"): every updated leaf already exists, so the
+// tree keeps its structure and only the k root-to-leaf paths are re-merged, on the device, in three launches.  *done = false
+// (nothing above the leaves touched) when some index is new: the caller then rebuilds.
+static int32_t tree_update_incremental(dapol_tree_owned* own, size_t k, const std::vector<uint64_t>& idx, const std::vector<uint64_t>& v,
+                                       const std::vector<uint8_t>& r, bool* done) {
+    *done = false;
+    dapol_ctx* ctx = own->ctx;
+    hipStream_t st = ctx->stream;
+    const int H = own->height;
+    // one staging buffer up, one scratch allocation (kept with the tree): idx | v | r | dv | dr | dP | pos | missing
+    const size_t o_idx = 0, o_v = o_idx + k * 8, o_r = o_v + k * 8, o_dv = o_r + k * 32, o_dr = o_dv + k * 8, o_dP = o_dr + k * 32,
+                 o_pos = o_dP + k * 160, o_miss = align_up(o_pos + k * (size_t)(H + 1) * 4, 8), total = o_miss + 8;
+    if (own->upd_scratch.n < total) HIPCHK(own->upd_scratch.alloc(total + total / 2));
+    std::vector<uint8_t> stage(o_dv);
+    memcpy(stage.data() + o_idx, idx.data(), k * 8);
+    memcpy(stage.data() + o_v, v.data(), k * 8);
+    memcpy(stage.data() + o_r, r.data(), k * 32);
+    uint8_t* d = own->upd_scratch.p;
+    HIPCHK(hipMemcpyAsync(d, stage.data(), o_dv, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(d + o_miss, 0, 8, st));
+    TreeUpdArgs U{k, H, (const uint64_t*)(d + o_idx), (const uint64_t*)(d + o_v), (const uint32_t*)(d + o_r), (uint32_t*)(d + o_pos), (int32_t*)(d + o_dP),
+                  (uint64_t*)(d + o_dv), (uint32_t*)(d + o_dr), (uint32_t*)(d + o_miss)};
+    hipLaunchKernelGGL(k_tree_upd_find, dim3(nblk(k, 64)), dim3(64), 0, st, own->d_views.p, U);
+    LAUNCH_CHECK();
+    uint32_t missing = 0;
+    HIPCHK(hipMemcpyAsync(&missing, d + o_miss, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (missing) return DAPOL_OK;                            // a new index: nothing has been written, the caller rebuilds
+    hipLaunchKernelGGL(k_tree_upd_leaves, dim3(nblk(k, 64)), dim3(64), 0, st, ctx->tv, own->d_views.p, U);
+    LAUNCH_CHECK();
+    if (H >= 1) {
+        hipLaunchKernelGGL(k_tree_upd_nodes, dim3(nblk(k * (size_t)H, 64)), dim3(64), 0, st, own->d_views.p, U);
+        LAUNCH_CHECK();
+        if (k <= 1024) {
+            hipLaunchKernelGGL(k_tree_upd_hash, dim3(1), dim3((unsigned)align_up(k, 64)), 0, st, ctx->tv.digest, own->d_views.p, U, 0, H);
+            LAUNCH_CHECK();
+        } else {
+            for (int lv = 0; lv < H; lv++) {
+                hipLaunchKernelGGL(k_tree_upd_hash, dim3(nblk(k, 256)), dim3(256), 0, st, ctx->tv.digest, own->d_views.p, U, lv, lv + 1);
+                LAUNCH_CHECK();
+            }
+        }
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    *done = true;
+    return DAPOL_OK;
+}
+
 int32_t dapol_tree_update(dapol_tree* tree, size_t k, const uint64_t* leaf_idx, const uint64_t* v, const uint8_t* r32) {
     if (!tree || (k && (!leaf_idx || !v || !r32))) return fail(DAPOL_ERR_INVALID_ARGUMENT, "null argument");
     if (k == 0) return DAPOL_OK;
@@ -511,6 +583,30 @@ int32_t dapol_tree_update(dapol_tree* tree, size_t k, const uint64_t* leaf_idx, 
     dapol_ctx* ctx = tree->ctx;
     HIPCHK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
+    // Replacing the liabilities of leaves that exist (what smtree's update does to ONE leaf: re-merge its root-to-leaf path) keeps the
+    // structure: up to DAPOL_UPDATE_INCREMENTAL_MAX (default 65,536, and at most an eighth of the leaves) such updates are applied
+    // in place on the device.  Anything else -- a new index, a big batch -- takes the rebuild below, which is bit for bit the same tree.
+    {
+        size_t inc_max = 65536;
+        if (const char* e = getenv("DAPOL_UPDATE_INCREMENTAL_MAX")) inc_max = (size_t)atoll(e);
+        if (k <= inc_max && k <= tree->levels[0].n / 8 + 1 && tree->levels[0].n > 0) {
+            std::vector<uint32_t> ord(k);
+            for (size_t i = 0; i < k; i++) ord[i] = (uint32_t)i;
+            std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return leaf_idx[a] < leaf_idx[b]; });
+            std::vector<uint64_t> si, sv;
+            std::vector<uint8_t> sr;
+            for (size_t b = 0; b < k; b++) {
+                if (b + 1 < k && leaf_idx[ord[b + 1]] == leaf_idx[ord[b]]) continue;      // later updates of the same index win
+                const uint32_t u = ord[b];
+                si.push_back(leaf_idx[u]); sv.push_back(v[u]);
+                sr.insert(sr.end(), r32 + (size_t)u * 32, r32 + (size_t)u * 32 + 32);
+            }
+            bool done = false;
+            int32_t rc = tree_update_incremental(own, si.size(), si, sv, sr, &done);
+            if (rc != DAPOL_OK) return rc;
+            if (done) return DAPOL_OK;
+        }
+    }
     const size_t n0 = tree->levels[0].n;
     std::vector<uint64_t> oi(n0), ov(n0);
     std::vector<uint8_t> orr(n0 * 32);
@@ -778,6 +874,7 @@ static int32_t tree_paths_device(dapol_tree* tree, size_t b, const uint64_t* d_l
 
 int32_t dapol_tree_paths(dapol_tree* tree, size_t b, const uint64_t* leaf_idx, uint8_t* sib_C32, uint8_t* sib_H32, uint64_t* sib_v,
                          uint8_t* sib_r32) {
+    WIRE_SCOPE();
     if (!tree || (b && !leaf_idx)) return fail(DAPOL_ERR_INVALID_ARGUMENT, "null argument");
     if (b == 0) return DAPOL_OK;
     HIPCHK(hipSetDevice(tree->ctx->device));

@@ -308,6 +308,142 @@ __global__ __launch_bounds__(256) void k_tree_merge(TableView tbl, LevelView cur
     if (nxt.ext) st_p3(nxt.ext + q * 40, pp);
 }
 
+// ------------------------------------------------------------------------------------- incremental update
+// smtree's `update` (src/dapol/mod.rs:210-213 -> SparseMerkleTree::update) re-merges ONE root-to-leaf path.  Replacing the
+// liabilities of k leaves that already exist changes no structure: the same nodes, parents and padding siblings (those are keyed
+// by position).  What changes along every path is a sum: an ancestor's value, blinding and commitment move by the sum of the
+// deltas of the updated leaves below it --
+//     v' = v + sum dv (u64 wrap, as Mergeable::merge),   r' = r + sum dr (mod l),   C' = C + sum dP  (group addition)
+// -- and every ancestor is independent of every other, so all levels run side by side (U2); only the hash chain is sequential
+// over the levels (U3, one block stepping through them).  The result equals dapol_tree_build over the new leaf set bit for bit
+// (ristretto encodings are canonical; tests/test_gpu_parity.py::test_update_equals_build).
+//   U0  k_tree_upd_find     per update: find the leaf and its node positions at every level (parent pointers); a missing index
+//                           sends the whole batch to the rebuild before anything has been written
+//   U1  k_tree_upd_leaves   per update: the leaf's new node, dP = P_new - P_old, dv, dr
+//   U2  k_tree_upd_nodes    per (update, level >= 1): the first update of a run that shares the node adds the run's deltas to it
+//   U3  k_tree_upd_hash     one block, level by level: re-hash the touched parents from their (updated) children
+struct TreeUpdArgs {
+    size_t k;                  // updates, sorted by leaf index, distinct
+    int height;
+    const uint64_t* idx;       // [k]
+    const uint64_t* v;         // [k]
+    const uint32_t* r;         // [k][8]
+    uint32_t* pos;             // [k][height + 1]   node position of update j at every level
+    int32_t* dP;               // [k][40]           P_new - P_old, extended
+    uint64_t* dv;              // [k]
+    uint32_t* dr;              // [k][8]            Montgomery form
+    uint32_t* missing;         // != 0: some leaf index is not in the tree (the caller rebuilds instead)
+};
+// U0: where the updated leaves are (nothing is written to the tree until every index has been found)
+__global__ __launch_bounds__(64) void k_tree_upd_find(const LevelView* views, TreeUpdArgs U) {
+    const size_t j = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (j >= U.k) return;
+    const LevelView L0 = views[0];
+    const uint64_t want = U.idx[j];
+    size_t lo = 0, hi = L0.n;                       // lower bound in the sorted leaf indexes
+    while (lo < hi) {
+        const size_t mid = (lo + hi) >> 1;
+        if (L0.idx[mid] < want) lo = mid + 1; else hi = mid;
+    }
+    if (lo >= L0.n || L0.idx[lo] != want) { atomicOr(U.missing, 1u); return; }
+    uint32_t* pos = U.pos + j * (size_t)(U.height + 1);
+    size_t p = lo;
+    pos[0] = (uint32_t)p;
+    for (int k = 0; k < U.height; k++) { p = views[k].parent[p]; pos[k + 1] = (uint32_t)p; }
+}
+__global__ __launch_bounds__(64) void k_tree_upd_leaves(TableView tbl, const LevelView* views, TreeUpdArgs U) {
+    const size_t j = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (j >= U.k) return;
+    const LevelView L0 = views[0];
+    const size_t lo = U.pos[j * (size_t)(U.height + 1)];
+    uint32_t rn[8], ro[8], c[8], h[8];
+    ld8(rn, U.r + j * 8);
+    rn[7] &= 0x7fffffffu;                          // Scalar::from_bits
+    ld8(ro, L0.r + lo * 8);
+    ld8(c, L0.C + lo * 8);
+    ge_p3 pn, po, npo, d;
+    ge_identity(pn);
+    tbl_fixed_mul_add_u64(pn, tbl, tbl.row_B(0), U.v[j]);
+    tbl_fixed_mul_add(pn, tbl, tbl.row_Bb(0), rn);
+    (void)ge_decompress(po, c);                    // the tree's own encoding: always decodes
+    ge_neg(npo, po);
+    ge_add(d, pn, npo);
+    st_p3(U.dP + j * 40, d);
+    sc mn, mo, md;
+    sc_to_mont(mn, rn);
+    sc_to_mont(mo, ro);
+    sc_sub(md, mn, mo);
+    for (int i = 0; i < 8; i++) U.dr[j * 8 + i] = md.v[i];
+    U.dv[j] = U.v[j] - L0.v[lo];
+    ge_compress(c, pn);
+    node_hash32(tbl.digest, h, c);
+    L0.v[lo] = U.v[j];
+    st8(L0.r + lo * 8, rn);
+    st8(L0.C + lo * 8, c);
+    st8(L0.H + lo * 8, h);
+}
+__global__ __launch_bounds__(64) void k_tree_upd_nodes(const LevelView* views, TreeUpdArgs U) {
+    const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (t >= U.k * (size_t)U.height) return;
+    const size_t j = t / (size_t)U.height;
+    const int k = 1 + (int)(t - j * (size_t)U.height);
+    const size_t stride = (size_t)U.height + 1;
+    const uint32_t p = U.pos[j * stride + k];
+    if (j > 0 && U.pos[(j - 1) * stride + k] == p) return;          // an earlier update of the run owns this node
+    ge_p3 sum, q, s;
+    ld_p3(sum, U.dP + j * 40);
+    uint64_t dv = U.dv[j];
+    sc dr, t2;
+    for (int i = 0; i < 8; i++) dr.v[i] = U.dr[j * 8 + i];
+    for (size_t jj = j + 1; jj < U.k && U.pos[jj * stride + k] == p; jj++) {
+        ld_p3(q, U.dP + jj * 40);
+        ge_add(s, sum, q);
+        sum = s;
+        dv += U.dv[jj];
+        for (int i = 0; i < 8; i++) t2.v[i] = U.dr[jj * 8 + i];
+        sc_add(dr, dr, t2);
+    }
+    const LevelView L = views[k];
+    uint32_t c[8], rr[8];
+    ld8(c, L.C + (size_t)p * 8);
+    ge_p3 old;
+    (void)ge_decompress(old, c);
+    ge_add(s, old, sum);
+    ge_compress(c, s);
+    st8(L.C + (size_t)p * 8, c);
+    L.v[p] += dv;
+    ld8(rr, L.r + (size_t)p * 8);
+    sc mr;
+    sc_to_mont(mr, rr);
+    sc_add(mr, mr, dr);
+    sc_from_mont(rr, mr);
+    st8(L.r + (size_t)p * 8, rr);
+}
+// grid = 1 block of up to 1,024 threads; thread j = update j (k <= 1,024), stepping through the levels together.
+__global__ __launch_bounds__(1024) void k_tree_upd_hash(int digest, const LevelView* views, TreeUpdArgs U, int level_begin, int level_end) {
+    const size_t j = threadIdx.x + (size_t)blockIdx.x * blockDim.x;
+    const size_t stride = (size_t)U.height + 1;
+    for (int k = level_begin; k < level_end; k++) {                // children at level k -> parent at level k + 1
+        if (j < U.k) {
+            const uint32_t pp = U.pos[j * stride + k + 1];
+            if (j == 0 || U.pos[(j - 1) * stride + k + 1] != pp) {
+                const LevelView L = views[k];
+                const size_t i = U.pos[j * stride + k];
+                const uint64_t my = L.idx[i];
+                uint32_t cA[8], hA[8], cB[8], hB[8], hp[8];
+                ld8(cA, L.C + i * 8); ld8(hA, L.H + i * 8);
+                const bool left = (my & 1ull) == 0;
+                if (L.has_pad[i]) { ld8(cB, L.padC + i * 8); ld8(hB, L.padH + i * 8); }
+                else { const size_t s = left ? i + 1 : i - 1; ld8(cB, L.C + s * 8); ld8(hB, L.H + s * 8); }
+                if (left) node_hash128(digest, hp, cA, cB, hA, hB);
+                else node_hash128(digest, hp, cB, cA, hB, hA);
+                st8(views[k + 1].H + (size_t)pp * 8, hp);
+            }
+        }
+        if (gridDim.x == 1) __syncthreads();                       // (several blocks: one launch per level instead)
+    }
+}
+
 // ------------------------------------------------------------------------------------- small trees, by phases
 // k_tree_merge makes a level in one pass, which is right for millions of nodes (one trip through HBM) and wrong for a tree of a
 // few thousand (the reference's `build` criterion group, benches/dapol.rs:24-57; dapol_tree_update): a level is then ONE lane's

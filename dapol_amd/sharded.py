@@ -75,6 +75,8 @@ class ShardedProver:
         self.upper = None
         self.root = None
         self.comm = None
+        self.comm_ranks = None                    # ncclCommCount of the library's communicator, when it carries the exchange
+        self.comm_error = None
         self.exchange_path = "none (single GPU)"
         if world > 1:
             self.exchange_path = "torch.distributed all_gather (%s)" % ("RCCL" if comm_device == "cuda" else "gloo")
@@ -82,43 +84,35 @@ class ShardedProver:
                 self._create_comm()
 
     def _create_comm(self, timeout_s=90.0):
-        """RCCL communicator inside the library: rank 0 draws the id, torch.distributed carries it to the other ranks.
-        ncclCommInitRank blocks until every rank has called it, so it runs on a helper thread with a deadline: a rank that
-        cannot join (or a bootstrap that never completes) must not hang the job -- every rank then falls back to the
-        torch.distributed transport, and the line says which one ran."""
+        """RCCL communicator inside the library: rank 0 draws the id, torch.distributed carries it to the other ranks, and
+        every rank creates its end NON-BLOCKING with a deadline (dapol_comm_create_timeout: ncclCommInitRankConfig(blocking = 0)
+        polled with ncclCommGetAsyncError; a communicator that has not come up by the deadline is aborted inside the call, not
+        abandoned).  The ranks then AGREE on the outcome (all-reduce MIN) before anybody tears anything down: if any rank failed,
+        the ranks that did get a communicator abort it (ncclCommAbort -- never a destroy that would wait for a peer that is
+        gone) and every rank uses the torch.distributed transport; the line says which one ran."""
         import os
-        import threading
         t, ok = self.torch, 1
         if os.environ.get("DAPOL_EXCHANGE", "").lower() == "torch":
             return
-        box = {}
-
-        def create(uid_bytes):
-            try:
-                box["comm"] = capi.Comm(self.ctx, uid_bytes, self.rank, self.world)
-            except Exception as e:                          # stay on the torch.distributed path, and say so
-                box["err"] = repr(e)
-
         try:
             uid = capi.comm_unique_id() if self.rank == 0 else bytes(capi.COMM_ID_BYTES)
             buf = t.from_numpy(np.frombuffer(uid, np.uint8).copy()).to(self.comm_device)
             self.dist.broadcast(buf, src=0)
-            th = threading.Thread(target=create, args=(buf.cpu().numpy().tobytes(),), daemon=True)
-            th.start()
-            th.join(timeout_s)
-            if th.is_alive() or "comm" not in box:
-                self.comm_error, ok = box.get("err", "ncclCommInitRank did not return within %.0f s" % timeout_s), 0
-            else:
-                self.comm = box["comm"]
+            self.comm = capi.Comm(self.ctx, buf.cpu().numpy().tobytes(), self.rank, self.world, timeout_s=timeout_s)
+            self.comm_ranks = self.comm.count()
+            if self.comm_ranks != self.world:
+                raise capi.DapolError(10, "ncclCommCount says %d ranks, expected %d" % (self.comm_ranks, self.world))
         except Exception as e:
             self.comm_error, ok = repr(e), 0
         flag = t.tensor([ok], dtype=t.int64, device=self.comm_device)
         self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
         if int(flag.item()) == 1:
             self.exchange_path = "dapol_shard_exchange (ncclAllGather inside libdapol_hip.so)"
-        elif self.comm is not None:
-            self.comm.close()
+        else:
+            if self.comm is not None:
+                self.comm.abort()
             self.comm = None
+            self.comm_ranks = None
 
     def _exchange(self, root):
         if self.world == 1:

@@ -185,8 +185,10 @@ struct DapolProof {
         std::vector<uint8_t> C(h * 32 + 1), H(h * 32 + 1);
         for (size_t i = 0; i < h; i++) { std::memcpy(&C[i * 32], merkle_siblings[i].com.data(), 32); std::memcpy(&H[i * 32], merkle_siblings[i].hash.data(), 32); }
         uint8_t ok = 0;
-        check(dapol_verify_entities(ctx.get(), height, 1, &leaf_index, leaf.com.data(), leaf.hash.data(), C.data(), H.data(), root.com.data(), root.hash.data(),
-                                    (int)policy, (int)aggregation_factor, n_bits, range_proofs.data(), nullptr, &ok));
+        // the length-checked entry point: a proof whose sibling count or range-proof bytes do not fit (height, policy, aggregation
+        // factor) -- e.g. one deserialised from hostile bytes -- is simply invalid
+        check(dapol_verify_entities_checked(ctx.get(), height, 1, &leaf_index, leaf.com.data(), leaf.hash.data(), h, C.data(), H.data(), root.com.data(),
+                                            root.hash.data(), (int)policy, (int)aggregation_factor, n_bits, range_proofs.data(), range_proofs.size(), nullptr, &ok));
         return ok != 0;
     }
 };
@@ -222,8 +224,8 @@ struct DapolBatchProof {
         for (size_t i = 0; i < k; i++) { std::memcpy(&lC[i * 32], leaves[i].com.data(), 32); std::memcpy(&lH[i * 32], leaves[i].hash.data(), 32); }
         for (size_t i = 0; i < S; i++) { std::memcpy(&sC[i * 32], merkle_siblings[i].com.data(), 32); std::memcpy(&sH[i * 32], merkle_siblings[i].hash.data(), 32); }
         uint8_t ok = 0;
-        check(dapol_verify_batch(ctx.get(), height, k, leaf_indexes.data(), lC.data(), lH.data(), S, sC.data(), sH.data(), root.com.data(),
-                                 root.hash.data(), (int)policy, (int)aggregation_factor, n_bits, range_proofs.data(), verify_seed, &ok));
+        check(dapol_verify_batch_checked(ctx.get(), height, k, leaf_indexes.data(), lC.data(), lH.data(), S, sC.data(), sH.data(), root.com.data(),
+                                         root.hash.data(), (int)policy, (int)aggregation_factor, n_bits, range_proofs.data(), range_proofs.size(), verify_seed, &ok));
         return ok != 0;
     }
 };

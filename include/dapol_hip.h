@@ -263,11 +263,31 @@ int32_t dapol_verify_batch(dapol_ctx* ctx, int32_t height, size_t k, const uint6
                            const uint8_t root_C32[32], const uint8_t root_H32[32], int32_t policy, int32_t aggregation_factor,
                            int32_t n_bits, const uint8_t* range_proofs, const uint8_t verify_seed32[32], uint8_t* ok);
 
+/* Length-checked forms for buffers that come from UNTRUSTED bytes (a decoded wire): the counts the caller holds are compared
+ * with what (height, policy, aggregation_factor, n_bits) imply before anything is read; a proof of the wrong shape is an INVALID
+ * proof (ok = 0, DAPOL_OK), never an over-read.  n_path_nodes = records in path_C32 / path_H32 (must be b * height);
+ * range_proofs_len in bytes (must be b * dapol_entity_proof_size(height, ...), or the size over n_siblings for a batch proof). */
+int32_t dapol_verify_entities_checked(dapol_ctx* ctx, int32_t height, size_t b, const uint64_t* leaf_idx, const uint8_t* leaf_C32, const uint8_t* leaf_H32,
+                                      size_t n_path_nodes, const uint8_t* path_C32, const uint8_t* path_H32, const uint8_t root_C32[32],
+                                      const uint8_t root_H32[32], int32_t policy, int32_t aggregation_factor, int32_t n_bits, const uint8_t* range_proofs,
+                                      size_t range_proofs_len, const uint8_t verify_seed32[32], uint8_t* ok);
+int32_t dapol_verify_batch_checked(dapol_ctx* ctx, int32_t height, size_t k, const uint64_t* leaf_idx, const uint8_t* leaf_C32, const uint8_t* leaf_H32,
+                                   size_t n_siblings, const uint8_t* sib_C32, const uint8_t* sib_H32, const uint8_t root_C32[32], const uint8_t root_H32[32],
+                                   int32_t policy, int32_t aggregation_factor, int32_t n_bits, const uint8_t* range_proofs, size_t range_proofs_len,
+                                   const uint8_t verify_seed32[32], uint8_t* ok);
+
 /* Multi-GPU: one process per GPU, rank g owning the top-level subtree with index prefix g (dapol_tree_build_shard /
  * dapol_workload_create_shard).  The reference has no communication (single process, single thread); the sharded path has
  * exactly one exchange step and one final reduce, both RCCL calls inside this library (librccl.so, over xGMI):
  *   dapol_comm_unique_id   rank 0 makes the 128-byte RCCL id; the host distributes it by whatever means it has
- *   dapol_comm_create      ncclCommInitRank on the context's GPU; world must be a power of two
+ *   dapol_comm_create      the communicator on the context's GPU (world must be a power of two), created NON-BLOCKING
+ *                          (ncclCommInitRankConfig, blocking = 0) and polled with ncclCommGetAsyncError.
+ *   dapol_comm_create_timeout  ... up to a deadline: a communicator that has not come up after timeout_ms is aborted
+ *                          (ncclCommAbort) and the call returns DAPOL_ERR_COMM, so that one absent rank cannot hang the others
+ *                          inside ncclCommInitRank for good; timeout_ms <= 0 waits without a deadline.
+ *   dapol_comm_abort       the failure path (ncclCommAbort): tear down without waiting for the peers, once the ranks have
+ *                          agreed not to use this communicator; dapol_comm_destroy is the orderly end (finalize + destroy).
+ *   dapol_comm_count       the number of ranks as RCCL reports it (ncclCommCount)
  *   dapol_shard_exchange   ncclAllGather of the G subtree-root records (C | H | v LE64 | r = 104 bytes each; an empty shard
  *                          sends the padding node of its root position, dapol_padding_nodes), then every rank merges the
  *                          log2 G replicated top levels on its own GPU (Mergeable::merge) -> the global root record and the
@@ -281,7 +301,10 @@ enum { DAPOL_COMM_ID_BYTES = 128, DAPOL_RECORD_BYTES = 104 };
 enum { DAPOL_REDUCE_SUM = 0, DAPOL_REDUCE_MIN = 1, DAPOL_REDUCE_MAX = 2 };
 int32_t dapol_comm_unique_id(uint8_t id_out[DAPOL_COMM_ID_BYTES]);
 int32_t dapol_comm_create(dapol_ctx* ctx, const uint8_t id[DAPOL_COMM_ID_BYTES], int32_t rank, int32_t world, dapol_comm** out);
+int32_t dapol_comm_create_timeout(dapol_ctx* ctx, const uint8_t id[DAPOL_COMM_ID_BYTES], int32_t rank, int32_t world, int64_t timeout_ms, dapol_comm** out);
 int32_t dapol_comm_destroy(dapol_comm* comm);
+int32_t dapol_comm_abort(dapol_comm* comm);
+int32_t dapol_comm_count(dapol_comm* comm, int32_t* count);
 int32_t dapol_shard_exchange(dapol_comm* comm, const uint8_t sub_C[32], const uint8_t sub_H[32], uint64_t sub_v, const uint8_t sub_r[32],
                              uint8_t root_C[32], uint8_t root_H[32], uint64_t* root_v, uint8_t root_r[32], uint8_t* up_C32, uint8_t* up_H32,
                              uint64_t* up_v, uint8_t* up_r32, uint8_t* records_out);
@@ -326,6 +349,11 @@ typedef struct {
     uint64_t msm_launches, proofs, proof_bytes;
     uint64_t checksum;
     uint8_t root_C[32], root_H[32];
+    /* (appended in round 3; the fields above keep their offsets)  msm_ms / msm_launches bracket the PLAIN fixed-base MSMs (S
+     * commitment + never-fold rounds), mat_ms / mat_launches the materialisation of the folded generators; *_kernels = launches
+     * of the dominant kernel inside those brackets (a generator-stationary MSM is a few hundred tile launches of k_rp_msm_gs). */
+    double mat_ms;
+    uint64_t mat_launches, msm_kernels, mat_kernels;
 } dapol_workload_stats;
 int32_t dapol_workload_run(dapol_workload* w, const uint8_t pad_seed32[32], const uint8_t nonce_seed32[32], int32_t n_bits,
                            size_t first_entity, size_t n_entities, dapol_workload_stats* stats);
@@ -336,6 +364,11 @@ int32_t dapol_workload_build(dapol_workload* w, const uint8_t pad_seed32[32], ui
 int32_t dapol_workload_prove(dapol_workload* w, const uint8_t nonce_seed32[32], int32_t n_bits, size_t first_entity, size_t n_entities,
                              int32_t n_upper, const uint8_t* up_C32, const uint8_t* up_H32, const uint64_t* up_v, const uint8_t* up_r32,
                              dapol_workload_stats* stats);
+/* dapol_workload_prove under either policy / any aggregation factor (the reference's bench also times RangeProofSplitting,
+ * benches/dapol.rs:71-78); dapol_workload_prove = (DAPOL_POLICY_PADDING, height). */
+int32_t dapol_workload_prove_policy(dapol_workload* w, const uint8_t nonce_seed32[32], int32_t n_bits, size_t first_entity, size_t n_entities,
+                                    int32_t policy, int32_t aggregation_factor, int32_t n_upper, const uint8_t* up_C32, const uint8_t* up_H32,
+                                    const uint64_t* up_v, const uint8_t* up_r32, dapol_workload_stats* stats);
 /* Siblings of sampled leaves of the last build, with the upper siblings prepended: [b][n_upper+levels].  (v, r) are the
  * secrets handed to the range prover; (C, H) the Merkle path proof nodes.  Output / upper pointers may be NULL in pairs. */
 int32_t dapol_workload_paths(dapol_workload* w, size_t b, const uint64_t* leaf_idx, int32_t n_upper, const uint64_t* up_v,

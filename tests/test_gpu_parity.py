@@ -285,6 +285,79 @@ def test_update_equals_build(gpu_ctx, hip_lib, ref):
     assert C.shape == (3, height, 32)
 
 
+@pytest.mark.parametrize("k", [1, 7, 64, 1500])
+def test_incremental_update_equals_build_every_level(gpu_ctx, hip_lib, k):
+    """dapol_tree_update on EXISTING leaves re-merges only the k root-to-leaf paths on the device (smtree's update,
+    src/dapol/mod.rs:210-213); the tree must equal dapol_tree_build over the new liabilities at every level -- values,
+    blindings, commitments, hashes, padding siblings -- both by the in-place path and by the rebuild it falls back to."""
+    import os
+    rng = np.random.default_rng(1000 + k)
+    height, n = 24, 20000
+    idx, v, r = _rand_leaves(rng, height, n)
+    sel = rng.choice(n, size=k, replace=False)
+    if k >= 7:
+        sel[1] = sel[0] ^ 1 if (sel[0] ^ 1) < n else sel[1]      # neighbours in the sorted order (often siblings high up)
+        sel = np.unique(sel)
+    v2, r2 = v.copy(), r.copy()
+    v2[sel] = rng.integers(0, 2**40, size=len(sel), dtype=np.uint64)
+    r2[sel] = rng.integers(0, 256, size=(len(sel), 32), dtype=np.uint8)
+    r2[sel, 31] &= 0x7F                                          # 255-bit blindings (Scalar::from_bits), some beyond l
+    want = hip_lib.Tree(gpu_ctx, height, idx, v2, r2, SEED)
+    order = rng.permutation(len(sel))                             # the update list arrives unsorted
+    for env in ({}, {"DAPOL_UPDATE_INCREMENTAL_MAX": "0"}):
+        tr = hip_lib.Tree(gpu_ctx, height, idx, v, r, SEED)
+        os.environ.update(env)
+        try:
+            tr.update(idx[sel][order], v2[sel][order], r2[sel][order])
+        finally:
+            for key in env:
+                os.environ.pop(key, None)
+        assert tr.root() == want.root() and tr.node_count() == want.node_count(), env
+        for level in range(height + 1):
+            for a, b in zip(tr.level_nodes(level), want.level_nodes(level)):
+                assert np.array_equal(a, b), (env, level)
+        tr.close()
+    want.close()
+
+
+def test_incremental_update_at_2e20_leaves(gpu_ctx, hip_lib):
+    """one leaf and 64 leaves replaced in the headline tree (2^20 leaves, height 32): root, value sum and the
+    sampled paths equal a fresh build's; a batch that also holds a NEW index takes the rebuild and still agrees; the in-place
+    path is far below the rebuild's 45 ms."""
+    import time
+    import bench
+    height, n = 32, 1 << 20
+    idx, v, r = bench.synth_inputs(n, height, 0, n)
+    tr = hip_lib.Tree(gpu_ctx, height, idx, v, r, SEED)
+    rng = np.random.default_rng(5)
+    v2, r2 = v.copy(), r.copy()
+    for k in (1, 64):
+        sel = np.sort(rng.choice(n, size=k, replace=False))
+        v2[sel] = rng.integers(0, 2**32, size=k, dtype=np.uint64)
+        r2[sel] = rng.integers(0, 256, size=(k, 32), dtype=np.uint8)
+        r2[sel, 31] &= 0x0F
+        tr.update(idx[sel], v2[sel], r2[sel])                      # warm (scratch allocation)
+        t0 = time.perf_counter()
+        tr.update(idx[sel], v2[sel], r2[sel])
+        dt = time.perf_counter() - t0
+        assert dt < 0.010, "incremental update of %d leaves took %.2f ms" % (k, dt * 1e3)
+    want = hip_lib.Tree(gpu_ctx, height, idx, v2, r2, SEED)
+    assert tr.root() == want.root() and tr.root()[2] == int(v2.sum())
+    probe = np.concatenate([idx[sel][:8], idx[::n // 8][:8]])
+    for a, b in zip(tr.paths(probe), want.paths(probe)):
+        assert np.array_equal(a, b)
+    # a new index among the updates: rebuild path, same tree as building from scratch
+    new_idx = np.array([idx[3] + 1, idx[10]], np.uint64)           # idx[3] + 1 is free in the strided layout
+    tr.update(new_idx, np.array([77, 88], np.uint64), r[:2])
+    i3 = np.concatenate([idx, new_idx[:1]])
+    o = np.argsort(i3, kind="stable")
+    v3 = np.concatenate([v2, [77]]).astype(np.uint64)
+    r3 = np.concatenate([r2, r[:1]])
+    v3[10], r3[10] = 88, r[1]
+    want3 = hip_lib.Tree(gpu_ctx, height, i3[o], v3[o], r3[o], SEED)
+    assert tr.root() == want3.root()
+
+
 def test_value_sum_wraps_like_release_rust(gpu_ctx, hip_lib, ref):
     idx = np.array([0, 1], np.uint64)
     v = np.array([2**64 - 1, 5], np.uint64)

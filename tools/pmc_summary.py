@@ -65,13 +65,15 @@ def main():
         out["hbm_bytes_per_launch"] = out["hbm_read_bytes_per_launch"] + out.get("hbm_write_bytes_per_launch", 0)
         out["hbm_GBps"] = out["hbm_bytes_per_launch"] / (c["_dur_ns"])
     for k in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "GRBM_GUI_ACTIVE",
-              "TCC_HIT_sum", "TCC_MISS_sum"):
+              "TCC_HIT_sum", "TCC_MISS_sum", "TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_LEVEL_sum"):
         if k in c:
             out[k] = c[k]
     if "GRBM_GUI_ACTIVE" in c:
         out["effective_clock_GHz"] = c["GRBM_GUI_ACTIVE"] / 8 / c["_dur_ns"]
     if "SQ_INSTS_VALU" in c and "GRBM_GUI_ACTIVE" in c:
         out["cycles_per_valu_inst_per_simd"] = (c["GRBM_GUI_ACTIVE"] / 8) / (c["SQ_INSTS_VALU"] / 1024)
+    if "TCC_EA0_RDREQ_sum" in c and c["TCC_EA0_RDREQ_sum"]:
+        out["l2_read_miss_latency_cycles"] = c["TCC_EA0_RDREQ_LEVEL_sum"] / c["TCC_EA0_RDREQ_sum"]      # fabric round trip of an L2 read miss (Infinity Cache or HBM)
     if "TCC_HIT_sum" in c:
         out["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
     try:                                     # identity of the kernel sources these counters were collected on (bench.py quotes the

@@ -159,6 +159,66 @@ __global__ __launch_bounds__(64, OCC) void k_gs(int32_t* out, int32_t* accs, con
     }
 }
 
+// Tile form with the NEXT row's entry requested in the MIDDLE of the addition: the three products that consume the entry come
+// first, then the loads of the next entry go out into the same registers, then the four products that finish the addition.
+__device__ __forceinline__ void madd_first(fe& E, fe& F, fe& G, fe& H, const ge_p3& p, const ge_niels& q, bool neg) {
+    fe ypx, ymx, A, B, C, D, qa = q.ymx, qb = q.ypx;
+    fe_cswap(qa, qb, neg);
+    fe_add(ypx, p.Y, p.X);
+    fe_sub(ymx, p.Y, p.X);
+    fe_mul(A, ymx, qa);
+    fe_mul(B, ypx, qb);
+    fe_mul(C, p.T, q.xy2d);
+    fe nC;
+    fe_neg(nC, C);
+    fe_cmov(C, nC, neg);
+    fe_add(D, p.Z, p.Z);
+    fe_sub(E, B, A);
+    fe_add(H, B, A);
+    fe_sub(F, D, C);
+    fe_add(G, D, C);
+    fe_carry(G, G);
+}
+__device__ __forceinline__ void madd_second(ge_p3& r, const fe& E, const fe& F, const fe& G, const fe& H) {
+    fe_mul(r.X, F, E);
+    fe_mul(r.Y, H, G);
+    fe_mul(r.Z, F, G);
+    fe_mul(r.T, H, E);
+}
+__global__ __launch_bounds__(64, 3) void k_gs_mid(int32_t* accs, const int32_t* tbl, const int32_t* dig, size_t lanes, int row0, int rows, size_t row_words, unsigned long long* clk) {
+    unsigned long long c0 = clock64(), w0 = wall_clock64();
+    const size_t lane = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (lane >= lanes) return;
+    ge_p3 acc;
+    int32_t* p = accs + lane;
+    for (int i = 0; i < FE_NL; i++) {
+        acc.X.v[i] = p[(size_t)i * lanes]; acc.Y.v[i] = p[(size_t)(9 + i) * lanes];
+        acc.Z.v[i] = p[(size_t)(18 + i) * lanes]; acc.T.v[i] = p[(size_t)(27 + i) * lanes];
+    }
+    const v4i* dg = reinterpret_cast<const v4i*>(dig) + lane;
+    v4i d4 = dg[0];
+    ge_niels e;
+    int d = d4.x;
+    load_entry(e, tbl + (uint64_t)(uint32_t)row0 * (uint32_t)row_words + (uint32_t)((d < 0 ? -d : d) * 32));
+#pragma nounroll
+    for (int g = 0; g < rows; g++) {
+        fe E, F, G, H;
+        madd_first(E, F, G, H, acc, e, d < 0);
+        d4.x = d4.y; d4.y = d4.z; d4.z = d4.w;
+        if (((g + 1) & 3) == 0 && g + 1 < rows) d4 = dg[(size_t)((g + 1) >> 2) * lanes];
+        d = d4.x;
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 1 < rows) load_entry(e, tbl + (uint64_t)(uint32_t)(row0 + g + 1) * (uint32_t)row_words + (uint32_t)((d < 0 ? -d : d) * 32));
+        __builtin_amdgcn_sched_barrier(0);
+        madd_second(acc, E, F, G, H);
+    }
+    if (blockIdx.x == 100 && threadIdx.x == 0) { clk[0] = clock64() - c0; clk[1] = wall_clock64() - w0; }
+    for (int i = 0; i < FE_NL; i++) {
+        p[(size_t)i * lanes] = acc.X.v[i]; p[(size_t)(9 + i) * lanes] = acc.Y.v[i];
+        p[(size_t)(18 + i) * lanes] = acc.Z.v[i]; p[(size_t)(27 + i) * lanes] = acc.T.v[i];
+    }
+}
+
 static double clock_ghz(unsigned long long* d_clk) {
     unsigned long long h[2];
     CHECK(hipMemcpy(h, d_clk, 16, hipMemcpyDeviceToHost));
@@ -228,7 +288,8 @@ int main(int argc, char** argv) {
                     else hipLaunchKernelGGL((k_gs<2, 3>), dim3(blocks), dim3(64), 0, 0, out, accs, tbl, dig, lanes, row_base, list_rows, row_words, 0, d_clk);
                 } else {
                     for (int t = 0; t < list_rows; t += tile_rows) {
-                        if (dv) hipLaunchKernelGGL((k_gs<1, 4, 1>), dim3(blocks), dim3(64), 0, 0, out, accs, tbl, dig + (size_t)t * lanes, lanes, row_base + t, tile_rows, row_words, 1, d_clk);
+                        if (dv == 2) hipLaunchKernelGGL(k_gs_mid, dim3(blocks), dim3(64), 0, 0, accs, tbl, dig + (size_t)t * lanes, lanes, row_base + t, tile_rows, row_words, d_clk);
+                        else if (dv) hipLaunchKernelGGL((k_gs<1, 4, 1>), dim3(blocks), dim3(64), 0, 0, out, accs, tbl, dig + (size_t)t * lanes, lanes, row_base + t, tile_rows, row_words, 1, d_clk);
                         else hipLaunchKernelGGL((k_gs<1, 4>), dim3(blocks), dim3(64), 0, 0, out, accs, tbl, dig + (size_t)t * lanes, lanes, row_base + t, tile_rows, row_words, 1, d_clk);
                     }
                 }
@@ -262,7 +323,7 @@ int main(int argc, char** argv) {
             if (tok.rfind("gst:", 0) == 0) {
                 size_t lanes = 0; int tile = 16; char v = 0;
                 sscanf(tok.c_str(), "gst:%zu:%d:%c", &lanes, &tile, &v);
-                run_gs(v == 'v' ? "gstv" : "gst", 1, lanes, tile, v == 'v');
+                run_gs(v == 'v' ? "gstv" : v == 'm' ? "gstm" : "gst", 1, lanes, tile, v == 'v' ? 1 : v == 'm' ? 2 : 0);
             }
         }
     }
