@@ -2,22 +2,26 @@
 """bench.py -- headline metric of BASELINE.json on MI355X: entities/sec for DAPOL+ tree build + 64-bit range-proof
 generation (one padding-policy inclusion proof per entity, aggregation_factor = height; benches/dapol.rs:59-91,149-175).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--budget-s S]      (N > 1: launched by torch.distributed.run)
-  python bench.py --mode build      the reference's `build` criterion group (benches/dapol.rs:24-57) on the GPU
-  python bench.py --mode verify     BASELINE configs[4]: verification-only, aggregated proofs of 1,024 parties
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--budget-s S]
+      N > 1: one rank per GPU.  Under a launcher (torch.distributed.run sets WORLD_SIZE) this process IS a rank; without one
+      the process -- which has not touched the GPU -- starts `python -m torch.distributed.run --nproc-per-node N ... bench.py`
+      as a child, relays rank 0's JSON line and exits with the child's code.
+  python bench.py --mode build      the reference's `build` criterion group (benches/dapol.rs:24-57) on the GPU, and the
+                                    incremental dapol_tree_update on the headline tree
+  python bench.py --mode verify [--gpus N]   BASELINE configs[4]: verification-only, aggregated proofs of 1,024 parties
   python bench.py --mode criterion  the reference's three criterion groups as it defines them (benches/dapol.rs:24-141):
                                     build, prove (ONE inclusion proof per iteration), verify; N = 1,024, heights 16 / 24 / 32
 
 A step = one pass of the hot path over the whole synthetic entity set, inputs already resident in HBM:
 tree build (commit + hash + merge, padding nodes made on the fly) followed by one aggregated Bulletproof per
-entity.  N = 1 workload: BASELINE.json configs[2] -- 2^20 entities, height 32, 64-bit proofs (the configuration
-the metric is quoted on).  N > 1: weak scaling by default (2^20 entities per GPU, each GPU owning one top-level
-subtree); --log2-entities-total fixes the TOTAL instead (strong scaling: configs[3] = 2^22 over 8).  The only
+entity.  The workload is the one the metric names -- BASELINE.json configs[2]: 2^20 entities IN TOTAL, height 32, 64-bit
+proofs -- at every N: N > 1 is STRONG scaling by default (each GPU owns one top-level subtree holding 2^20 / N entities);
+--log2-entities-total 22 gives configs[3] (2^22 over 8); --weak keeps 2^--log2-entities per GPU instead.  The only
 exchange is an all-gather of the N subtree-root records and an all-reduce of the proof checksum.
 
-Wall budget.  One step of configs[2] takes ~20 s, so the driver's `--steps 20 --warmup 5` cannot fit its 600 s
-limit.  The GPU loop therefore has a wall budget (--budget-s, default 450 s counted from process start, including
-imports / build / context creation): after the first warm-up step the number of timed steps is clamped to what fits
+Wall budget.  One step of configs[2] takes ~19 s, so the driver's `--steps 20 --warmup 5` (25 steps) does not fit its 600 s
+limit with everything else the line carries.  The GPU loop therefore has a wall budget (--budget-s, default 555 s counted from
+process start, including imports / build / context creation and a reserve for the legs after the timed region): after the first warm-up step the number of timed steps is clamped to what fits
 (never below 3) and extra warm-up steps are dropped.  The line reports the steps actually run (`steps`, `warmup`) and
 what was asked for (`steps_requested`, `warmup_requested`).  A heartbeat goes to stderr after every step.
 
@@ -40,6 +44,11 @@ import sys        # noqa: E402
 
 import numpy as np  # noqa: E402
 
+if os.environ.get("DAPOL_BENCH_T0"):            # a rank started by spawn_ranks(): the wall budget counts from the parent's start
+    try:
+        T_PROC0 = float(os.environ["DAPOL_BENCH_T0"])
+    except ValueError:
+        pass
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")   # the CPU-baseline leg's OpenMP team must not spin beside the GPU launches
@@ -231,6 +240,23 @@ def plan_steps(steps_req, warm_req, t_step, seconds_left):
     return extra_warm, steps
 
 
+def plan_workload(args, world):
+    """(entities in total, per GPU, log2 of the total, "strong" | "weak").  The metric is quoted on 2^20 leaves at 1 / 2 / 4 / 8
+    GPUs, so the TOTAL is what --log2-entities (default 20) or --log2-entities-total names and N > 1 divides it (strong
+    scaling); --weak keeps 2^--log2-entities per GPU.  At N = 1 the two are the same thing (reported as "weak": per-GPU work
+    fixed, as the contract's default)."""
+    if world & (world - 1):
+        raise SystemExit("the number of GPUs must be a power of two (each rank owns one top-level subtree)")
+    if args.weak and args.log2_entities_total is None:
+        n_per_gpu = 1 << args.log2_entities
+        return n_per_gpu * world, n_per_gpu, args.log2_entities + (world.bit_length() - 1), "weak"
+    lg_total = args.log2_entities_total if args.log2_entities_total is not None else args.log2_entities
+    n_total = 1 << lg_total
+    if n_total % world or n_total // world < 1:
+        raise SystemExit("2^%d entities cannot be divided over %d GPUs" % (lg_total, world))
+    return n_total, n_total // world, lg_total, ("strong" if world > 1 else "weak")
+
+
 def kernel_src_sha():
     """Identity of the kernel sources a profile was taken on (profiles/*.json carry it; bench.py quotes a profile only
     when it matches the build that is running)."""
@@ -268,8 +294,7 @@ def init_dist(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N > 1 as `python -m torch.distributed.run --nproc-per-node N bench.py "
-                         "--gpus N ...` (and N = 1 without a launcher)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (a launcher started a different number of ranks)" % (args.gpus, world))
     import torch
     dist = None
     backend = os.environ.get("DAPOL_BENCH_BACKEND", "nccl")
@@ -299,18 +324,7 @@ def mode_prove(args):
     from dapol_amd import capi
     from dapol_amd.sharded import ShardedProver
 
-    if args.log2_entities_total is not None:
-        lg_total = args.log2_entities_total
-        n_total = 1 << lg_total
-        if n_total % world:
-            raise SystemExit("--log2-entities-total must give a multiple of the number of GPUs")
-        n_per_gpu = n_total // world
-        scaling = "strong"
-    else:
-        n_per_gpu = 1 << args.log2_entities
-        n_total = n_per_gpu * world
-        lg_total = args.log2_entities + (world.bit_length() - 1)
-        scaling = "weak"
+    n_total, n_per_gpu, lg_total, scaling = plan_workload(args, world)
     height, n_bits = args.height, args.n_bits
     idx, v, r = synth_inputs(n_total, height, rank * n_per_gpu, n_per_gpu)
     ctx = capi.Context(local_rank, _np2(height))
@@ -332,7 +346,8 @@ def mode_prove(args):
 
     # ---- warm-up: one step always (it also sizes the timed loop), more only if asked for AND they fit
     deadline = T_PROC0 + args.budget_s
-    post_reserve = 45.0 if not args.no_cpu_baseline else 20.0           # CPU baseline (~12 s) + parity legs + verification
+    # what follows the timed region: CPU baseline (~12 s) + parity legs + verification (~15 s) + the secondary legs (~30 s, N = 1)
+    post_reserve = (45.0 if not args.no_cpu_baseline else 20.0) + (35.0 if (world == 1 and not args.no_secondary) else 0.0)
     warm_req, steps_req = args.warmup, args.steps
     warm_done = 0
     t_step = None
@@ -354,7 +369,8 @@ def mode_prove(args):
         log("wall budget %.0f s: running %d timed steps (asked %d) after %d warm-up (asked %d)" % (args.budget_s, steps, steps_req, warm_done, warm_req))
 
     # ---- timed region: EXACTLY `steps` steps between barrier + synchronize on both sides
-    acc = {"tree_ms": 0.0, "prove_ms": 0.0, "msm_ms": 0.0, "msm_launches": 0, "proofs": 0}
+    acc = {"tree_ms": 0.0, "prove_ms": 0.0, "msm_ms": 0.0, "msm_launches": 0, "proofs": 0, "mat_ms": 0.0, "mat_launches": 0, "msm_kernels": 0,
+           "mat_kernels": 0, "msm_all_ms": 0.0}
     stats = None
     sync()
     t0 = time.perf_counter()
@@ -380,34 +396,58 @@ def mode_prove(args):
     ms_per_step = elapsed * 1e3 / steps
     value = n_total * steps / elapsed
     ab_prove, ab_tree = algorithmic_bytes(height, n_bits, lg_total)
-    # Dominant kernel: k_rp_msm (fixed-base MSM; S commitment, never-fold rounds, materialisation).  Its launches are
-    # bracketed by HIP events on the stream they run on, inside the library (MsmTiming); summed over the timed steps.
-    msm_s = acc["msm_ms"] / 1e3
-    launches = int(acc["msm_launches"])
+    # Dominant kernel: the fixed-base MSM of the plain rounds (S commitment + never-fold rounds).  Large calls run it
+    # generator-stationary -- k_rp_msm_gs, a few hundred tile launches per MSM -- smaller ones proof-stationary (k_rp_msm<0, .>).
+    # The library brackets every MSM with HIP events on the stream it runs on (MsmTiming) and counts the kernel launches inside
+    # the brackets; the materialisation of the folded generators (k_rp_mat_gs / k_rp_msm<1, .>) is bracketed separately.
+    # Two chunks are in flight on two streams: the library reports UNIONS of the bracket intervals (time during which a plain MSM /
+    # a materialisation / either was running), not sums of bracket lengths.
+    plain_s, mat_s = acc["msm_ms"] / 1e3, acc["mat_ms"] / 1e3
+    msm_s = acc["msm_all_ms"] / 1e3 if acc["msm_all_ms"] > 0 else plain_s + mat_s
+    launches = int(acc["msm_kernels"]) or int(acc["msm_launches"])
+    gs = int(acc["msm_kernels"]) > int(acc["msm_launches"])
     avg_launch_ms = acc["msm_ms"] / max(1, launches)
-    units_per_launch = acc["proofs"] / max(1, launches)               # entities whose bytes one launch accounts for (proofs / launches)
-    ach = (acc["proofs"] * ab_prove / 1e9) / msm_s if msm_s > 0 else 0.0
+    # algorithmic bytes per launch (6,384 B of compulsory traffic per entity on the prove path, spread evenly over the
+    # time of the fixed-base MSM kernels) = proofs x 6,384 B x (share of that time spent in this kernel) / its launches
+    bytes_per_launch = acc["proofs"] * ab_prove * (plain_s / (plain_s + mat_s) if plain_s + mat_s > 0 else 0.0) / max(1, launches)
+    ach = (bytes_per_launch / 1e9) / (avg_launch_ms / 1e3) if avg_launch_ms > 0 else 0.0
     sha = kernel_src_sha()
-    full_size = n_per_gpu >= 73728 and height == 32 and n_bits == 64
+    full_size = n_per_gpu >= 65536 and height == 32 and n_bits == 64
     prof = from_profiles(sha, full_size)
     traffic = None
+    valu = None
     pmc = prof.get("msm_pmc")
-    if pmc and pmc.get("current_build") and full_size:
-        traffic = pmc.get("hbm_bytes_per_launch")                      # PMC passes of THIS build (tools/profile_round.sh), per full launch
+    if pmc and pmc.get("current_build") and full_size and gs == ("k_rp_msm_gs" in str(pmc.get("kernel"))):
+        traffic = pmc.get("hbm_bytes_per_launch")                      # PMC passes of THIS build (tools/pmc_only.sh), per launch of the same kernel
+        roof = prof.get("valu_roof", {})
+        cyc, reg = pmc.get("cycles_per_valu_inst_per_simd"), roof.get("register_only_cycles_per_valu_inst")
+        valu = {"cycles_per_valu_inst_per_simd": cyc, "register_only_cycles_per_valu_inst": reg,
+                "valu_issue_frac": (reg / cyc) if cyc and reg else None,
+                "clock_ghz": pmc.get("effective_clock_GHz"), "clock_frac_of_2p4": (pmc.get("effective_clock_GHz") or 0) / 2.4,
+                "valu_instructions_per_launch": pmc.get("SQ_INSTS_VALU"), "l2_hit_rate": pmc.get("l2_hit_rate"),
+                "l2_read_miss_latency_cycles": pmc.get("l2_read_miss_latency_cycles")}
     roofline = {
         "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": traffic,
-        "kernel": "k_rp_msm", "launches": launches, "avg_launch_ms": avg_launch_ms, "kernel_time_s": msm_s,
-        "algorithmic_bytes_per_entity": ab_prove, "entities_per_launch_share": units_per_launch,
+        "traffic_over_algorithmic": (traffic / bytes_per_launch) if traffic and bytes_per_launch else None,
+        "binding_resource": "integer VALU issue (no MFMA: 255-bit modular arithmetic); see `valu`",
+        "valu": valu,
+        "kernel": "k_rp_msm_gs" if gs else "k_rp_msm", "launches": launches, "avg_launch_ms": avg_launch_ms, "kernel_time_s": plain_s,
+        "msm_brackets": int(acc["msm_launches"]), "avg_msm_ms": acc["msm_ms"] / max(1, int(acc["msm_launches"])),
+        "materialisation": {"kernel": "k_rp_mat_gs" if gs else "k_rp_msm<1, 32>", "launches": int(acc["mat_kernels"]), "kernel_time_s": mat_s},
+        "algorithmic_bytes_per_entity": ab_prove, "algorithmic_bytes_per_launch": bytes_per_launch,
         "whole_step": {"algorithmic_bytes_per_entity": ab_prove + ab_tree,
                        "achieved": (n_per_gpu * steps * (ab_prove + ab_tree) / 1e9) / elapsed,
                        "frac": (n_per_gpu * steps * (ab_prove + ab_tree) / 1e9) / elapsed / PEAK_HBM_GBS,
                        "note": "tree + proof bytes (SURVEY 8d: 9,136 B at 2^20 x H=32) over the whole step time, per GPU"},
-        "kernel_share_of_step": msm_s / elapsed if elapsed > 0 else None,
-        "note": "achieved = ALGORITHMIC bytes (SURVEY 8d, prove path: 6,384 B per entity at H=32) of all timed proofs / summed k_rp_msm "
-                "time of this run (= per-launch bytes / average launch duration).  By construction ~1e-5 of the HBM peak: the path does "
-                "~1e7 modular multiplications per 9 KB of compulsory traffic; the binding roof is integer-VALU issue at the socket power "
-                "cap (DESIGN.md sections 5, 8).  `traffic` is only set from a PMC pass of the build that is running; older profiles "
-                "are under from_profiles with their build hash.",
+        "kernel_share_of_step": plain_s / elapsed if elapsed > 0 else None,
+        "msm_share_of_step": msm_s / elapsed if elapsed > 0 else None,
+        "note": "achieved = ALGORITHMIC bytes per launch of the dominant kernel (SURVEY 8d, prove path: 6,384 B per entity at H=32, spread over the "
+                "fixed-base MSM time; this kernel's share / its launches) / its average launch duration (HIP events around every MSM on the "
+                "stream it runs on, divided by the tile launches inside).  By construction ~1e-5 of the HBM peak: the path does ~1e7 modular "
+                "multiplications per 9 KB of compulsory traffic; what binds is integer-VALU issue (`valu`, from the PMC pass of this "
+                "build).  `traffic` = L2<->fabric bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE; Infinity-Cache hits are counted by "
+                "that counter: for the generator-stationary kernel most of them ARE Infinity-Cache hits, DESIGN.md section 5); it and "
+                "`valu` are only set from a PMC pass of the build that is running; older profiles are under from_profiles with their hash.",
         "kernel_src_sha": sha, "from_profiles": prof}
     cpu = None
     parity = None
@@ -435,6 +475,13 @@ def mode_prove(args):
         rC, rH = prover.root[0], prover.root[1]
         okv = ctx.verify_entities(height, vids, lC, lH, vC, vH, rC, rH, capi.POLICY_PADDING, height, n_bits, vproofs, verify_seed=os.urandom(32))
         parity = dict(parity or {}, inclusion_proofs_verified_on_gpu=int(okv.sum()), inclusion_proofs_checked=int(len(okv)))
+    secondary = None
+    if world == 1 and not args.no_secondary and prover.w is not None:
+        log("secondary legs (splitting policy, API layout, host-buffer entry points)")
+        try:
+            secondary = secondary_legs(ctx, capi, prover, height, n_bits, idx, v, r, n_per_gpu)
+        except Exception as e:                                   # the headline line must not die with a secondary leg
+            secondary = {"error": repr(e)}
     line = {
         "metric": METRIC,
         "value": value, "unit": "entities/s", "n_gpus": world, "steps": steps, "warmup": warm_done,
@@ -442,13 +489,15 @@ def mode_prove(args):
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "int32 limbs (255-bit modular integers)", "data": "synthetic",
         "config": {"workload": "2^%d entities%s, height=%d, %d-bit range proofs, padding policy, aggregation_factor=height, BLAKE3 node hash"
-                               % (lg_total if scaling == "strong" else args.log2_entities,
-                                  " in total" if scaling == "strong" and world > 1 else (" per GPU" if world > 1 else ""), height, n_bits),
+                               % (lg_total if scaling == "strong" or world == 1 else args.log2_entities,
+                                  " in total (strong scaling: 2^%d per GPU)" % (lg_total - (world.bit_length() - 1)) if scaling == "strong" and world > 1
+                                  else (" per GPU (weak scaling)" if world > 1 else ""), height, n_bits),
                    "entities_total": n_total, "entities_per_gpu": n_per_gpu, "proof_bytes": int(stats.proof_bytes // max(1, stats.proofs)),
                    "sharding": "none" if world == 1 else "top-level subtrees, all-gather of %d subtree roots" % world,
-                   "exchange": prover.exchange_path},
+                   "exchange": prover.exchange_path, "rccl_ranks_in_library_communicator": prover.comm_ranks,
+                   "exchange_fallback_reason": prover.comm_error},
         "phases_ms": {"tree_build": acc["tree_ms"] / steps, "prove": acc["prove_ms"] / steps},
-        "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
+        "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "secondary": secondary,
         "checksum": "%016x" % stats.checksum,
         "wall_s_since_process_start": time.time() - T_PROC0,
     }
@@ -456,6 +505,115 @@ def mode_prove(args):
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def secondary_legs(ctx, capi, prover, height, n_bits, idx, v, r, n_per_gpu):
+    """SURVEY 8(d)'s secondary measurements, each on a BOUNDED sample of the same workload (the sample is named in the entry):
+      splitting    the reference bench's other policy (benches/dapol.rs:71-78).  At aggregation_factor = height = 32 the splitting
+                   plan is ONE 32-party proof -- the padding policy's proof, byte for byte -- so that is checked, and the two
+                   policies are timed where they differ: aggregation factor 24 (splitting: 16 + 8 parties; padding: 32) plus 8
+                   individual proofs per entity;
+      api_layout   Dapol::new's way in (src/dapol/mod.rs:323-441): dapol_build_leaf_nodes over 2^20 ids `id-%08d` (BLAKE3 index
+                   derivation, collision resolution, sort) -> tree build -> proofs of a sample;
+      host_buffers the PCIe-inclusive rate: tree from host arrays + dapol_prove_entities returning paths and proofs to the host."""
+    import torch
+    out = {}
+    sync = torch.cuda.synchronize
+    w = prover.w
+    ns = min(n_per_gpu, 1 << 16)
+    ps = proof_bytes(height, n_bits)
+    pad32 = w.proofs(0, min(64, ns), ps).copy()                                     # of the timed run (padding, aggregation 32)
+    sync(); t0 = time.perf_counter()
+    st = w.prove(NONCE_SEED, n_bits, first=0, count=ns, upper=prover.upper, policy=capi.POLICY_SPLITTING, aggregation_factor=height)
+    sync(); dt = time.perf_counter() - t0
+    same = bool(np.array_equal(w.proofs(0, min(64, ns), ps), pad32))
+    out["splitting"] = {"sample": "first 2^%d entities of the workload" % (ns.bit_length() - 1),
+                        "agg32_entities_per_s": ns / dt, "agg32_bytes_equal_padding": same}
+    n24 = min(n_per_gpu, 1 << 14)
+    for pol, name in ((capi.POLICY_SPLITTING, "splitting"), (capi.POLICY_PADDING, "padding")):
+        w.prove(NONCE_SEED, n_bits, first=0, count=256, upper=prover.upper, policy=pol, aggregation_factor=24)      # warm the shapes
+        sync(); t0 = time.perf_counter()
+        st = w.prove(NONCE_SEED, n_bits, first=0, count=n24, upper=prover.upper, policy=pol, aggregation_factor=24)
+        sync(); dt = time.perf_counter() - t0
+        out["splitting"]["agg24_%s_entities_per_s" % name] = n24 / dt
+        out["splitting"]["agg24_%s_proof_bytes" % name] = int(st.proof_bytes // max(1, st.proofs))
+    out["splitting"]["agg24_sample"] = "first 2^%d entities, aggregation factor 24 on the height-32 tree" % (n24.bit_length() - 1)
+    # leave the workload as the timed run left it (sampled proofs are read from it afterwards)
+    w.prove(NONCE_SEED, n_bits, upper=prover.upper)
+    # ---- API layout
+    n_ids = 1 << 20
+    ids = np.char.add("id-", np.char.zfill(np.arange(n_ids).astype("U8"), 8)).astype("S11")
+    packed = ids.tobytes()
+    off = (np.arange(n_ids + 1, dtype=np.uint64) * 11).astype(np.uint32)
+    vals = np.random.default_rng(3).integers(0, 1 << 32, size=n_ids, dtype=np.uint64)
+    t0 = time.perf_counter()
+    lf = ctx.build_leaf_nodes_packed(packed, off, packed, off, vals, b"bench-audit-seed", height)
+    t_leaf = time.perf_counter() - t0
+    wa = capi.Workload(ctx, height, lf["leaf_idx"], lf["v"], lf["r"])
+    sync(); t0 = time.perf_counter()
+    root, sta = wa.build(PAD_SEED)
+    sync(); t_build = time.perf_counter() - t0
+    na = 1 << 16
+    sync(); t0 = time.perf_counter()
+    sta = wa.prove(NONCE_SEED, n_bits, first=0, count=na, stats=sta)
+    sync(); t_prove = time.perf_counter() - t0
+    sample = lf["leaf_idx"][:na:max(1, na // 256)][:256]
+    pos = np.searchsorted(lf["leaf_idx"], sample)
+    _, _, sC, sH = wa.paths(sample, with_nodes=True)
+    got = np.stack([wa.proofs(int(p), 1, ps)[0] for p in pos])
+    lC, lH = ctx.commit_hash_batch(lf["v"][pos], lf["r"][pos])
+    okv = ctx.verify_entities(height, sample, lC, lH, sC, sH, root[0], root[1], capi.POLICY_PADDING, height, n_bits, got)
+    out["api_layout"] = {"ids": "2^20 ids id-%08d, BLAKE3 index derivation, height 32", "build_leaf_nodes_s": t_leaf,
+                         "build_leaf_nodes_entities_per_s": n_ids / t_leaf, "host_inclusive": True,
+                         "indexes_distinct": bool(len(np.unique(lf["leaf_idx"])) == n_ids),
+                         "root_value_equals_sum": bool(root[2] == int(vals.sum())), "tree_build_ms": t_build * 1e3,
+                         "prove_sample": "first 2^16 leaves in index order", "prove_entities_per_s": na / t_prove,
+                         "sampled_proofs_verified": int(okv.sum()), "sampled_proofs_checked": int(len(okv))}
+    wa.close()
+    # ---- host buffers (PCIe-inclusive)
+    nh = min(n_per_gpu, 1 << 16)
+    tree = capi.Tree(ctx, height, idx[:nh], v[:nh], r[:nh], PAD_SEED)
+    tree.prove_entities(idx[:1024], capi.POLICY_PADDING, height, n_bits, NONCE_SEED)
+    tree.close()
+    t0 = time.perf_counter()
+    tree = capi.Tree(ctx, height, idx[:nh], v[:nh], r[:nh], PAD_SEED)                      # H2D of the entity arrays + build
+    pC, pH, proofs = tree.prove_entities(idx[:nh], capi.POLICY_PADDING, height, n_bits, NONCE_SEED)   # D2H: 2 x 32 x 32 B of path + 992 B of proof per entity
+    t_host = time.perf_counter() - t0
+    tree.close()
+    out["host_buffers"] = {"sample": "2^%d entities through dapol_tree_build + dapol_prove_entities (host arrays in, paths and proofs back)" % (nh.bit_length() - 1),
+                           "entities_per_s": nh / t_host, "bytes_returned_per_entity": int(pC[0].nbytes + pH[0].nbytes + proofs[0].nbytes),
+                           "note": "PCIe-inclusive; never the headline `value` (inputs resident in HBM)"}
+    return out
+
+
+def spawn_ranks(args):
+    """`--gpus N` without a launcher: this process has not touched the GPU (no torch import, no HIP call), so it may start the
+    ranks itself -- N fresh children under torch.distributed.run, never an exec -- relay rank 0's JSON line, and leave with
+    the launcher's exit code."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["DAPOL_BENCH_T0"] = repr(T_PROC0)                     # the ranks count the wall budget from THIS process's start
+    log("no launcher (WORLD_SIZE unset): starting %d ranks: %s" % (args.gpus, " ".join(cmd[1:8]) + " ..."))
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    last_json = None
+    for ln in p.stdout:
+        ln = ln.rstrip("\n")
+        if ln.startswith("{") and '"metric"' in ln:
+            last_json = ln
+        else:
+            print(ln, file=sys.stderr, flush=True)
+    rc = p.wait()
+    if last_json is not None:
+        print(last_json, flush=True)
+    elif rc == 0:
+        rc = 1
+    sys.exit(rc)
 
 
 def mode_build(args):
@@ -505,50 +663,142 @@ def mode_build(args):
             ref.ref_tree_root(t, oC, oH, ctypes.byref(ov), orr)
             ref.ref_tree_free(t)
             row["root_bit_exact_vs_oracle"] = bool((oC.raw, oH.raw, ov.value, orr.raw) == root)
+    # dapol_tree_update on the headline tree: k existing liabilities replaced, the k root-to-leaf paths re-merged in place on the
+    # device (smtree's update re-merges one path, src/dapol/mod.rs:210-213); beside it the rebuild it replaces for such updates.
+    update_rows = []
+    h, n = args.height, 1 << args.log2_entities
+    idx, v, r = inputs[(h, n)]
+    tree = capi.Tree(ctx, h, idx, v, r, PAD_SEED)
+    rng = np.random.default_rng(11)
+    for k in (1, 64, 4096):
+        if k > n // 8:
+            continue
+        sel = np.sort(rng.choice(n, size=k, replace=False))
+        nv = rng.integers(0, 1 << 32, size=k, dtype=np.uint64)
+        nr = rng.integers(0, 256, size=(k, 32), dtype=np.uint8)
+        nr[:, 31] &= 0x0F
+        tree.update(idx[sel], nv, nr)                                  # warm-up (scratch allocation)
+        ts = []
+        for _ in range(11):
+            t0 = time.perf_counter()
+            tree.update(idx[sel], nv, nr)
+            ts.append(time.perf_counter() - t0)
+        row = {"leaves_replaced": k, "incremental_ms": 1e3 * sorted(ts)[len(ts) // 2]}
+        if k == 1:
+            os.environ["DAPOL_UPDATE_INCREMENTAL_MAX"] = "0"
+            try:
+                t0 = time.perf_counter()
+                tree.update(idx[sel], nv, nr)
+                row["rebuild_ms"] = 1e3 * (time.perf_counter() - t0)
+            finally:
+                os.environ.pop("DAPOL_UPDATE_INCREMENTAL_MAX", None)
+        update_rows.append(row)
+        log("update k=%d: %.3f ms" % (k, row["incremental_ms"]))
+    tree.close()
     big = rows[-1]
     ab_prove, ab_tree = algorithmic_bytes(args.height, args.n_bits, args.log2_entities)
     ach = big["entities"] * ab_tree / 1e9 / (big["device_ms"] / 1e3)
     print(json.dumps({"metric": "tree build (Dapol::new_blank + build), entities/s", "value": big["entities_per_s"], "unit": "entities/s",
                       "n_gpus": 1, "higher_is_better": True, "data": "synthetic", "dtype": "int32 limbs (255-bit modular integers)",
                       "config": {"workload": "benches/dapol.rs:24-57 build group + 2^%d x height %d" % (args.log2_entities, args.height)},
-                      "cases": rows,
+                      "cases": rows, "update": {"tree": "2^%d leaves x height %d, host-inclusive (H2D of the k records)" % (args.log2_entities, args.height),
+                                               "cases": update_rows},
                       "roofline": {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": None,
                                    "kernel": "k_tree_merge (+ scan / flags)", "algorithmic_bytes_per_entity": ab_tree}}), flush=True)
 
 
 def mode_verify(args):
-    """BASELINE configs[4] on one GPU: verification-only throughput of aggregated Bulletproofs with m = 1,024 parties of 64
-    bits (the reference's `verify` group is benches/dapol.rs:93-141).  The proofs are made by this build's prover first
-    (untimed); then dapol_range_verify_batch over resident... host buffers is timed (host-inclusive: H2D of proofs + commitments)."""
-    import torch
+    """BASELINE configs[4]: verification-only throughput of aggregated Bulletproofs with m = 1,024 parties of 64 bits (the
+    reference's `verify` group is benches/dapol.rs:93-141), on N GPUs.  Verification does not shard a tree: the ranks are
+    REPLICAS of the verifier, each owning a slice of the proofs -- --verify-proofs in total, divided over the ranks (strong
+    scaling; --weak: that many per rank) -- and the only exchange is the AND of the verdicts: dapol_comm_allreduce_u64(MIN) over
+    RCCL inside the library (torch.distributed MIN under the gloo test hook), once per step, inside the timed region.
+    The proofs are made by this build's prover first (untimed); then dapol_range_verify_batch over host buffers is timed
+    (host-inclusive: H2D of proofs + commitments).  value = commitments verified by all ranks / max-over-ranks time."""
+    rank, local_rank, world, torch, dist, backend = init_dist(args)
     from __graft_entry__ import build, ORACLE_LIB
-    build()
+    if rank == 0:
+        build()
+    if dist is not None:
+        dist.barrier()
     from dapol_amd import capi
-    B, m, n = args.verify_proofs, args.verify_parties, 64
-    ctx = capi.Context(0, m)
-    rng = np.random.default_rng(5)
+    from dapol_amd.sharded import create_library_comm
+    B_total, m, n = args.verify_proofs, args.verify_parties, 64
+    if args.weak:
+        B, B_total = B_total, B_total * world
+    else:
+        if B_total % world:
+            raise SystemExit("--verify-proofs must be a multiple of the number of GPUs")
+        B = B_total // world
+    scaling = "weak" if (args.weak or world == 1) else "strong"
+    ctx = capi.Context(local_rank, m)
+    comm_device = "cuda" if backend == "nccl" else "cpu"
+    comm, comm_ranks, comm_err = (None, None, None)
+    reduce_path = "none (single GPU)"
+    if world > 1:
+        reduce_path = "torch.distributed all_reduce MIN (%s)" % ("RCCL" if comm_device == "cuda" else "gloo")
+        if comm_device == "cuda" and os.environ.get("DAPOL_EXCHANGE", "").lower() != "torch":
+            comm, comm_ranks, comm_err = create_library_comm(ctx, rank, world, dist, torch, comm_device)
+            if comm is not None:
+                reduce_path = "dapol_comm_allreduce_u64 MIN (ncclAllReduce inside libdapol_hip.so)"
+
+    def verdict_and(all_ok):
+        if world == 1:
+            return all_ok
+        if comm is not None:
+            return int(comm.allreduce([all_ok], capi.REDUCE_MIN)[0])
+        t = torch.tensor([all_ok], dtype=torch.int64, device=comm_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return int(t.item())
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    rng = np.random.default_rng(5 + rank)
     v = rng.integers(0, 2**32, size=(B, m), dtype=np.uint64)
     r = rng.integers(0, 256, size=(B, m, 32), dtype=np.uint8)
     r[:, :, 31] &= 0x0F
-    log("proving %d x m=%d (untimed setup)" % (B, m))
-    proofs = ctx.range_prove_batch(n, m, v, r, nonce_seed=NONCE_SEED, stream_id=np.arange(B, dtype=np.uint64))
+    log("rank %d: proving %d x m=%d (untimed setup)" % (rank, B, m))
+    proofs = ctx.range_prove_batch(n, m, v, r, nonce_seed=NONCE_SEED, stream_id=np.arange(rank * B, (rank + 1) * B, dtype=np.uint64))
     C, _ = ctx.commit_hash_batch(v.reshape(-1), r.reshape(-1, 32))
     Vs = C.reshape(B, m, 32)
     seed = os.urandom(32)
     for _ in range(max(1, args.warmup)):
         ok = ctx.range_verify_batch(n, m, proofs, Vs, verify_seed=seed)
-    torch.cuda.synchronize()
+        verdict_and(int(ok.all()))
     steps = max(args.steps, 5)
+    sync()
     t0 = time.perf_counter()
+    all_and = 1
     for _ in range(steps):
         ok = ctx.range_verify_batch(n, m, proofs, Vs, verify_seed=seed)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+        all_and &= verdict_and(int(ok.all()))
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=comm_device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    dt = elapsed / steps
+    # one bad proof on ONE rank must turn the job's verdict
     bad = proofs.copy()
-    bad[B // 3, 100] ^= 1
+    if rank == world - 1:
+        bad[B // 3, 100] ^= 1
     ok_bad = ctx.range_verify_batch(n, m, bad, Vs, verify_seed=seed)
+    and_bad = verdict_and(int(ok_bad.all()))
+    local_bad_found = bool(ok_bad[B // 3] == 0 and ok_bad.sum() == B - 1) if rank == world - 1 else bool(ok_bad.all())
+    lb = verdict_and(int(local_bad_found))
+    if rank != 0:
+        if comm is not None:
+            comm.close()
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     cpu = None
-    if not args.no_cpu_baseline and os.path.exists(ORACLE_LIB):
+    if not args.no_cpu_baseline and os.path.exists(ORACLE_LIB) and world == 1:
         ref = ctypes.CDLL(ORACLE_LIB)
         p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
         c32 = bytes(range(1, 33))
@@ -557,14 +807,23 @@ def mode_verify(args):
         t1 = time.perf_counter() - t0
         cpu = {"value": m / t1, "unit": "commitments/s", "cores": 1, "kind": "port", "sample": "one m=%d proof, tuned, single thread: %.2f s; verdict %d" % (m, t1, okc)}
     ab = proofs.shape[1] + m * 32
-    print(json.dumps({"metric": "verification-only throughput, aggregated Bulletproofs (m=%d), commitments/s" % m, "value": B * m / dt,
-                      "unit": "commitments/s", "n_gpus": 1, "steps": steps, "ms_per_step": dt * 1e3, "higher_is_better": True, "data": "synthetic",
+    print(json.dumps({"metric": "verification-only throughput, aggregated Bulletproofs (m=%d), commitments/s" % m, "value": B_total * m / dt,
+                      "unit": "commitments/s", "n_gpus": world, "steps": steps, "warmup": max(1, args.warmup), "ms_per_step": dt * 1e3,
+                      "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "data": "synthetic",
                       "dtype": "int32 limbs (255-bit modular integers)",
-                      "config": {"workload": "%d proofs x m=%d x n=64 (proof %d bytes), host-inclusive" % (B, m, proofs.shape[1])},
-                      "all_verified": bool(ok.all()), "one_bad_proof_found": bool(ok_bad[B // 3] == 0 and ok_bad.sum() == B - 1),
+                      "config": {"workload": "%d proofs x m=%d x n=64 (proof %d bytes) in total, %d per GPU, host-inclusive, replicas of the verifier"
+                                             % (B_total, m, proofs.shape[1], B),
+                                 "verdict_reduce": reduce_path, "rccl_ranks_in_library_communicator": comm_ranks, "reduce_fallback_reason": comm_err},
+                      "all_verified": bool(all_and == 1), "one_bad_proof_turns_the_job_verdict": bool(and_bad == 0 and lb == 1),
                       "roofline": {"bound": "hbm", "achieved": B * ab / 1e9 / dt, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                   "frac": B * ab / 1e9 / dt / PEAK_HBM_GBS, "traffic": None, "algorithmic_bytes_per_proof": ab},
+                                   "frac": B * ab / 1e9 / dt / PEAK_HBM_GBS, "traffic": None, "algorithmic_bytes_per_proof": ab,
+                                   "note": "per GPU: proof + commitment bytes of this rank's proofs / step time"},
                       "cpu_baseline": cpu}), flush=True)
+    if comm is not None:
+        comm.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def _plan(policy, n, agg):
@@ -665,11 +924,14 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--mode", choices=("prove", "build", "verify", "criterion"), default="prove")
-    ap.add_argument("--budget-s", type=float, default=450.0,
+    ap.add_argument("--budget-s", type=float, default=555.0,
                     help="wall budget of the whole process, counted from its start; the timed steps are clamped to fit (>= 3)")
     ap.add_argument("--cpu-budget-s", type=float, default=10.0, help="wall budget of the CPU-baseline leg")
-    ap.add_argument("--log2-entities", type=int, default=20, help="entities per GPU = 2^this (default: BASELINE configs[2])")
-    ap.add_argument("--log2-entities-total", type=int, default=None, help="fix the TOTAL entity count instead (strong scaling)")
+    ap.add_argument("--log2-entities", type=int, default=20,
+                    help="entities IN TOTAL = 2^this (default 20: BASELINE configs[2], the metric's workload at every N); per GPU with --weak")
+    ap.add_argument("--log2-entities-total", type=int, default=None, help="the same, spelled out (configs[3]: 22 with --gpus 8)")
+    ap.add_argument("--weak", action="store_true", help="N > 1: weak scaling, 2^--log2-entities per GPU (default: strong, the total is divided)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary legs (splitting policy, API layout, host buffers)")
     ap.add_argument("--height", type=int, default=32)
     ap.add_argument("--n-bits", type=int, default=64)
     ap.add_argument("--verify-proofs", type=int, default=1024)
@@ -678,6 +940,10 @@ def main():
     args = ap.parse_args()
     if args.steps < 1 or args.warmup < 0:
         raise SystemExit("--steps must be >= 1 and --warmup >= 0")
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and args.mode in ("prove", "verify"):
+        return spawn_ranks(args)                  # (never returns)
     if args.mode == "build":
         return mode_build(args)
     if args.mode == "verify":

@@ -23,7 +23,8 @@ class WorkloadStats(ctypes.Structure):
     _fields_ = [("tree_ms", ctypes.c_double), ("prove_ms", ctypes.c_double), ("msm_ms", ctypes.c_double),
                 ("msm_launches", ctypes.c_uint64), ("proofs", ctypes.c_uint64), ("proof_bytes", ctypes.c_uint64),
                 ("checksum", ctypes.c_uint64), ("root_C", ctypes.c_uint8 * 32), ("root_H", ctypes.c_uint8 * 32),
-                ("mat_ms", ctypes.c_double), ("mat_launches", ctypes.c_uint64), ("msm_kernels", ctypes.c_uint64), ("mat_kernels", ctypes.c_uint64)]
+                ("mat_ms", ctypes.c_double), ("mat_launches", ctypes.c_uint64), ("msm_kernels", ctypes.c_uint64), ("mat_kernels", ctypes.c_uint64),
+                ("msm_all_ms", ctypes.c_double)]
 
 
 _lib = None
@@ -276,6 +277,21 @@ class Context:
         vals = _u64([l[2] for l in liabilities])
         ib = _u8(np.frombuffer(iid, np.uint8)) if iid else np.zeros(1, np.uint8)
         eb = _u8(np.frombuffer(eid, np.uint8)) if eid else np.zeros(1, np.uint8)
+        sd = _u8(np.frombuffer(audit_seed, np.uint8)) if audit_seed else None
+        idx, v, order, by_e = np.zeros(n, np.uint64), np.zeros(n, np.uint64), np.zeros(n, np.uint32), np.zeros(n, np.uint64)
+        r = np.zeros((n, 32), np.uint8)
+        _chk(lib().dapol_build_leaf_nodes(self.h, digest, _ptr(sd), len(audit_seed), height, n, _ptr(ib), _ptr(ioff), _ptr(eb), _ptr(eoff),
+                                          _ptr(vals), _ptr(idx), _ptr(v), _ptr(r), _ptr(order), _ptr(by_e)))
+        return dict(leaf_idx=idx, v=v, r=r, order=order, idx_by_entity=by_e)
+
+    def build_leaf_nodes_packed(self, iid, ioff, eid, eoff, values, audit_seed, height, digest=DIGEST_BLAKE3):
+        """build_leaf_nodes over PACKED ids (the C ABI's own layout: id i = iid[ioff[i]:ioff[i + 1]]) -- what a caller with a
+        million liabilities hands over; same result dict as build_leaf_nodes."""
+        ioff, eoff = np.ascontiguousarray(ioff, np.uint32), np.ascontiguousarray(eoff, np.uint32)
+        n = ioff.shape[0] - 1
+        vals = _u64(values)
+        ib = _u8(np.frombuffer(bytes(iid), np.uint8)) if len(iid) else np.zeros(1, np.uint8)
+        eb = _u8(np.frombuffer(bytes(eid), np.uint8)) if len(eid) else np.zeros(1, np.uint8)
         sd = _u8(np.frombuffer(audit_seed, np.uint8)) if audit_seed else None
         idx, v, order, by_e = np.zeros(n, np.uint64), np.zeros(n, np.uint64), np.zeros(n, np.uint32), np.zeros(n, np.uint64)
         r = np.zeros((n, 32), np.uint8)

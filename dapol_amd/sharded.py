@@ -60,6 +60,34 @@ def top_levels(ctx, records, rank, merge=None):
     return (C[0].tobytes(), H[0].tobytes(), int(v[0]), r[0].tobytes()), upper
 
 
+def create_library_comm(ctx, rank, world, dist, torch, device, timeout_s=90.0):
+    """The RCCL communicator INSIDE libdapol_hip.so for ranks that already share a torch.distributed group: rank 0 draws the
+    128-byte id, a torch.distributed broadcast carries it, and every rank creates its end NON-BLOCKING with a deadline
+    (dapol_comm_create_timeout: ncclCommInitRankConfig(blocking = 0) polled with ncclCommGetAsyncError; a communicator that has
+    not come up by the deadline is aborted inside the call, not abandoned).  The ranks then AGREE on the outcome (all-reduce MIN)
+    before anybody tears anything down: if any rank failed, the ranks that did get a communicator abort it (ncclCommAbort --
+    never a destroy that would wait for a peer that is gone) and all of them get (None, None, reason).
+    Returns (comm or None, ncclCommCount or None, error text or None)."""
+    comm, ranks, err, ok = None, None, None, 1
+    try:
+        uid = capi.comm_unique_id() if rank == 0 else bytes(capi.COMM_ID_BYTES)
+        buf = torch.from_numpy(np.frombuffer(uid, np.uint8).copy()).to(device)
+        dist.broadcast(buf, src=0)
+        comm = capi.Comm(ctx, buf.cpu().numpy().tobytes(), rank, world, timeout_s=timeout_s)
+        ranks = comm.count()
+        if ranks != world:
+            raise capi.DapolError(10, "ncclCommCount says %d ranks, expected %d" % (ranks, world))
+    except Exception as e:
+        err, ok = repr(e), 0
+    flag = torch.tensor([ok], dtype=torch.int64, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 1:
+        return comm, ranks, None
+    if comm is not None:
+        comm.abort()
+    return None, None, err or "another rank could not create its communicator"
+
+
 class ShardedProver:
     """bench.py's step: build this rank's subtree, exchange roots, prove this rank's entities."""
 
@@ -84,35 +112,12 @@ class ShardedProver:
                 self._create_comm()
 
     def _create_comm(self, timeout_s=90.0):
-        """RCCL communicator inside the library: rank 0 draws the id, torch.distributed carries it to the other ranks, and
-        every rank creates its end NON-BLOCKING with a deadline (dapol_comm_create_timeout: ncclCommInitRankConfig(blocking = 0)
-        polled with ncclCommGetAsyncError; a communicator that has not come up by the deadline is aborted inside the call, not
-        abandoned).  The ranks then AGREE on the outcome (all-reduce MIN) before anybody tears anything down: if any rank failed,
-        the ranks that did get a communicator abort it (ncclCommAbort -- never a destroy that would wait for a peer that is
-        gone) and every rank uses the torch.distributed transport; the line says which one ran."""
         import os
-        t, ok = self.torch, 1
         if os.environ.get("DAPOL_EXCHANGE", "").lower() == "torch":
             return
-        try:
-            uid = capi.comm_unique_id() if self.rank == 0 else bytes(capi.COMM_ID_BYTES)
-            buf = t.from_numpy(np.frombuffer(uid, np.uint8).copy()).to(self.comm_device)
-            self.dist.broadcast(buf, src=0)
-            self.comm = capi.Comm(self.ctx, buf.cpu().numpy().tobytes(), self.rank, self.world, timeout_s=timeout_s)
-            self.comm_ranks = self.comm.count()
-            if self.comm_ranks != self.world:
-                raise capi.DapolError(10, "ncclCommCount says %d ranks, expected %d" % (self.comm_ranks, self.world))
-        except Exception as e:
-            self.comm_error, ok = repr(e), 0
-        flag = t.tensor([ok], dtype=t.int64, device=self.comm_device)
-        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
-        if int(flag.item()) == 1:
+        self.comm, self.comm_ranks, self.comm_error = create_library_comm(self.ctx, self.rank, self.world, self.dist, self.torch, self.comm_device, timeout_s)
+        if self.comm is not None:
             self.exchange_path = "dapol_shard_exchange (ncclAllGather inside libdapol_hip.so)"
-        else:
-            if self.comm is not None:
-                self.comm.abort()
-            self.comm = None
-            self.comm_ranks = None
 
     def _exchange(self, root):
         if self.world == 1:

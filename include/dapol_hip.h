@@ -354,6 +354,8 @@ typedef struct {
      * of the dominant kernel inside those brackets (a generator-stationary MSM is a few hundred tile launches of k_rp_msm_gs). */
     double mat_ms;
     uint64_t mat_launches, msm_kernels, mat_kernels;
+    double msm_all_ms;      /* time with a bracket of either kind open (msm_ms / mat_ms / this are UNIONS of the bracket intervals:
+                             * two chunks are in flight on two streams and their brackets overlap) */
 } dapol_workload_stats;
 int32_t dapol_workload_run(dapol_workload* w, const uint8_t pad_seed32[32], const uint8_t nonce_seed32[32], int32_t n_bits,
                            size_t first_entity, size_t n_entities, dapol_workload_stats* stats);

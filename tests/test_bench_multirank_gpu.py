@@ -19,7 +19,7 @@ def test_bench_two_ranks_share_one_gpu(hip_lib):
         port = str(sk.getsockname()[1])
     env = dict(os.environ, DAPOL_BENCH_BACKEND="gloo", DAPOL_TABLE_GB="3", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
-           port, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log2-entities", "9", "--height", "16", "--steps", "2", "--warmup", "1"]
+           port, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log2-entities", "9", "--weak", "--height", "16", "--steps", "2", "--warmup", "1"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
@@ -28,9 +28,46 @@ def test_bench_two_ranks_share_one_gpu(hip_lib):
     assert line["parity"]["bit_exact"] and line["parity"]["proofs_compared"] > 0
     assert line["parity"]["inclusion_proofs_verified_on_gpu"] == line["parity"]["inclusion_proofs_checked"] == 512
     # the same 1,024 entities on one rank give the same aggregate checksum (the reduce of the per-rank transcripts)
-    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--log2-entities", "10", "--height", "16", "--no-cpu-baseline"], cwd=ROOT,
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--log2-entities", "10", "--height", "16", "--no-cpu-baseline", "--no-secondary"], cwd=ROOT,
                          env=dict(os.environ, DAPOL_TABLE_GB="3"), capture_output=True, text=True, timeout=900)
     assert one.returncode == 0, one.stderr[-2000:]
     single = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
     assert single["parity"]["inclusion_proofs_verified_on_gpu"] == single["parity"]["inclusion_proofs_checked"]
-    print("checksums", line["checksum"], single["checksum"])
+    print("checksums", line["checksum"], single["checksum"])      # (each rank's sum also folds in ITS subtree root: not comparable bit for bit)
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_without_a_launcher_spawns_its_ranks(hip_lib):
+    """`python3 bench.py --gpus 2` with no launcher (WORLD_SIZE unset) must not be a SystemExit: the parent --
+    which has not touched the GPU -- starts the two ranks under torch.distributed.run itself and relays rank 0's line.  N > 1
+    defaults to the metric's configuration: STRONG scaling, --log2-entities names the TOTAL."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(DAPOL_BENCH_BACKEND="gloo", DAPOL_TABLE_GB="3")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log2-entities", "10", "--height", "16", "--steps", "2", "--warmup", "1"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                           # ONE JSON line on stdout, everything else went to stderr
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["steps"] == 2
+    assert line["config"]["entities_total"] == 1024 and line["config"]["entities_per_gpu"] == 512
+    assert "strong scaling" in line["config"]["workload"] and "gloo" in line["config"]["exchange"]
+    assert line["parity"]["bit_exact"] and line["parity"]["inclusion_proofs_verified_on_gpu"] == line["parity"]["inclusion_proofs_checked"]
+    assert line["secondary"] is None and line["cpu_baseline"] is None       # N = 1 legs
+
+
+@pytest.mark.gpu
+def test_bench_verify_mode_two_ranks(hip_lib):
+    """BASELINE configs[4] on N > 1 GPUs: replicas of the verifier, the proofs divided over the ranks, the verdicts AND-ed by an
+    all-reduce MIN inside the timed region (gloo here: two ranks share the one GPU; RCCL's path is the same call with one rank in
+    test_rccl_exchange_one_rank_and_top_levels)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(DAPOL_BENCH_BACKEND="gloo", DAPOL_TABLE_GB="3")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "verify", "--gpus", "2", "--verify-proofs", "16", "--verify-parties", "32", "--steps", "5",
+           "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["unit"] == "commitments/s"
+    assert line["all_verified"] and line["one_bad_proof_turns_the_job_verdict"]
+    assert "8 per GPU" in line["config"]["workload"] and "MIN" in line["config"]["verdict_reduce"]

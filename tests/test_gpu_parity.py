@@ -633,6 +633,70 @@ def test_leaf_derivation_vs_oracle_with_collisions(gpu_ctx, hip_lib, pyref, heig
         assert int(out["v"][p]) == nd.v and out["r"][p].tobytes() == nd.r.to_bytes(32, "little")
 
 
+def test_leaf_derivation_near_the_sparsity_bound(gpu_ctx, hip_lib):
+    """the densest tree Dapol::new accepts (2^height = 2 n: height 16, 32,768 liabilities -- about 11,600
+    first-choice collisions, retried in input order) against an independent restatement of build_leaf_nodes' index rule
+    (src/dapol/mod.rs:341-441) on hashlib's Blake2s: every index, in entity order and in sorted order, and every blinding."""
+    import hashlib
+    height, n = 16, 1 << 15
+    seed = b"sparsity bound"
+    ids = [b"id-%08d" % i for i in range(n)]
+    eids = [b"ext-%d" % (i * 7) for i in range(n)]
+    dg = lambda *parts: hashlib.blake2s(b"".join(parts)).digest()
+    taken, want_idx, want_r, retried = set(), [], [], 0
+    for iid, eid in zip(ids, eids):
+        audit_id = dg(seed, iid)
+        s = dg(audit_id, b"index_seed", eid)
+        for attempt in range(1 << 20):
+            s = dg(s)
+            idx = int.from_bytes(s[:8], "big") >> (64 - height)
+            if idx not in taken:
+                taken.add(idx)
+                break
+            retried += 1
+        want_idx.append(idx)
+        want_r.append(int.from_bytes(dg(audit_id, b"blind_seed", eid), "little") & (2**255 - 1))
+    assert retried > 5000, "the case must exercise collision resolution"
+    vals = np.arange(n, dtype=np.uint64) + 1
+    out = gpu_ctx.build_leaf_nodes(list(zip(ids, eids, [int(x) for x in vals])), seed, height, hip_lib.DIGEST_BLAKE2S)
+    assert [int(x) for x in out["idx_by_entity"]] == want_idx
+    order = np.argsort(np.array(want_idx, np.uint64), kind="stable")
+    assert np.array_equal(out["leaf_idx"], np.array(want_idx, np.uint64)[order]) and np.array_equal(out["order"], order.astype(np.uint32))
+    assert np.array_equal(out["v"], vals[order])
+    for p in range(0, n, 97):
+        assert out["r"][p].tobytes() == want_r[int(order[p])].to_bytes(32, "little")
+
+
+def test_leaf_derivation_at_2e20(gpu_ctx, hip_lib, pyref):
+    """dapol_build_leaf_nodes at the headline size (2^20 ids `id-%08d`, BLAKE3, height 32): every index below
+    2^32 and distinct, the sorted view a permutation of the entity view, values carried; 64 sampled entities' blindings and
+    first-choice indexes equal the Python restatement's (at 2^20 in 2^32 slots a collision is rare: an index that differs from
+    the first choice must be one whose first choice is taken by an EARLIER entity); the tree over them sums the liabilities."""
+    n, height, seed = 1 << 20, 32, b"bench-audit-seed"
+    ids = np.char.add("id-", np.char.zfill(np.arange(n).astype("U8"), 8)).astype("S11")
+    off = (np.arange(n + 1, dtype=np.uint64) * 11).astype(np.uint32)
+    vals = np.random.default_rng(4).integers(0, 1 << 32, size=n, dtype=np.uint64)
+    out = gpu_ctx.build_leaf_nodes_packed(ids.tobytes(), off, ids.tobytes(), off, vals, seed, height)
+    li, be = out["leaf_idx"], out["idx_by_entity"]
+    assert li.max() < (1 << height) and np.all(li[1:] > li[:-1])                     # sorted, distinct
+    assert np.array_equal(np.sort(be), li) and np.array_equal(be[out["order"]], li) and np.array_equal(out["v"], vals[out["order"]])
+    pos_of = np.empty(n, np.int64)
+    pos_of[out["order"]] = np.arange(n)
+    moved = 0
+    for e in list(range(0, n, n // 60)) + [n - 1]:
+        iid = bytes(ids[e])
+        audit_id = pyref.digest("blake3", seed, iid)
+        first = pyref.shuffle_index(pyref.digest("blake3", audit_id, b"index_seed", iid), height, set(), "blake3")
+        r_want = pyref.scalar_from_bits(pyref.digest("blake3", audit_id, b"blind_seed", iid)).to_bytes(32, "little")
+        assert out["r"][pos_of[e]].tobytes() == r_want
+        if int(be[e]) != first:
+            moved += 1
+            assert first in set(int(x) for x in be[:e][be[:e] == first])             # its first choice went to an earlier entity
+    assert moved <= 2
+    tr = hip_lib.Tree(gpu_ctx, height, li, out["v"], out["r"], SEED)
+    assert tr.root()[2] == int(vals.sum())
+
+
 def test_leaf_derivation_errors(gpu_ctx, hip_lib):
     E = hip_lib.DapolError
     with pytest.raises(E) as e:
@@ -1201,6 +1265,57 @@ def test_dapol_proof_serialization_round_trip(gpu_ctx, hip_lib, pyref):
 
 
 @pytest.mark.gpu
+def test_structurally_inconsistent_wires_are_rejected(gpu_ctx, hip_lib):
+    """a wire whose pieces do not fit each other must never reach the verifier's kernels, which size their reads
+    from (height, policy, aggregation factor) alone.  (a) a single-leaf wire that claims more siblings than its aggregated proof
+    has parties for -- h = S = 32 with the 480-byte proof of ONE 8-bit party where the padding policy needs the 32-party one;
+    (b) a single-leaf wire with fewer siblings than levels; (c) an aggregated proof of the wrong size under the splitting policy.
+    All three: ValueDecodingError (7) from dapol_proof_deserialize.  And the verifier entry points themselves, handed arrays of
+    the wrong length (as a binding that skipped deserialize might), answer 'invalid' without reading past them."""
+    n_bits = 8
+    rng = np.random.default_rng(8)
+    idx, v, r = _rand_leaves(rng, 8, 20, vmax=12)
+    tree = hip_lib.Tree(gpu_ctx, 8, idx, v, r, SEED)
+    rC, rH, _, _ = tree.root()
+    lC, lH = gpu_ctx.commit_hash_batch(v, r)
+    pC, pH, out = tree.prove_entities(idx[:1], hip_lib.POLICY_PADDING, 8, n_bits, SEED)
+    good = hip_lib.proof_serialize(8, idx[:1], pC[0], pH[0], hip_lib.POLICY_PADDING, 8, n_bits, out[0].tobytes())
+    assert gpu_ctx.proof_deserialize(hip_lib.POLICY_PADDING, n_bits, good)["height"] == 8
+    one = gpu_ctx.range_prove_batch(n_bits, 1, np.array([[5]], np.uint64), r[:1].reshape(1, 1, 32), nonce_seed=SEED,
+                                    stream_id=np.array([1], np.uint64))[0].tobytes()
+    assert len(one) == 480
+    C32, _ = gpu_ctx.commit_hash_batch(v, r)
+    be = lambda x, n: int(x).to_bytes(n, "big")
+
+    def wire(agg_proofs, n_ind, k, S, h, policy):
+        w = b""
+        if policy == hip_lib.POLICY_SPLITTING:
+            w += be(len(agg_proofs), 2)
+        for p in agg_proofs:
+            w += be(len(p), 8) + p
+        w += be(n_ind, 8) + b"".join(one for _ in range(n_ind))
+        w += be(k, 8) + be(S, 8) + be(h, 2) + b"".join(bytes((h + 7) // 8) for _ in range(k))
+        return w + b"".join(C32[i % 20].tobytes() + lH[i % 20].tobytes() for i in range(S))
+
+    for bad, pol in ((wire([one], 0, 1, 32, 32, hip_lib.POLICY_PADDING), hip_lib.POLICY_PADDING),       # (a)
+                     (wire([one], 3, 1, 4, 8, hip_lib.POLICY_PADDING), hip_lib.POLICY_PADDING),         # (b) S = 4 < h = 8
+                     (wire([one, one], 0, 1, 3, 3, hip_lib.POLICY_SPLITTING), hip_lib.POLICY_SPLITTING)):   # (c) 3 = 2 + 1: the first must hold 2 parties
+        with pytest.raises(hip_lib.DapolError) as e:
+            gpu_ctx.proof_deserialize(pol, n_bits, bad)
+        assert e.value.code == 7, e.value
+    # the verifier with arrays that do not fit its arguments: invalid, not an over-read
+    ok = gpu_ctx.verify_entities(32, idx[:1], lC[:1], lH[:1], np.tile(C32[:1], (32, 1))[None], np.tile(lH[:1], (32, 1))[None], rC, rH,
+                                 hip_lib.POLICY_PADDING, 32, n_bits, np.frombuffer(one, np.uint8)[None])
+    assert ok.tolist() == [0]
+    ok = gpu_ctx.verify_entities(8, idx[:1], lC[:1], lH[:1], pC[:, :5], pH[:, :5], rC, rH, hip_lib.POLICY_PADDING, 8, n_bits, out)
+    assert ok.tolist() == [0]
+    assert gpu_ctx.verify_entities(8, idx[:1], lC[:1], lH[:1], pC, pH, rC, rH, hip_lib.POLICY_PADDING, 8, n_bits, out).tolist() == [1]
+    level, index, sC, sH, blob = tree.prove_batch(idx[:4], hip_lib.POLICY_PADDING, 2, n_bits, SEED)
+    assert gpu_ctx.verify_batch(8, idx[:4], lC[:4], lH[:4], sC, sH, rC, rH, hip_lib.POLICY_PADDING, 2, n_bits, blob)
+    assert not gpu_ctx.verify_batch(8, idx[:4], lC[:4], lH[:4], sC, sH, rC, rH, hip_lib.POLICY_PADDING, 2, n_bits, blob[:-32])
+
+
+@pytest.mark.gpu
 def test_sibling_order_switch(gpu_ctx, hip_lib, ref):
     """dapol_wire_config.siblings_leaf_first (smtree's sibling order is not pinned by the reference repository): with the
     switch on, paths come leaf side first, the range proof's parties follow that order (bytes = the C oracle's proof over the
@@ -1316,6 +1431,56 @@ def test_config3_eight_shards_height32_64bit(gpu_ctx, hip_lib):
         a = w.paths(probe, upper=upper, with_nodes=True)
         b = full.paths(probe, with_nodes=True)
         assert all(x.tobytes() == y.tobytes() for x, y in zip(a, b))
+
+
+@pytest.mark.gpu
+def test_config3_full_size_2e22_entities_eight_shards(gpu_ctx, hip_lib):
+    """BASELINE configs[3] at its FULL size -- 2^22 entities, height 32, 64-bit proofs, 8 top-level shards -- with the 8 shards run
+    one after the other on the one GPU a test box has (the multi-GPU run differs only in where each shard lives and in the
+    transport of the 8 x 104-byte root records).  Properties: the global root rebuilt from the 8 subtree roots equals the
+    unsharded build's root and carries the sum of the liabilities; the per-shard proof checksums add up to the unsharded run's
+    checksum (2^19 entities per shard is a multiple of the checksum's period, so it is additive here); 512 sampled inclusion
+    proofs out of the shards verify against the global root.  No CPU leg at this size."""
+    import bench
+    from dapol_amd import sharded
+    height, n_bits, n, sb = 32, 64, 1 << 22, 3
+    G, per = 1 << sb, n >> sb
+    idx, v, r = bench.synth_inputs(n, height, 0, n)
+    full = hip_lib.Workload(gpu_ctx, height, idx, v, r)
+    froot, fst = full.build(bench.PAD_SEED)
+    assert froot[2] == int(v.sum())
+    fst = full.prove(bench.NONCE_SEED, n_bits, stats=fst)
+    assert fst.proofs == n
+    full_checksum = int(fst.checksum)
+    del full
+    shards, recs = [], []
+    for g in range(G):
+        sl = slice(g * per, (g + 1) * per)
+        assert int(idx[sl][0] >> (height - sb)) == g and int(idx[sl][-1] >> (height - sb)) == g
+        w = hip_lib.Workload(gpu_ctx, height, idx[sl], v[sl], r[sl], shard_bits=sb)
+        root, st = w.build(bench.PAD_SEED)
+        shards.append((w, st))
+        recs.append(sharded.pack_record(root))
+    records = sharded.unpack_records(np.stack(recs), G)
+    total, ok_all, checked = 0, 0, 0
+    rng = np.random.default_rng(22)
+    for g, (w, st) in enumerate(shards):
+        groot, upper = sharded.top_levels(gpu_ctx, records, g)
+        assert groot == froot                                         # every shard rebuilds the same global root
+        st = w.prove(bench.NONCE_SEED, n_bits, upper=upper, stats=st)
+        total = (total + int(st.checksum)) & 0xFFFFFFFFFFFFFFFF
+        sl = slice(g * per, (g + 1) * per)
+        pos = np.sort(rng.choice(per, size=64, replace=False))
+        sample = idx[sl][pos]
+        _, _, sC, sH = w.paths(sample, upper=upper, with_nodes=True)
+        got = np.stack([w.proofs(int(p), 1, 992)[0] for p in pos])
+        lC, lH = gpu_ctx.commit_hash_batch(v[sl][pos], r[sl][pos])
+        ok = gpu_ctx.verify_entities(height, sample, lC, lH, sC, sH, froot[0], froot[1], hip_lib.POLICY_PADDING, height, n_bits, got)
+        ok_all += int(ok.sum())
+        checked += len(ok)
+        w.close()
+    assert total == full_checksum
+    assert ok_all == checked == 512
 
 
 @pytest.mark.gpu
