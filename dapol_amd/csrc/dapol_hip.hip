@@ -66,28 +66,7 @@ struct DevBuf {
 static inline unsigned nblk(size_t n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-// The assumptions about smtree 0.1.2 that nothing in the reference repository pins (include/dapol_hip.h, dapol_wire_config):
-// byte order and widths of the wire integers, path width, and the order of a proof's siblings.  One field each; the
-// defaults are the believed ones.  Set / read through dapol_wire_config_set / _get (host_wire.inc).
-// The stored configuration is process-wide and mutable (dapol_wire_config_set); a call must not see it change under its feet
-// (sizes computed in one pass, bytes written in the next; the sibling order between the prover's gather and its range proofs).
-// Every public entry point that depends on it therefore opens a WIRE_SCOPE(): the outermost scope of a thread copies the stored
-// configuration under the mutex into a thread-local snapshot, and everything below reads the snapshot (`g_wire`).
-static dapol_wire_config g_wire_store = {1, 8, 8, 2, 0, 0};
-static std::mutex g_wire_mu;
-static thread_local dapol_wire_config t_wire = {1, 8, 8, 2, 0, 0};
-static thread_local int t_wire_depth = 0;
-struct WireScope {
-    WireScope() {
-        if (t_wire_depth++ == 0) {
-            std::lock_guard<std::mutex> g(g_wire_mu);
-            t_wire = g_wire_store;
-        }
-    }
-    ~WireScope() { --t_wire_depth; }
-};
-#define WIRE_SCOPE() WireScope wire_scope_
-#define g_wire t_wire
+#include "wire_scope.inc"
 
 // ------------------------------------------------------------------------------------------------ context
 struct dapol_ctx {
