@@ -685,13 +685,13 @@ def mode_build(args):
             ts.append(time.perf_counter() - t0)
         row = {"leaves_replaced": k, "incremental_ms": 1e3 * sorted(ts)[len(ts) // 2]}
         if k == 1:
-            os.environ["DAPOL_UPDATE_INCREMENTAL_MAX"] = "0"
+            ctx.set_options(capi.Options(update_incremental_max=-1))       # the rebuild every update took before round 3
             try:
                 t0 = time.perf_counter()
                 tree.update(idx[sel], nv, nr)
                 row["rebuild_ms"] = 1e3 * (time.perf_counter() - t0)
             finally:
-                os.environ.pop("DAPOL_UPDATE_INCREMENTAL_MAX", None)
+                ctx.set_options(capi.Options())
         update_rows.append(row)
         log("update k=%d: %.3f ms" % (k, row["incremental_ms"]))
     tree.close()

@@ -27,11 +27,31 @@ class WorkloadStats(ctypes.Structure):
                 ("msm_all_ms", ctypes.c_double)]
 
 
+class Options(ctypes.Structure):
+    """dapol_options (include/dapol_hip.h): zeros = the library's own choices."""
+    _fields_ = [("struct_size", ctypes.c_int32), ("window_bits", ctypes.c_int32), ("table_gb", ctypes.c_double), ("high_half_rows", ctypes.c_int32),
+                ("generator_stationary", ctypes.c_int32), ("gs_tile_rows", ctypes.c_int32), ("streams", ctypes.c_int32), ("chunk_proofs", ctypes.c_int64),
+                ("scratch_gb", ctypes.c_double), ("tail_length", ctypes.c_int32), ("small_call_max", ctypes.c_int32), ("verify_batch_min", ctypes.c_int32),
+                ("update_incremental_max", ctypes.c_int64)]
+
+    def __init__(self, **kw):
+        super().__init__()
+        self.struct_size = ctypes.sizeof(Options)
+        for k, v in kw.items():
+            if k not in dict(self._fields_):
+                raise TypeError("dapol_options has no field " + k)
+            setattr(self, k, v)
+
+
 _lib = None
 
 _P = ctypes.c_void_p
 _SIG = {
     "dapol_ctx_create": (ctypes.c_int32, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(_P)]),
+    "dapol_ctx_create_opts": (ctypes.c_int32, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(Options), ctypes.POINTER(_P)]),
+    "dapol_ctx_get_options": (ctypes.c_int32, [_P, ctypes.POINTER(Options)]),
+    "dapol_ctx_set_options": (ctypes.c_int32, [_P, ctypes.POINTER(Options)]),
+    "dapol_env_knobs": (ctypes.c_int32, [ctypes.c_int32]),
     "dapol_ctx_destroy": (ctypes.c_int32, [_P]),
     "dapol_ctx_generator": (ctypes.c_int32, [_P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P]),
     "dapol_strerror": (ctypes.c_char_p, [ctypes.c_int32]),
@@ -234,10 +254,13 @@ class Context:
         _chk(lib().dapol_proof_nodes_deserialize(self.h, n, _ptr(w), len(wire), _ptr(C), _ptr(H)))
         return C[:n], H[:n]
 
-    def __init__(self, device=0, max_parties=32, digest=DIGEST_BLAKE3):
-        """digest: the node hash D of Dapol<D, R> (DIGEST_BLAKE3 or DIGEST_BLAKE2S)."""
+    def __init__(self, device=0, max_parties=32, digest=DIGEST_BLAKE3, options=None):
+        """digest: the node hash D of Dapol<D, R> (DIGEST_BLAKE3 or DIGEST_BLAKE2S); options: an Options (dapol_options)."""
         self.h = _P()
-        _chk(lib().dapol_ctx_create(device, max_parties, digest, ctypes.byref(self.h)))
+        if options is None:
+            _chk(lib().dapol_ctx_create(device, max_parties, digest, ctypes.byref(self.h)))
+        else:
+            _chk(lib().dapol_ctx_create_opts(device, max_parties, digest, ctypes.byref(options), ctypes.byref(self.h)))
         self.max_parties = max_parties
 
     def close(self):
@@ -283,6 +306,14 @@ class Context:
         _chk(lib().dapol_build_leaf_nodes(self.h, digest, _ptr(sd), len(audit_seed), height, n, _ptr(ib), _ptr(ioff), _ptr(eb), _ptr(eoff),
                                           _ptr(vals), _ptr(idx), _ptr(v), _ptr(r), _ptr(order), _ptr(by_e)))
         return dict(leaf_idx=idx, v=v, r=r, order=order, idx_by_entity=by_e)
+
+    def get_options(self):
+        o = Options()
+        _chk(lib().dapol_ctx_get_options(self.h, ctypes.byref(o)))
+        return o
+
+    def set_options(self, options):
+        _chk(lib().dapol_ctx_set_options(self.h, ctypes.byref(options)))
 
     def build_leaf_nodes_packed(self, iid, ioff, eid, eoff, values, audit_seed, height, digest=DIGEST_BLAKE3):
         """build_leaf_nodes over PACKED ids (the C ABI's own layout: id i = iid[ioff[i]:ioff[i + 1]]) -- what a caller with a

@@ -44,6 +44,24 @@ static int32_t fail(int32_t code, const char* msg) {
     } while (0)
 #define LAUNCH_CHECK() HIPCHK(hipGetLastError())
 
+// The DAPOL_* environment variables are measurement knobs (A/B switches of tools/ and tests/).  They are read only when the
+// process has opted in -- DAPOL_ENV_KNOBS set to anything but "0", or dapol_env_knobs(1) -- so that a host embedding the library
+// does not inherit behaviour from stray variables; what an embedder may want to set is a field of dapol_options.
+static std::atomic<int> g_env_knobs{-1};          // -1: ask the environment
+static const char* knob(const char* name) {
+    int on = g_env_knobs.load(std::memory_order_relaxed);
+    if (on < 0) {
+        const char* e = getenv("DAPOL_ENV_KNOBS");
+        on = (e && *e && strcmp(e, "0") != 0) ? 1 : 0;
+    }
+    return on ? getenv(name) : nullptr;
+}
+int32_t dapol_env_knobs(int32_t enable) {
+    int old = g_env_knobs.exchange(enable ? 1 : 0);
+    if (old < 0) { const char* e = getenv("DAPOL_ENV_KNOBS"); old = (e && *e && strcmp(e, "0") != 0) ? 1 : 0; }
+    return old;
+}
+
 template <typename T>
 struct DevBuf {
     T* p = nullptr;
@@ -73,6 +91,7 @@ struct dapol_ctx {
     // One reference for the caller's handle plus one per tree / workload built on the context: dapol_ctx_destroy only
     // drops the caller's, so handles may be destroyed in any order (garbage-collected language bindings do exactly that).
     std::atomic<int> refs{1};
+    dapol_options opt{};                                 // zeros = the library's own choices (dapol_ctx_set_options)
     int device = 0;
     int max_parties = 0;
     int n_cu = 256;                                      // hipDeviceProp_t::multiProcessorCount (MI355X: 256)
@@ -110,9 +129,39 @@ const char* dapol_strerror(int32_t code) {
 }
 const char* dapol_last_error(void) { return g_last_error.c_str(); }
 
+static bool options_ok(const dapol_options* o) {
+    if (!o) return true;
+    if (o->struct_size != 0 && o->struct_size != (int32_t)sizeof(dapol_options)) return false;
+    if (o->window_bits && (o->window_bits < WBITS_MIN || o->window_bits > WBITS_MAX)) return false;
+    if (o->gs_tile_rows && (o->gs_tile_rows < 4 || o->gs_tile_rows % 4)) return false;
+    if (o->streams < 0 || o->streams > 4 || o->chunk_proofs < 0 || o->table_gb < 0 || o->scratch_gb < 0) return false;
+    if (o->tail_length && o->tail_length != -1 && o->tail_length != 32 && o->tail_length != 64 && o->tail_length != 128 && o->tail_length != 256) return false;
+    if (o->small_call_max < 0 || o->verify_batch_min < 0 || o->update_incremental_max < -1) return false;
+    return true;
+}
 int32_t dapol_ctx_create(int32_t device, int32_t max_parties, int32_t digest_id, dapol_ctx** out) {
+    return dapol_ctx_create_opts(device, max_parties, digest_id, nullptr, out);
+}
+int32_t dapol_ctx_get_options(dapol_ctx* ctx, dapol_options* out) {
+    if (!ctx || !out) return fail(DAPOL_ERR_INVALID_ARGUMENT, "null argument");
+    *out = ctx->opt;
+    out->struct_size = (int32_t)sizeof(dapol_options);
+    out->window_bits = ctx->tv.wbits;
+    out->high_half_rows = ctx->tv.hi_split ? 1 : -1;
+    return DAPOL_OK;
+}
+int32_t dapol_ctx_set_options(dapol_ctx* ctx, const dapol_options* o) {
+    if (!ctx || !o) return fail(DAPOL_ERR_INVALID_ARGUMENT, "null argument");
+    if (!options_ok(o)) return fail(DAPOL_ERR_INVALID_ARGUMENT, "bad dapol_options (struct_size, or a field out of range)");
+    const dapol_options keep = ctx->opt;
+    ctx->opt = *o;
+    ctx->opt.window_bits = keep.window_bits; ctx->opt.table_gb = keep.table_gb; ctx->opt.high_half_rows = keep.high_half_rows;    // fixed at creation
+    return DAPOL_OK;
+}
+int32_t dapol_ctx_create_opts(int32_t device, int32_t max_parties, int32_t digest_id, const dapol_options* options, dapol_ctx** out) {
     if (!out) return fail(DAPOL_ERR_INVALID_ARGUMENT, "out is null");
     *out = nullptr;
+    if (!options_ok(options)) return fail(DAPOL_ERR_INVALID_ARGUMENT, "bad dapol_options (struct_size, or a field out of range)");
     if (digest_id != DAPOL_DIGEST_BLAKE3 && digest_id != DAPOL_DIGEST_BLAKE2S)
         return fail(DAPOL_ERR_INVALID_DIGEST_SIZE, "node digest must be BLAKE3 or Blake2s-256 (32-byte output, DapolError::InvalidDigestSize)");
     if (max_parties < 1 || max_parties > 1024 || (max_parties & (max_parties - 1)))
@@ -122,6 +171,7 @@ int32_t dapol_ctx_create(int32_t device, int32_t max_parties, int32_t digest_id,
         return fail(DAPOL_ERR_NO_DEVICE, "no usable HIP device");
     HIPCHK(hipSetDevice(device));
     dapol_ctx* c = new dapol_ctx();
+    if (options) c->opt = *options;
     c->device = device;
     c->max_parties = max_parties;
     {
@@ -131,7 +181,7 @@ int32_t dapol_ctx_create(int32_t device, int32_t max_parties, int32_t digest_id,
         // Residency of the dominant kernel (one wavefront per block): what its registers and LDS allow -- asked of the runtime,
         // not assumed.  DAPOL_MSM_OCC_CAP=<waves per SIMD> lowers it by padding the launch's LDS (A/B knob: at the socket power
         // cap more resident wavefronts are not automatically faster, profiles/r01_madchain_ab.txt).
-        if (const char* e = getenv("DAPOL_MSM_OCC_CAP")) {
+        if (const char* e = knob("DAPOL_MSM_OCC_CAP")) {
             int cap = atoi(e);
             const size_t lds_cu = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : 163840, stat = 0;   // (the kernel itself uses no LDS)
             if (cap >= 1 && cap <= 8) {
@@ -157,16 +207,18 @@ int32_t dapol_ctx_create(int32_t device, int32_t max_parties, int32_t digest_id,
     // the same GPU, or a smaller device, gets narrower windows instead of an allocation failure) -- or DAPOL_WBITS (up to 20)
     int wbits = WBITS_MIN;
     {
-        const char* eb = getenv("DAPOL_TABLE_GB");
+        const char* eb = knob("DAPOL_TABLE_GB");
         double budget = 40.0e9;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)free_b * 0.30 < budget) budget = (double)free_b * 0.30;
+        if (c->opt.table_gb > 0) budget = c->opt.table_gb * 1e9;
         if (eb) budget = atof(eb) * 1e9;
         for (int w = WBITS_MIN; w <= WBITS_AUTO_MAX; w++) {
             TableView t{nullptr, P, w, 0, 0};
             if ((double)t.n_rows() * (double)t.row_words() * 4.0 <= budget) wbits = w;
         }
-        const char* ew = getenv("DAPOL_WBITS");
+        const char* ew = knob("DAPOL_WBITS");
+        if (c->opt.window_bits) wbits = c->opt.window_bits;
         if (ew) {
             int w = atoi(ew);
             if (w < WBITS_MIN || w > WBITS_MAX) return fail(DAPOL_ERR_INVALID_ARGUMENT, "DAPOL_WBITS must be in [8, 20]");
@@ -182,7 +234,8 @@ int32_t dapol_ctx_create(int32_t device, int32_t max_parties, int32_t digest_id,
         size_t free_b = 0, total_b = 0;
         const double bytes2 = (double)(rows + 128 * P) * (double)tv.row_words() * 4.0;
         bool hi = P <= 64 && hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes2 <= 0.30 * (double)free_b;
-        if (const char* e = getenv("DAPOL_TABLE_HI")) hi = atoi(e) != 0;
+        if (c->opt.high_half_rows) hi = c->opt.high_half_rows > 0 && P <= 64;
+        if (const char* e = knob("DAPOL_TABLE_HI")) hi = atoi(e) != 0;
         if (hi) tv.hi_split = (tv.nwin_c() + 1) / 2;
     }
     const int rows_total = tv.n_rows_total();
@@ -365,7 +418,7 @@ static int32_t tree_build_device(dapol_ctx* ctx, int index_bits, int shard_bits,
     const uint32_t n32 = (uint32_t)n;
     HIPCHK(hipMemcpyAsync(cnt.p, &n32, 4, hipMemcpyHostToDevice, st));
     DevBuf<int32_t> ext_a, ext_b;
-    const bool phased = n <= (size_t)TREE_SMALL_MAX && height >= 1 && !getenv("DAPOL_TREE_LEVELWISE");
+    const bool phased = n <= (size_t)TREE_SMALL_MAX && height >= 1 && !knob("DAPOL_TREE_LEVELWISE");
     if (phased) {
         // Small trees, by phases (kernels_ctx_tree.h, "small trees"): structure, all padding nodes, point sums level by level, all
         // encodings, hashes level by level.  The extended points of every level are kept until the encodings are done.
@@ -567,7 +620,9 @@ int32_t dapol_tree_update(dapol_tree* tree, size_t k, const uint64_t* leaf_idx, 
     // in place on the device.  Anything else -- a new index, a big batch -- takes the rebuild below, which is bit for bit the same tree.
     {
         size_t inc_max = 65536;
-        if (const char* e = getenv("DAPOL_UPDATE_INCREMENTAL_MAX")) inc_max = (size_t)atoll(e);
+        if (ctx->opt.update_incremental_max > 0) inc_max = (size_t)ctx->opt.update_incremental_max;
+        if (ctx->opt.update_incremental_max < 0) inc_max = 0;
+        if (const char* e = knob("DAPOL_UPDATE_INCREMENTAL_MAX")) inc_max = (size_t)atoll(e);
         if (k <= inc_max && k <= tree->levels[0].n / 8 + 1 && tree->levels[0].n > 0) {
             std::vector<uint32_t> ord(k);
             for (size_t i = 0; i < k; i++) ord[i] = (uint32_t)i;

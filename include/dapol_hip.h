@@ -70,6 +70,32 @@ enum { DAPOL_DIGEST_BLAKE3 = 0, DAPOL_DIGEST_BLAKE2S = 1 };     /* D = blake3::H
  * digest_id: the node hash D of Dapol<D, R> used by every tree / merge / verify call of this context; anything but the
  * two 32-byte digests above -> DAPOL_ERR_INVALID_DIGEST_SIZE (DapolError::InvalidDigestSize, src/dapol/mod.rs:101-103). */
 int32_t dapol_ctx_create(int32_t device, int32_t max_parties, int32_t digest_id, dapol_ctx** out);
+/* Settings of a context.  Every field: 0 = the library's own choice (what a plain dapol_ctx_create gives).  The first three are
+ * fixed at creation (dapol_ctx_create_opts), the others may be changed at any time between calls (dapol_ctx_set_options).
+ * None of them changes a byte of any output (tests/test_gpu_parity.py::test_every_proving_strategy_gives_the_same_bytes); they
+ * trade memory against speed or pick among equivalent schedules.
+ * The DAPOL_* ENVIRONMENT variables the sources mention are measurement knobs: they are read ONLY when the process has opted in
+ * (DAPOL_ENV_KNOBS=1 in the environment, or dapol_env_knobs(1)) -- a host embedding this library does not inherit behaviour from
+ * stray variables.  When enabled, a variable overrides the corresponding field. */
+typedef struct {
+    int32_t struct_size;              /* = sizeof(dapol_options): lets the struct grow */
+    int32_t window_bits;              /* creation: width of the fixed-base windows, 8..20 (0: widest <= 17 whose tables fit table_gb) */
+    double  table_gb;                 /* creation: budget of the window tables in GB (0: 40 GB, at most 30 % of the free memory) */
+    int32_t high_half_rows;           /* creation: 0 auto, 1 on, -1 off: second table row per generator (halves the window steps of lanes that cannot share doublings) */
+    int32_t generator_stationary;     /* 0 auto (calls of >= one full chunk), 1 every call that is not a small one, -1 never */
+    int32_t gs_tile_rows;             /* rows per launch of the generator-stationary sweep (multiple of 4; 0: 16) */
+    int32_t streams;                  /* chunks in flight, 1..4 (0: 2) */
+    int64_t chunk_proofs;             /* proofs per chunk (0: whole rounds of resident wavefronts, 65,536 on MI355X) */
+    double  scratch_gb;               /* scratch budget of the range prover / verifier in GB (0: 130 GB, at most what is free beyond 8 GB) */
+    int32_t tail_length;              /* length T of the hybrid inner-product argument's tail: 32 / 64 / 128 / 256, -1 = no tail (0: 64) */
+    int32_t small_call_max;           /* calls of up to this many proofs take the latency shapes (0: 4,096) */
+    int32_t verify_batch_min;         /* fewest proofs the verifier checks as ONE random linear combination (0: 112) */
+    int64_t update_incremental_max;   /* dapol_tree_update: most replaced leaves re-merged in place (0: 65,536; -1: always rebuild) */
+} dapol_options;
+int32_t dapol_ctx_create_opts(int32_t device, int32_t max_parties, int32_t digest_id, const dapol_options* options, dapol_ctx** out);
+int32_t dapol_ctx_get_options(dapol_ctx* ctx, dapol_options* out);      /* the stored settings (zeros = defaults) + window_bits / high_half_rows as built */
+int32_t dapol_ctx_set_options(dapol_ctx* ctx, const dapol_options* options);   /* creation-time fields are ignored here */
+int32_t dapol_env_knobs(int32_t enable);                                 /* process-wide opt-in to the DAPOL_* measurement knobs; returns the old setting */
 /* Trees and workloads built on a context keep it alive: dapol_ctx_destroy releases the caller's handle, the storage goes
  * when the last tree / workload of the context is destroyed too -- handles may be destroyed in any order. */
 int32_t dapol_ctx_destroy(dapol_ctx* ctx);

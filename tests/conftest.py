@@ -10,6 +10,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# The library reads its DAPOL_* measurement knobs only in a process that has opted in (include/dapol_hip.h, dapol_options): the
+# tests do -- they drive every strategy through those knobs and compare bytes -- and so do the child processes they start.
+os.environ.setdefault("DAPOL_ENV_KNOBS", "1")
 
 
 def pytest_configure(config):

@@ -1131,6 +1131,47 @@ def test_every_proving_strategy_gives_the_same_bytes(gpu_ctx, n_bits, m):
         assert got == base, env
 
 
+def test_options_struct_and_env_knob_gate(hip_lib):
+    """VERDICT r2 hygiene: the settings an embedder may want are fields of dapol_options on the context (readable and settable
+    through the C ABI); the DAPOL_* environment variables are measurement knobs that the library reads ONLY when the process has
+    opted in (DAPOL_ENV_KNOBS / dapol_env_knobs).  Same bytes under every setting."""
+    import os
+    L = hip_lib.lib()
+    ctx = hip_lib.Context(0, 8, options=hip_lib.Options(window_bits=12, high_half_rows=-1, streams=1, tail_length=32))
+    o = ctx.get_options()
+    assert (o.window_bits, o.high_half_rows, o.streams, o.tail_length, o.struct_size) == (12, -1, 1, 32, __import__("ctypes").sizeof(hip_lib.Options))
+    dflt = hip_lib.Context(0, 8).get_options()
+    assert dflt.window_bits >= 12 and dflt.streams == 0
+    b, m, n_bits = 40, 8, 32
+    rng = np.random.default_rng(3)
+    v = rng.integers(0, 2**32, size=(b, m), dtype=np.uint64)
+    r = rng.integers(0, 256, size=(b, m, 32), dtype=np.uint8)
+    r[:, :, 31] &= 0x0F
+    sid = np.arange(b, dtype=np.uint64)
+    base = ctx.range_prove_batch(n_bits, m, v, r, nonce_seed=SEED, stream_id=sid).tobytes()
+    for opt in (hip_lib.Options(generator_stationary=1, small_call_max=1, gs_tile_rows=8), hip_lib.Options(tail_length=-1, chunk_proofs=7, streams=3),
+                hip_lib.Options(generator_stationary=-1, small_call_max=8), hip_lib.Options()):
+        ctx.set_options(opt)
+        assert ctx.range_prove_batch(n_bits, m, v, r, nonce_seed=SEED, stream_id=sid).tobytes() == base
+        got = ctx.get_options()
+        assert got.window_bits == 12 and got.gs_tile_rows == opt.gs_tile_rows and got.tail_length == opt.tail_length      # creation-time fields stay
+    with pytest.raises(hip_lib.DapolError):
+        ctx.set_options(hip_lib.Options(gs_tile_rows=6))
+    with pytest.raises(hip_lib.DapolError):
+        hip_lib.Context(0, 8, options=hip_lib.Options(window_bits=30))
+    # the gate: with the knobs off an absurd variable is not even read; with them on it is (and rejected)
+    old = L.dapol_env_knobs(0)
+    os.environ["DAPOL_WBITS"] = "99"
+    try:
+        hip_lib.Context(0, 8).close() if hasattr(hip_lib.Context, "close") else hip_lib.Context(0, 8)
+        L.dapol_env_knobs(1)
+        with pytest.raises(hip_lib.DapolError):
+            hip_lib.Context(0, 8)
+    finally:
+        os.environ.pop("DAPOL_WBITS", None)
+        L.dapol_env_knobs(old)
+
+
 # ------------------------------------------------------------------------------- soundness of the cross-proof batch check
 def _forged_cancelling_pair(pyref, seed):
     """Two 8-bit, one-party proofs that are each INVALID but whose residuals cancel in a random linear combination whose

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DAPOL_ENV_KNOBS=1     # the DAPOL_* knobs below are read only by a process that opts in
 # Interleaved A/B of environment settings on one box: tools/ab.sh <repeats> <log2_entities> "ENV1=.. ENV2=.." "ENV=.." ...
 # ("-" = defaults).  Prints one line per run: <config> <entities/s>.
 reps=$1; shift; lg=$1; shift

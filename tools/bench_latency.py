@@ -3,6 +3,7 @@
 height-32 tree, 64-bit padding-policy proofs.  Host-inclusive, median of 5.  Usage: python tools/bench_latency.py"""
 import json
 import os
+os.environ.setdefault("DAPOL_ENV_KNOBS", "1")     # the library reads its DAPOL_* knobs only in a process that opts in
 import sys
 import time
 

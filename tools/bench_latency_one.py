@@ -3,6 +3,7 @@
 one leaf of a 1,024-leaf, height-32 tree a few times and prints the best and median latency; run it under
 `rocprofv3 --kernel-trace` for tools/kernel_timeline.py.  The DAPOL_* knobs of host_range.inc / host_verify.inc apply."""
 import os
+os.environ.setdefault("DAPOL_ENV_KNOBS", "1")     # the library reads its DAPOL_* knobs only in a process that opts in
 import statistics
 import sys
 import time

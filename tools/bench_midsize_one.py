@@ -1,4 +1,5 @@
 import os, sys, time
+os.environ.setdefault("DAPOL_ENV_KNOBS", "1")     # the library reads its DAPOL_* knobs only in a process that opts in
 import numpy as np
 sys.path.insert(0, "/root/repo")
 from dapol_amd import capi

@@ -4,6 +4,7 @@ dapol_verify_entities (Merkle re-merge + padding-policy range verification) over
 Usage: python tools/bench_verify_entities.py [log2_entities]"""
 import json
 import os
+os.environ.setdefault("DAPOL_ENV_KNOBS", "1")     # the library reads its DAPOL_* knobs only in a process that opts in
 import sys
 import time
 

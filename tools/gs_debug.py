@@ -1,5 +1,6 @@
 """Bring-up check of the generator-stationary MSM: each forced-GS setting against the default path's bytes, progress flushed line by line."""
 import os, sys
+os.environ.setdefault("DAPOL_ENV_KNOBS", "1")     # the library reads its DAPOL_* knobs only in a process that opts in
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dapol_amd import capi

@@ -1,5 +1,6 @@
 """Bring-up: generator-stationary against proof-stationary bytes at growing batch sizes (n = 64, m = 32)."""
 import os, sys, hashlib
+os.environ.setdefault("DAPOL_ENV_KNOBS", "1")     # the library reads its DAPOL_* knobs only in a process that opts in
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dapol_amd import capi

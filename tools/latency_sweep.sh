@@ -1,4 +1,5 @@
 set -e
+export DAPOL_ENV_KNOBS=1     # the DAPOL_* knobs below are read only by a process that opts in
 cd /root/repo
 out=gpurun_out/r02x_latency_sweep.txt
 : > $out

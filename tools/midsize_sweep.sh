@@ -1,4 +1,5 @@
 #!/bin/bash
+export DAPOL_ENV_KNOBS=1     # the DAPOL_* knobs below are read only by a process that opts in
 # tools/midsize_sweep.sh: one prove_entities call of b proofs (tools/bench_midsize_one.py) under the lanes-per-list / small-call knobs
 cd "$(dirname "$0")/.."
 for b in ${BS:-128 256 512 1024 1536}; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DAPOL_ENV_KNOBS=1     # the DAPOL_* knobs below are read only by a process that opts in
 # The --pmc passes of profile_round.sh alone: tools/pmc_only.sh <tag>   (KERNEL, PMC_LG and DAPOL_* from the environment)
 set -o pipefail
 tag=${1:-r03}

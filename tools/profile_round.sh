@@ -1,4 +1,5 @@
 #!/bin/bash
+export DAPOL_ENV_KNOBS=1     # the DAPOL_* knobs below are read only by a process that opts in
 # One GPU call that refreshes the evidence under profiles/: tools/profile_round.sh <tag>   (run from the repo root on the GPU box)
 #   gpurun_out/<tag>_ubench_madd.txt      VALU-only cost of the point operations (the MSM's issue roof)
 #   gpurun_out/<tag>_bench.json           python bench.py (default workload, with the CPU baseline)

@@ -5,6 +5,7 @@ oracle/ref_dapol.c for the padding policy, verification of every proof (wavefron
 tampered copy that must fail.  usage: tools/soak_small_calls.py [cases] [seed]"""
 import ctypes
 import os
+os.environ.setdefault("DAPOL_ENV_KNOBS", "1")     # the library reads its DAPOL_* knobs only in a process that opts in
 import sys
 
 import numpy as np

@@ -2,6 +2,7 @@
 """Verification latency of b inclusion proofs in one call (height 32, 64-bit, padding policy), median of 7, under the knobs given in
 the environment.  usage: tools/verify_small_sweep.py b [b ...]"""
 import os
+os.environ.setdefault("DAPOL_ENV_KNOBS", "1")     # the library reads its DAPOL_* knobs only in a process that opts in
 import sys
 import time
 

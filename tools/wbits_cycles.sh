@@ -1,4 +1,5 @@
 #!/bin/bash
+export DAPOL_ENV_KNOBS=1     # the DAPOL_* knobs below are read only by a process that opts in
 # Cycles per table addition at different window widths (is the gap to the VALU-only cost caused by the HBM gathers?):
 # rocprofv3 kernel stats of one chunk at a time + rocm-smi clock samples.   tools/wbits_cycles.sh <W> [<W> ...]
 R=$(pwd); OUT=$R/gpurun_out; export TMPDIR=/tmp; export DAPOL_STREAMS=1
