@@ -243,11 +243,14 @@ __global__ __launch_bounds__(64) void k_rp_A(RangeArgs A, TableView tbl) {
     if (l == 0) st_p3(A.PA + b * 40, acc);
 }
 
-// ------------------------------------------------------------------- K2: the fixed-base MSM (dominant kernel)
-// One wavefront per proof.  Lane l owns the terms at positions 64*i + l of the digit rows (N/32 terms), walks
-// the nwin signed W-bit windows from the top with W shared doublings per window (Straus), and looks every
-// digit up in the generator's row (one 128-byte cache line per lookup, L2 / Infinity-Cache resident).
-// Lanes 0-31 accumulate list 0, lanes 32-63 list 1; two 32-lane LDS tree reductions give P0 and P1.
+// ------------------------------------------------------------------- K2: the fixed-base MSM, proof-stationary form
+// A list (L or R of one proof) is owned by LPL lanes; a lane walks the nwin signed W-bit windows from the top with W shared
+// doublings per window (Straus) and, per window, its terms of the list: digit -> one 128-byte entry of the generator's table row
+// (a random HBM line: the rows of a 17-bit table are 8.4 MB each, 35 GB in all) -> one mixed addition.  The lanes' partial sums
+// meet in a shuffle reduction (wave_reduce_point: no LDS, no barrier).  This is the form of calls BELOW one full chunk -- mid-size
+// and small calls, the tail argument over a proof's own tables, the verifier's generator MSM; calls of at least one full chunk run
+// the plain rounds and the materialisation generator-stationary instead (kernels_range_gs.h), which reads the same table rows
+// out of the Infinity Cache.
 #ifndef DAPOL_MSM_OCC
 #define DAPOL_MSM_OCC 3          // resident wavefronts per SIMD the register allocation is bounded for
 #endif
