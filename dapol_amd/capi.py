@@ -24,7 +24,7 @@ class WorkloadStats(ctypes.Structure):
                 ("msm_launches", ctypes.c_uint64), ("proofs", ctypes.c_uint64), ("proof_bytes", ctypes.c_uint64),
                 ("checksum", ctypes.c_uint64), ("root_C", ctypes.c_uint8 * 32), ("root_H", ctypes.c_uint8 * 32),
                 ("mat_ms", ctypes.c_double), ("mat_launches", ctypes.c_uint64), ("msm_kernels", ctypes.c_uint64), ("mat_kernels", ctypes.c_uint64),
-                ("msm_all_ms", ctypes.c_double)]
+                ("msm_all_ms", ctypes.c_double), ("msm_span_ms", ctypes.c_double)]
 
 
 class Options(ctypes.Structure):

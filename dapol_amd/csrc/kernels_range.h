@@ -40,6 +40,12 @@ struct RangeArgs {
     const uint32_t* tape;       // [B][m(2n+4)][16] or null
     // scratch
     sc* a; sc* b; sc* s1; sc* s2;       // [B][N] each
+    // Coefficient TABLES (null: the s-vectors themselves are folded every round, as before round 3).  The coefficient of
+    // generator j after k rounds depends only on the top k bits of j: s_G[j] = TG_k[j >> (lgN - k)], s_H[j] = y^-j * TH_k[...]
+    // (the products of u_t^{+-1} the verifier calls s).  So the two N-entry vectors need not be rewritten every round: a proof
+    // keeps 2^k-entry tables (k <= STAB_ROUNDS), extended by k_rp_fold, and s2 stays the constant y^-j.  Layout:
+    // stab[b][buffer k & 1][side][STAB_N]; TG entries in plain form, TH entries in Montgomery form.
+    sc* stab;
     dig_t* dig;                         // [B][nwin][TP] signed radix-2^wbits digits
     int nsplit;                         // MSM term-range splits per proof (0/1 = none); partial points at [b * nsplit + s]
     int use_hi;                         // small calls: the main MSM also walks only TableView::hi_split window steps (two lookups per term)
@@ -47,6 +53,7 @@ struct RangeArgs {
     sc* fs_part;                        // [B][fs_parts][3]: t1, t2 (k_rp_poly), t_x (k_rp_lr) of each wavefront's share of the positions
     ProofState* st;                     // [B]
     int32_t* PA; int32_t* P0; int32_t* P1;   // [B][40] partial points
+    int mat_round;                      // rounds folded before the materialisation (= never-fold rounds of the main argument)
     int tail_n;                         // T = length of the tail argument (32 / 64 / 128): 2T generators are materialised
     int32_t* tailT;                     // [B][2T][TAIL_ENTRIES][32]  per-proof window tables of the materialised folded generators
     sc* tail_a; sc* tail_b; sc* tail_s1; sc* tail_s2;   // [B][T] each: the vectors / coefficients of the tail argument
@@ -63,6 +70,7 @@ struct RangeArgs {
 #endif
 enum { TAIL_WBITS = DAPOL_TAIL_WBITS, TAIL_NWIN = 253 / TAIL_WBITS + 1, TAIL_ENTRIES = (1 << (TAIL_WBITS - 1)) + 1, TAIL_ROW_WORDS = TAIL_ENTRIES * 32 };
 enum { MSM_PLAIN = 0, MSM_MATERIALIZE = 1, MSM_TAIL = 2 };
+enum { STAB_ROUNDS = 6, STAB_N = 1 << STAB_ROUNDS };      // coefficient tables serve arguments that need at most TG_6 (64 entries)
 
 __device__ __forceinline__ void tape_wide(uint32_t* w16, const RangeArgs& A, size_t b, uint32_t slot) {
     if (A.tape) {
@@ -139,6 +147,47 @@ __device__ __forceinline__ void write_digits(const RangeArgs& A, size_t b, int p
 __device__ __forceinline__ void zero_digits(const RangeArgs& A, size_t b, int pos) {
     dig_t* d = A.dig + (size_t)b * A.nwin * A.TP + pos;
     for (int i = 0; i < A.nwin; i++) d[(size_t)i * A.TP] = 0;
+}
+
+// Coefficient of generator j (G side: isH = false) of proof b in round `round`, times the Montgomery-form vector entry v:
+// the canonical product the MSM's digits are made of.  Table mode or vector mode (RangeArgs::stab).
+__device__ __forceinline__ void coeff_times(sc& p, const RangeArgs& A, size_t b, int round, int j, bool isH, const sc& v) {
+    if (A.stab) {
+        const sc* T = A.stab + ((b * 2 + (size_t)(round & 1)) * 2 + (isH ? 1 : 0)) * STAB_N + (round ? (j >> (A.lgN - round)) : 0);
+        sc t;
+        ld_sc(t, T);
+        if (isH) {
+            sc yi, q;
+            ld_sc(yi, A.s2 + b * A.N + j);            // y^-j, plain (k_rp_lr); ones in the tail argument
+            sc_montmul(q, v, yi);                      // Montgomery x plain = plain v y^-j
+            sc_montmul(p, q, t);                       // plain x Montgomery = plain
+        } else sc_montmul(p, v, t);                    // Montgomery x plain
+    } else {
+        sc sv;
+        ld_sc(sv, (isH ? A.s2 : A.s1) + b * A.N + j);  // plain form (k_rp_lr)
+        sc_montmul(p, v, sv);                          // Montgomery x plain = the canonical product
+    }
+}
+// The coefficient itself in plain form (the materialisation's scalars), after `round` rounds.
+__device__ __forceinline__ void coeff_plain(sc& s, const RangeArgs& A, size_t b, int round, int j, bool isH) {
+    if (A.stab) {
+        const sc* T = A.stab + ((b * 2 + (size_t)(round & 1)) * 2 + (isH ? 1 : 0)) * STAB_N + (round ? (j >> (A.lgN - round)) : 0);
+        sc t;
+        ld_sc(t, T);
+        if (isH) {
+            sc yi;
+            ld_sc(yi, A.s2 + b * A.N + j);
+            sc_montmul(s, yi, t);                      // plain x Montgomery = plain
+        } else s = t;
+    } else ld_sc(s, (isH ? A.s2 : A.s1) + b * A.N + j);
+}
+__device__ __forceinline__ void stab_init(const RangeArgs& A, size_t b) {      // TG_0 = [1] (plain), TH_0 = [1] (Montgomery)
+    if (!A.stab) return;
+    sc one_p, one_m;
+    sc_zero(one_p); one_p.v[0] = 1;
+    sc_one_mont(one_m);
+    st_sc(A.stab + (b * 2 * 2 + 0) * STAB_N, one_p);
+    st_sc(A.stab + (b * 2 * 2 + 1) * STAB_N, one_m);
 }
 
 // List position -> generator.  A digit row holds two lists of N terms each: lanes 0-31 of the MSM wave walk
@@ -506,6 +555,7 @@ __global__ __launch_bounds__(64) void k_rp_tail_table(RangeArgs A) {
     sc one, v;
     sc_zero(one); one.v[0] = 1;                              // plain 1 (the s-vectors are kept in plain form)
     int i = g < T ? g : g - T;
+    if (g == 0) stab_init(A, b);                             // the tail argument starts from coefficient 1 on both sides
     st_sc((g < T ? A.tail_s1 : A.tail_s2) + b * T + i, one);
     ld_sc(v, (g < T ? A.a : A.b) + b * A.N + i);
     st_sc((g < T ? A.tail_a : A.tail_b) + b * T + i, v);
@@ -519,7 +569,7 @@ __global__ __launch_bounds__(64) void k_rp_mat_prep(RangeArgs A) {
     int ch = blockIdx.x % nch, l = threadIdx.x, side = l >> 5, q = 32 * ch + (l & 31), pos = 64 * ch + l;
     if (q >= A.N) { zero_digits(A, b, pos); return; }
     sc s;
-    ld_sc(s, (side ? A.s2 : A.s1) + b * A.N + q);           // plain form already
+    coeff_plain(s, A, b, A.mat_round, q, side != 0);        // plain form
     write_digits_plain(A, b, pos, s.v);
 }
 
@@ -831,6 +881,7 @@ __global__ __launch_bounds__(64) void k_rp_lr(RangeArgs A) {
     }
     wave_reduce_sc(tx);
     if (l == 0) {
+        if (part == 0) stab_init(A, b);
         if (parts > 1) st_sc(A.fs_part + (b * parts + part) * 3 + 2, tx);
         else A.st[b].t_x = tx;
     }
@@ -900,10 +951,9 @@ __global__ __launch_bounds__(64) void k_rp_round_prep(RangeArgs A, int round) {
     bool upper = (j >> lgh) & 1;              // generator sits in the upper half of its block
     // G_R pairs with a_L, G_L with a_R; H'_L pairs with b_R, H'_R with b_L
     int vi = upper ? off : off + half;
-    sc v, s, p;
+    sc v, p;
     ld_sc(v, (isH ? A.b : A.a) + b * A.N + vi);
-    ld_sc(s, (isH ? A.s2 : A.s1) + b * A.N + j);          // plain form (k_rp_lr)
-    sc_montmul(p, v, s);                                   // Montgomery x plain = the canonical product
+    coeff_times(p, A, b, round, j, isH, v);
     write_digits_plain(A, b, pos, p.v);
 }
 // c_L = <a_L, b_R>, c_R = <a_R, b_L>  (wave per proof)
@@ -966,15 +1016,63 @@ __global__ __launch_bounds__(64) void k_rp_round_finish(RangeArgs A, TableView t
     st_store(ps, s);
 }
 
-// --------------------------------------------- K6: fold a, b and update the s-vectors (elementwise, B * N lanes)
+// --------------------------------------------- K6: fold a, b and update the coefficients (elementwise)
+// Vector mode (A.stab null): B * N lanes, lane j multiplies s_G[j], s_H[j] by u^{+-1} and, for j < half, folds a and b.
+// Table mode: B * max(half, 2^(round + 2)) lanes; lane j < half folds a and b (both products of a fold in the 29-bit column domain,
+// ONE Montgomery reduction per folded entry), and lanes j < 2^(round + 2) extend the coefficient tables by the new challenge:
+// TG'[2t + bit] = TG[t] * (bit ? u : u^-1), TH'[2t + bit] = TH[t] * (bit ? u^-1 : u), into the other buffer.
+__device__ __forceinline__ void fold_pair(sc& r, const sc& lo, const sc& hi, const uint32_t* ulo29, const uint32_t* uhi29) {
+    uint32_t x[9];
+    uint64_t c[18];
+#pragma unroll
+    for (int k = 0; k < 18; k++) c[k] = 0;
+    sc_split29(x, lo.v);
+    sc_mac29(c, x, ulo29);
+    sc_split29(x, hi.v);
+    sc_mac29(c, x, uhi29);
+    sc_redc29(r, c);                              // (lo * ulo + hi * uhi) / R mod l, canonical: what two products and a sum give
+}
 __global__ __launch_bounds__(256) void k_rp_fold(RangeArgs A, int round) {
     size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    int lgh = A.lgN - 1 - round, half = 1 << lgh;
+    if (A.stab) {
+        const int nt = (round + 1 <= STAB_ROUNDS) ? (2 << (round + 1)) : 0;          // table entries to write: 2^(round+1) per side
+        const size_t per = (size_t)(half > nt ? half : nt);
+        if (gid >= A.B * per) return;
+        const size_t b = gid / per;
+        const int j = (int)(gid - b * per);
+        const ProofState& ps = A.st[b];
+        const sc u = ps.u, ui = ps.u_inv;
+        if (j < nt) {
+            const int side = j >= (nt >> 1) ? 1 : 0, tp = side ? j - (nt >> 1) : j, t = tp >> 1, bit = tp & 1;
+            const sc* src = A.stab + ((b * 2 + (size_t)(round & 1)) * 2 + side) * STAB_N;
+            sc* dst = A.stab + ((b * 2 + (size_t)((round + 1) & 1)) * 2 + side) * STAB_N;
+            sc x, y;
+            ld_sc(x, src + t);
+            sc_montmul(y, x, (bit != 0) != (side != 0) ? u : ui);        // G: bit ? u : u^-1;  H: bit ? u^-1 : u
+            st_sc(dst + tp, y);
+        }
+        if (j < half) {
+            uint32_t u29[9], ui29[9];
+            sc_split29(u29, u.v);
+            sc_split29(ui29, ui.v);
+            sc lo, hi, r;
+            ld_sc(lo, A.a + b * A.N + j);
+            ld_sc(hi, A.a + b * A.N + half + j);
+            fold_pair(r, lo, hi, u29, ui29);
+            st_sc(A.a + b * A.N + j, r);              // a' = a_L u + a_R u^-1
+            ld_sc(lo, A.b + b * A.N + j);
+            ld_sc(hi, A.b + b * A.N + half + j);
+            fold_pair(r, lo, hi, ui29, u29);
+            st_sc(A.b + b * A.N + j, r);              // b' = b_L u^-1 + b_R u
+        }
+        return;
+    }
     if (gid >= A.B * (size_t)A.N) return;
     size_t b = gid / A.N;
     int j = (int)(gid - b * A.N);
     const ProofState& ps = A.st[b];
     sc u = ps.u, ui = ps.u_inv;
-    int lgh = A.lgN - 1 - round, half = 1 << lgh;
     bool upper = (j >> lgh) & 1;
     sc s, t;
     ld_sc(s, A.s1 + b * A.N + j);                 // G' = u^-1 G_L + u G_R
@@ -997,74 +1095,6 @@ __global__ __launch_bounds__(256) void k_rp_fold(RangeArgs A, int round) {
         sc_montmul(hi, hi, u);
         sc_add(r, lo, hi);
         st_sc(A.b + b * A.N + j, r);              // b' = b_L u^-1 + b_R u
-    }
-}
-
-// K6 + K5 of the NEXT round in one pass (wave per proof): fold a, b by u_k; then, for round k + 1, the inner products c_L, c_R of
-// the folded halves and -- position by position of its digit rows -- the s-vector entry folded by u_k, stored, and multiplied
-// with its a' / b' partner into that position's digits.  Against k_rp_fold + k_rp_round_prep + k_rp_round_ip this reads the
-// s-vectors once instead of twice and finds a', b' in the cache they were just written through.  Opt-in (DAPOL_FUSE_FOLD=1): it
-// measured 1.7 % SLOWER than the three launches at 2^18 proofs and 40 % slower for a lone proof (profiles/r02_fold_fuse_ab.txt).
-__global__ __launch_bounds__(64) void k_rp_fold_next(RangeArgs A, int round) {
-    const size_t b = blockIdx.x;
-    const int l = threadIdx.x;
-    ProofState& ps = A.st[b];
-    const sc u = ps.u, ui = ps.u_inv;
-    const int lgh = A.lgN - 1 - round, half = 1 << lgh;
-    sc* va = A.a + b * A.N;
-    sc* vb = A.b + b * A.N;
-    for (int i = l; i < half; i += 64) {
-        sc lo, hi, r;
-        ld_sc(lo, va + i);
-        ld_sc(hi, va + half + i);
-        sc_montmul(lo, lo, u);
-        sc_montmul(hi, hi, ui);
-        sc_add(r, lo, hi);
-        st_sc(va + i, r);                         // a' = a_L u + a_R u^-1
-        ld_sc(lo, vb + i);
-        ld_sc(hi, vb + half + i);
-        sc_montmul(lo, lo, ui);
-        sc_montmul(hi, hi, u);
-        sc_add(r, lo, hi);
-        st_sc(vb + i, r);                         // b' = b_L u^-1 + b_R u
-    }
-    __syncthreads();                              // a', b' are read across lanes below
-    const int lgh1 = lgh - 1, half1 = half >> 1;
-    {
-        sc cL, cR;
-        sc_zero(cL);
-        sc_zero(cR);
-        for (int i = l; i < half1; i += 64) {
-            sc aL, aR, bL, bR, t;
-            ld_sc(aL, va + i);
-            ld_sc(aR, va + half1 + i);
-            ld_sc(bL, vb + i);
-            ld_sc(bR, vb + half1 + i);
-            sc_montmul(t, aL, bR);
-            sc_add(cL, cL, t);
-            sc_montmul(t, aR, bL);
-            sc_add(cR, cR, t);
-        }
-        wave_reduce_sc(cL);
-        wave_reduce_sc(cR);
-        if (l == 0) { ps.cL = cL; ps.cR = cR; }
-    }
-    for (int pos = l; pos < A.TP; pos += 64) {
-        const int ch = pos >> 6, side = (pos & 63) >> 5, q = 32 * ch + (pos & 31);
-        if (q >= A.N) { zero_digits(A, b, pos); continue; }
-        bool isH;
-        const int j = term_generator(round + 1, A.N, A.lgN, side, q, isH);
-        const bool upper = (j >> lgh) & 1;        // round k: G' = u^-1 G_L + u G_R, H' = u H_L + u^-1 H_R
-        sc* sp = (isH ? A.s2 : A.s1) + b * A.N + j;
-        sc s, t, v, p;
-        ld_sc(s, sp);
-        sc_montmul(t, s, (upper != isH) ? u : ui);
-        st_sc(sp, t);
-        const int off = j & (half1 - 1);          // round k + 1: G_R pairs with a_L, G_L with a_R; H'_L with b_R, H'_R with b_L
-        const int vi = ((j >> lgh1) & 1) ? off : off + half1;
-        ld_sc(v, (isH ? vb : va) + vi);
-        sc_montmul(p, v, t);                      // Montgomery x plain = the canonical product
-        write_digits_plain(A, b, pos, p.v);
     }
 }
 

@@ -88,10 +88,9 @@ __global__ __launch_bounds__(64) void k_rp_round_prep_gs(RangeArgs A, int round)
         const int off = j & (half - 1);
         const bool upper = (j >> lgh) & 1;
         const int vi = upper ? off : off + half;       // G_R pairs with a_L, G_L with a_R; H'_L with b_R, H'_R with b_L
-        sc v, s, pr;
+        sc v, pr;
         ld_sc(v, (isH ? A.b : A.a) + p * A.N + vi);
-        ld_sc(s, (isH ? A.s2 : A.s1) + p * A.N + j);   // plain form (k_rp_lr)
-        sc_montmul(pr, v, s);                          // Montgomery x plain = the canonical product
+        coeff_times(pr, A, p, round, j, isH, v);       // the canonical product a_i * s_j (coefficient tables or vectors)
         for (int i = 0; i < 8; i++) c[k][i] = pr.v[i];
     }
     write_digits_gs4(A, p, sp4, c);
@@ -175,7 +174,7 @@ __global__ __launch_bounds__(64) void k_rp_mat_prep_gs(RangeArgs A) {
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         sc s;
-        ld_sc(s, (side ? A.s2 : A.s1) + p * A.N + cls + (k0 + k) * A.tail_n);     // plain form already
+        coeff_plain(s, A, p, A.mat_round, cls + (k0 + k) * A.tail_n, side != 0);   // plain form
         for (int i = 0; i < 8; i++) c[k][i] = s.v[i];
     }
     write_digits_gs4(A, p, sp4, c);

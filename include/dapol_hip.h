@@ -382,6 +382,7 @@ typedef struct {
     uint64_t mat_launches, msm_kernels, mat_kernels;
     double msm_all_ms;      /* time with a bracket of either kind open (msm_ms / mat_ms / this are UNIONS of the bracket intervals:
                              * two chunks are in flight on two streams and their brackets overlap) */
+    double msm_span_ms;     /* SUM of the plain brackets' lengths: what a per-kernel profiler adds up for launches that overlap in time */
 } dapol_workload_stats;
 int32_t dapol_workload_run(dapol_workload* w, const uint8_t pad_seed32[32], const uint8_t nonce_seed32[32], int32_t n_bits,
                            size_t first_entity, size_t n_entities, dapol_workload_stats* stats);

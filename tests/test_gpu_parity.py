@@ -1111,10 +1111,11 @@ def test_every_proving_strategy_gives_the_same_bytes(gpu_ctx, n_bits, m):
                 {"DAPOL_LPL": "32"}, {"DAPOL_LPL": "4"}, {"DAPOL_LPL": "2"}, {"DAPOL_LPL": "2", "DAPOL_MSM_OCC_CAP": "3"}, {"DAPOL_CHUNK": "64"}, {"DAPOL_TAIL_N": "256", "DAPOL_LPL": "16"},
                 {"DAPOL_CHUNK": "8"}, {"DAPOL_CHUNK": "5", "DAPOL_STREAMS": "4"}, {"DAPOL_CHUNK": "16", "DAPOL_STREAMS": "1"},
                 {"DAPOL_CHUNK": "36", "DAPOL_STREAMS": "3"}, {"DAPOL_NO_SPLIT": "1"}, {"DAPOL_NO_SPLIT": "1", "DAPOL_TAIL_LPL": "32"},
-                # the small-call (latency) arrangements and the opt-in fused fold
+                # the small-call (latency) arrangements; coefficient tables off (DAPOL_NO_STAB: the s-vectors folded every round) and tails too long for them
                 {"DAPOL_SMALL_TAIL": "1"}, {"DAPOL_SMALL_TAIL": "1", "DAPOL_NO_SPLIT_MAT": "1"}, {"DAPOL_SMALL_SPLIT": "16"}, {"DAPOL_SMALL_SPLIT": "2"},
-                {"DAPOL_NO_SMALL_HI": "1"}, {"DAPOL_NO_PAIR": "1"}, {"DAPOL_FUSE_FOLD": "1"}, {"DAPOL_FUSE_FOLD": "1", "DAPOL_SMALL_TAIL": "1"},
-                {"DAPOL_FUSE_FOLD": "1", "DAPOL_NO_SPLIT": "1"}, {"DAPOL_FS_SHAPE": "0"}, {"DAPOL_FS_SHAPE": "1"}, {"DAPOL_FS_SHAPE": "2", "DAPOL_NO_SPLIT": "1"}, {"DAPOL_NO_QUAD": "1"}, {"DAPOL_NO_QUAD": "1", "DAPOL_SMALL_TAIL": "1"}, {"DAPOL_SMALL_SPLIT": "4"},
+                {"DAPOL_NO_SMALL_HI": "1"}, {"DAPOL_NO_PAIR": "1"}, {"DAPOL_NO_STAB": "1"}, {"DAPOL_NO_STAB": "1", "DAPOL_SMALL_TAIL": "1"},
+                {"DAPOL_NO_STAB": "1", "DAPOL_NO_SPLIT": "1"}, {"DAPOL_NO_STAB": "1", "DAPOL_NO_SPLIT": "1", "DAPOL_GS": "1"},
+                {"DAPOL_NO_SPLIT": "1", "DAPOL_TAIL_N": "256"}, {"DAPOL_NO_SPLIT": "1", "DAPOL_TAIL_N": "128", "DAPOL_GS": "1"}, {"DAPOL_FS_SHAPE": "0"}, {"DAPOL_FS_SHAPE": "1"}, {"DAPOL_FS_SHAPE": "2", "DAPOL_NO_SPLIT": "1"}, {"DAPOL_NO_QUAD": "1"}, {"DAPOL_NO_QUAD": "1", "DAPOL_SMALL_TAIL": "1"}, {"DAPOL_SMALL_SPLIT": "4"},
                 # four lanes per point for all 37 proofs (the default keeps it to calls of up to 8)
                 {"DAPOL_NO_FS_PARTS": "1"}, {"DAPOL_NO_SIDE_A": "1"},
                 # the generator-stationary sweep of large calls (kernels_range_gs.h), forced onto this small batch
