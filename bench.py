@@ -409,8 +409,9 @@ def mode_prove(args):
     # Two clocks per launch.  `avg_launch_ms` is the SPAN of a launch -- bracket lengths summed / launches inside: what
     # `rocprofv3 --kernel-trace --stats` of this command reports as the kernel's average, with the launches of the two chunks in
     # flight overlapping in time (each then takes about twice as long as alone).  `avg_launch_ms_exclusive` divides the time during
-    # which such a launch was running at all (the union of the brackets) by the launches: the chip-wide cost of one launch, what
-    # the serialised --pmc passes and a one-stream run measure.  `achieved` uses the exclusive time.
+    # which such a launch was running at all (the union of the brackets) by the launches: an upper bound of the chip-wide cost of one
+    # launch (the other chunk's kernels also run inside those intervals; the serialised --pmc passes measure 0.47-0.49 ms).
+    # `achieved` uses the exclusive time.
     avg_launch_span_ms = (acc["msm_span_ms"] if acc["msm_span_ms"] > 0 else acc["msm_ms"]) / max(1, launches)
     avg_launch_ms = acc["msm_ms"] / max(1, launches)
     # algorithmic bytes per launch (6,384 B of compulsory traffic per entity on the prove path, spread evenly over the
