@@ -387,6 +387,12 @@ def mode_prove(args):
         tt = torch.tensor([elapsed], dtype=torch.float64, device=comm_device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    # The library's communicator has done its work: every rank finalises it HERE, together (they have just left the same
+    # all-reduce), not one by one at interpreter exit while the others may already be gone.
+    exchange_path, comm_ranks, comm_error = prover.exchange_path, prover.comm_ranks, prover.comm_error
+    if prover.comm is not None:
+        prover.comm.close()
+        prover.comm = None
     if rank != 0:
         if dist is not None:
             dist.barrier()                     # leave together with rank 0 (which still runs its parity / verification legs)
@@ -504,8 +510,8 @@ def mode_prove(args):
                                   else (" per GPU (weak scaling)" if world > 1 else ""), height, n_bits),
                    "entities_total": n_total, "entities_per_gpu": n_per_gpu, "proof_bytes": int(stats.proof_bytes // max(1, stats.proofs)),
                    "sharding": "none" if world == 1 else "top-level subtrees, all-gather of %d subtree roots" % world,
-                   "exchange": prover.exchange_path, "rccl_ranks_in_library_communicator": prover.comm_ranks,
-                   "exchange_fallback_reason": prover.comm_error},
+                   "exchange": exchange_path, "rccl_ranks_in_library_communicator": comm_ranks,
+                   "exchange_fallback_reason": comm_error},
         "phases_ms": {"tree_build": acc["tree_ms"] / steps, "prove": acc["prove_ms"] / steps},
         "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "secondary": secondary,
         "checksum": "%016x" % stats.checksum,

@@ -113,12 +113,15 @@ __global__ __launch_bounds__(64, 4) void k_rp_msm_gs(RangeArgs A, TableView tbl,
         }
     }
     const dapol_v4i* dg = reinterpret_cast<const dapol_v4i*>(A.dig) + ((size_t)(side * A.N + q0) >> 2) * L + lane;
-    dapol_v4i d4 = {0, 0, 0, 0};
+    // The digits of the NEXT four rows are requested while the current four are being added: the digit load (a cold, streamed
+    // 16 bytes) is then never what a lane's table lookup waits for.
+    dapol_v4i d4 = dg[0], dn = d4;
 #pragma nounroll
     for (int i = 0; i < nq; i++) {
-        if ((i & 3) == 0) d4 = dg[(size_t)(i >> 2) * L];
+        if ((i & 3) == 0 && i + 4 < nq) dn = dg[(size_t)((i >> 2) + 1) * L];
         const int d = d4.x;
         d4.x = d4.y; d4.y = d4.z; d4.z = d4.w;
+        if ((i & 3) == 3) d4 = dn;
         bool isH;
         const int j = term_generator(round, A.N, A.lgN, side, q0 + i, isH);      // (uniform over the launch)
         tbl_madd(acc, tbl, gen_row(tbl, A.n, j, isH), d);
@@ -202,12 +205,13 @@ __global__ __launch_bounds__(64, 4) void k_rp_mat_gs(RangeArgs A, TableView tbl,
     }
     const int per = A.N / A.tail_n;
     const dapol_v4i* dg = reinterpret_cast<const dapol_v4i*>(A.dig) + ((size_t)(side * A.N + cls * per) >> 2) * L + (size_t)wd * A.B + p;
-    dapol_v4i d4 = {0, 0, 0, 0};
+    dapol_v4i d4 = dg[0], dn = d4;                       // (digits one quad ahead, as in k_rp_msm_gs)
 #pragma nounroll
     for (int k = 0; k < per; k++) {
-        if ((k & 3) == 0) d4 = dg[(size_t)(k >> 2) * L];
+        if ((k & 3) == 0 && k + 4 < per) dn = dg[(size_t)((k >> 2) + 1) * L];
         const int d = d4.x;
         d4.x = d4.y; d4.y = d4.z; d4.z = d4.w;
+        if ((k & 3) == 3) d4 = dn;
         const int row = gen_row(tbl, A.n, cls + k * A.tail_n, side != 0);
         tbl_madd(acc, tbl, hi ? tbl.row_hi(row) : row, d);
     }
