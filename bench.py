@@ -710,6 +710,32 @@ def mode_build(args):
                 ctx.set_options(capi.Options())
         update_rows.append(row)
         log("update k=%d: %.3f ms" % (k, row["incremental_ms"]))
+    # ... and NEW liabilities (the reference's update loop grows its tree this way, src/tests.rs:41-48): the levels that gain nodes
+    # are rewritten in order on the device (12 levels of 2^20 nodes in the strided layout), nothing is recomputed for nodes that move
+    stride = int(idx[1] - idx[0]) if n > 1 else 2
+    insert_rows = []
+    free = 1
+    for k in (1, 64):
+        if stride < 4:
+            break
+        ts = []
+        for rep in range(6):
+            pick = np.sort(rng.choice(n, size=k, replace=False))
+            new_idx = idx[pick] + np.uint64(free)                       # free slots of the strided layout; other slots every repetition
+            free += 1
+            if free >= stride:
+                break
+            nv = rng.integers(0, 1 << 32, size=k, dtype=np.uint64)
+            nr = rng.integers(0, 256, size=(k, 32), dtype=np.uint8)
+            nr[:, 31] &= 0x0F
+            t0 = time.perf_counter()
+            tree.update(new_idx, nv, nr)
+            if rep:                                                     # (the first repetition allocates the levels' second buffers)
+                ts.append(time.perf_counter() - t0)
+            assert tree.last_update_path() == 2
+        if ts:
+            insert_rows.append({"leaves_inserted": k, "incremental_ms": 1e3 * sorted(ts)[len(ts) // 2]})
+            log("insert k=%d: %.3f ms" % (k, insert_rows[-1]["incremental_ms"]))
     tree.close()
     big = rows[-1]
     ab_prove, ab_tree = algorithmic_bytes(args.height, args.n_bits, args.log2_entities)
@@ -718,7 +744,7 @@ def mode_build(args):
                       "n_gpus": 1, "higher_is_better": True, "data": "synthetic", "dtype": "int32 limbs (255-bit modular integers)",
                       "config": {"workload": "benches/dapol.rs:24-57 build group + 2^%d x height %d" % (args.log2_entities, args.height)},
                       "cases": rows, "update": {"tree": "2^%d leaves x height %d, host-inclusive (H2D of the k records)" % (args.log2_entities, args.height),
-                                               "cases": update_rows},
+                                               "cases": update_rows, "inserts": insert_rows},
                       "roofline": {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": None,
                                    "kernel": "k_tree_merge (+ scan / flags)", "algorithmic_bytes_per_entity": ab_tree}}), flush=True)
 

@@ -67,6 +67,7 @@ _SIG = {
     "dapol_tree_root": (ctypes.c_int32, [_P, _P, _P, _P, _P]),
     "dapol_tree_node_count": (ctypes.c_int32, [_P, _P, _P]),
     "dapol_tree_update": (ctypes.c_int32, [_P, ctypes.c_size_t, _P, _P, _P]),
+    "dapol_tree_last_update_path": (ctypes.c_int32, [_P, _P]),
     "dapol_tree_level_size": (ctypes.c_int32, [_P, ctypes.c_int32, _P, _P]),
     "dapol_tree_level_nodes": (ctypes.c_int32, [_P, ctypes.c_int32, _P, _P, _P, _P, _P, _P]),
     "dapol_tree_paths": (ctypes.c_int32, [_P, ctypes.c_size_t, _P, _P, _P, _P, _P]),
@@ -575,6 +576,12 @@ class Tree:
         """Dapol::update for a batch of leaves (insert or replace), applied in order."""
         leaf_idx, v, r32 = _u64(leaf_idx), _u64(v), _u8(r32)
         _chk(lib().dapol_tree_update(self.h, leaf_idx.shape[0], _ptr(leaf_idx), _ptr(v), _ptr(r32)))
+
+    def last_update_path(self):
+        """0 = the last update rebuilt the tree, 1 = replaced in place, 2 = inserted in place, 3 = both."""
+        p = ctypes.c_int32(-1)
+        _chk(lib().dapol_tree_last_update_path(self.h, ctypes.byref(p)))
+        return int(p.value)
 
     def node_count(self):
         a, b = np.zeros(1, np.uint64), np.zeros(1, np.uint64)

@@ -504,6 +504,11 @@ struct OwnedLeaves {
 struct dapol_tree_owned : dapol_tree {
     OwnedLeaves leaves;          // empty when level 0 borrows the caller's device arrays (workload trees)
     DevBuf<uint8_t> upd_scratch; // dapol_tree_update's incremental path (kept: an update must not pay for an allocation)
+    // A level that gains nodes (incremental insert) is rewritten out of place into one of two buffers of its own (ping-pong; the
+    // arena region it came from is simply left behind).  cur = which of the two holds the level now (-1: still in the arena).
+    struct LevelAlt { DevBuf<uint8_t> buf[2]; size_t cap[2] = {0, 0}; int cur = -1; };
+    std::vector<LevelAlt> alt;
+    int last_update_path = 0;    // what the last dapol_tree_update did: 0 rebuild, 1 replaced in place, 2 inserted in place, 3 both
     bool holds_ctx = false;      // API-created trees keep their context alive (workload trees live inside a workload that does)
 };
 
@@ -563,14 +568,14 @@ int32_t dapol_tree_build_shard(dapol_ctx* ctx, int32_t total_height, int32_t sha
 // tree keeps its structure and only the k root-to-leaf paths are re-merged, on the device, in three launches.  *done = false
 // (nothing above the leaves touched) when some index is new: the caller then rebuilds.
 static int32_t tree_update_incremental(dapol_tree_owned* own, size_t k, const std::vector<uint64_t>& idx, const std::vector<uint64_t>& v,
-                                       const std::vector<uint8_t>& r, bool* done) {
+                                       const std::vector<uint8_t>& r, bool* done, std::vector<uint8_t>* found_out = nullptr) {
     *done = false;
     dapol_ctx* ctx = own->ctx;
     hipStream_t st = ctx->stream;
     const int H = own->height;
     // one staging buffer up, one scratch allocation (kept with the tree): idx | v | r | dv | dr | dP | pos | missing
     const size_t o_idx = 0, o_v = o_idx + k * 8, o_r = o_v + k * 8, o_dv = o_r + k * 32, o_dr = o_dv + k * 8, o_dP = o_dr + k * 32,
-                 o_pos = o_dP + k * 160, o_miss = align_up(o_pos + k * (size_t)(H + 1) * 4, 8), total = o_miss + 8;
+                 o_pos = o_dP + k * 160, o_miss = align_up(o_pos + k * (size_t)(H + 1) * 4, 8), o_found = o_miss + 8, total = o_found + k;
     if (own->upd_scratch.n < total) HIPCHK(own->upd_scratch.alloc(total + total / 2));
     std::vector<uint8_t> stage(o_dv);
     memcpy(stage.data() + o_idx, idx.data(), k * 8);
@@ -580,13 +585,14 @@ static int32_t tree_update_incremental(dapol_tree_owned* own, size_t k, const st
     HIPCHK(hipMemcpyAsync(d, stage.data(), o_dv, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(d + o_miss, 0, 8, st));
     TreeUpdArgs U{k, H, (const uint64_t*)(d + o_idx), (const uint64_t*)(d + o_v), (const uint32_t*)(d + o_r), (uint32_t*)(d + o_pos), (int32_t*)(d + o_dP),
-                  (uint64_t*)(d + o_dv), (uint32_t*)(d + o_dr), (uint32_t*)(d + o_miss)};
+                  (uint64_t*)(d + o_dv), (uint32_t*)(d + o_dr), (uint32_t*)(d + o_miss), d + o_found, nullptr};
     hipLaunchKernelGGL(k_tree_upd_find, dim3(nblk(k, 64)), dim3(64), 0, st, own->d_views.p, U);
     LAUNCH_CHECK();
     uint32_t missing = 0;
     HIPCHK(hipMemcpyAsync(&missing, d + o_miss, 4, hipMemcpyDeviceToHost, st));
+    if (found_out) { found_out->resize(k); HIPCHK(hipMemcpyAsync(found_out->data(), d + o_found, k, hipMemcpyDeviceToHost, st)); }
     HIPCHK(hipStreamSynchronize(st));
-    if (missing) return DAPOL_OK;                            // a new index: nothing has been written, the caller rebuilds
+    if (missing) return DAPOL_OK;                            // a new index: nothing has been written; the caller inserts or rebuilds
     hipLaunchKernelGGL(k_tree_upd_leaves, dim3(nblk(k, 64)), dim3(64), 0, st, ctx->tv, own->d_views.p, U);
     LAUNCH_CHECK();
     if (H >= 1) {
@@ -603,6 +609,145 @@ static int32_t tree_update_incremental(dapol_tree_owned* own, size_t k, const st
         }
     }
     HIPCHK(hipStreamSynchronize(st));
+    *done = true;
+    return DAPOL_OK;
+}
+
+// Spans of one level inside a buffer of capacity `cap` records (incremental insert).
+static size_t level_alt_bytes(size_t cap) { return align_up(cap * 8, 256) * 2 + align_up(cap * 32, 256) * 6 + align_up(cap * 4, 256) + align_up(cap, 256); }
+static void level_alt_spans(uint8_t* base, size_t cap, LevelBuf& L, uint64_t** leaf_idx, uint64_t** leaf_v, uint32_t** leaf_r, bool is_leaf_level) {
+    size_t o = 0;
+    auto take = [&](size_t bytes) { uint8_t* p = base + o; o += align_up(bytes, 256); return p; };
+    uint64_t* idx = (uint64_t*)take(cap * 8);
+    uint64_t* vv = (uint64_t*)take(cap * 8);
+    uint32_t* rr = (uint32_t*)take(cap * 32);
+    if (is_leaf_level) { *leaf_idx = idx; *leaf_v = vv; *leaf_r = rr; }
+    else { L.idx.p = idx; L.v.p = vv; L.r.p = rr; }
+    L.C.p = (uint32_t*)take(cap * 32); L.H.p = (uint32_t*)take(cap * 32);
+    L.padC.p = (uint32_t*)take(cap * 32); L.padH.p = (uint32_t*)take(cap * 32); L.padr.p = (uint32_t*)take(cap * 32);
+    L.parent.p = (uint32_t*)take(cap * 4);
+    L.has_pad.p = take(cap);
+}
+
+// The incremental path for NEW leaves (kernels_ctx_tree.h, "incremental insert"): k sorted, distinct indexes none of which is in the
+// tree.  *done = false and nothing written when two new chains share a node (the caller rebuilds).
+static int32_t tree_insert_incremental(dapol_tree_owned* own, size_t k, const std::vector<uint64_t>& idx, const std::vector<uint64_t>& v,
+                                       const std::vector<uint8_t>& r, bool* done) {
+    *done = false;
+    dapol_ctx* ctx = own->ctx;
+    hipStream_t st = ctx->stream;
+    const int H = own->height;
+    if (H < 1 || own->levels[0].n + k > ((size_t)1 << 31)) return DAPOL_OK;
+    const size_t S1 = (size_t)H + 1;
+    // scratch: idx | v | r | m | inspos | newpos | pos | dP | dv | dr | first | level insert positions | pad seed | flags
+    const size_t o_idx = 0, o_v = o_idx + k * 8, o_r = o_v + k * 8, o_m = o_r + k * 32, o_ins = o_m + k * 4, o_new = o_ins + k * S1 * 4,
+                 o_pos = o_new + k * S1 * 4, o_dP = align_up(o_pos + k * S1 * 4, 16), o_dv = o_dP + k * 160, o_dr = o_dv + k * 8, o_lvl = o_dr + k * 32,
+                 o_seed = o_lvl + k * S1 * 4, o_flag = o_seed + 32, total = o_flag + 8;
+    if (own->upd_scratch.n < total) HIPCHK(own->upd_scratch.alloc(total + total / 2));
+    uint8_t* d = own->upd_scratch.p;
+    {
+        std::vector<uint8_t> stage(o_m);
+        memcpy(stage.data() + o_idx, idx.data(), k * 8);
+        memcpy(stage.data() + o_v, v.data(), k * 8);
+        memcpy(stage.data() + o_r, r.data(), k * 32);
+        HIPCHK(hipMemcpyAsync(d, stage.data(), o_m, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(d + o_seed, own->pad_seed, 32, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemsetAsync(d + o_flag, 0, 8, st));
+    }
+    TreeInsPlan P{k, H, (const uint64_t*)(d + o_idx), (uint32_t*)(d + o_m), (uint32_t*)(d + o_ins), (uint32_t*)(d + o_flag)};
+    hipLaunchKernelGGL(k_tree_ins_plan, dim3(nblk(k, 64)), dim3(64), 0, st, own->d_views.p, P);
+    LAUNCH_CHECK();
+    std::vector<uint32_t> hm(k), hins(k * S1);
+    uint32_t conflict = 0;
+    HIPCHK(hipMemcpyAsync(hm.data(), d + o_m, k * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(hins.data(), d + o_ins, k * S1 * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&conflict, d + o_flag, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (conflict) return DAPOL_OK;                          // chains that share a node (or an index that exists): the rebuild handles it
+    int max_m = 0;
+    for (size_t j = 0; j < k; j++) max_m = std::max(max_m, (int)hm[j]);
+    // per level t < max_m: the insert positions (old layout) of the chains that reach it, in leaf order
+    std::vector<std::vector<uint32_t>> lvl((size_t)max_m + 1);
+    std::vector<uint32_t> newpos(k * S1, 0), lvl_flat, lvl_off((size_t)max_m + 2, 0);
+    for (size_t j = 0; j < k; j++)
+        for (int t = 0; t < (int)hm[j]; t++) {
+            newpos[j * S1 + t] = hins[j * S1 + t] + (uint32_t)lvl[t].size();
+            lvl[t].push_back(hins[j * S1 + t]);
+        }
+    for (size_t j = 0; j < k; j++) {                         // the existing ancestor at level m_j, moved by what its level gains
+        const int m = (int)hm[j];
+        const uint32_t p = hins[j * S1 + m];
+        uint32_t sh = 0;
+        if (m < max_m) sh = (uint32_t)(std::upper_bound(lvl[m].begin(), lvl[m].end(), p) - lvl[m].begin());
+        newpos[j * S1 + m] = p + sh;
+    }
+    for (int t = 0; t <= max_m; t++) { lvl_off[t] = (uint32_t)lvl_flat.size(); lvl_flat.insert(lvl_flat.end(), lvl[t].begin(), lvl[t].end()); }
+    lvl_off[max_m + 1] = (uint32_t)lvl_flat.size();
+    HIPCHK(hipMemcpyAsync(d + o_new, newpos.data(), k * S1 * 4, hipMemcpyHostToDevice, st));
+    if (!lvl_flat.empty()) HIPCHK(hipMemcpyAsync(d + o_lvl, lvl_flat.data(), lvl_flat.size() * 4, hipMemcpyHostToDevice, st));
+    // new storage for the levels that gain nodes, then move their existing nodes
+    if (own->alt.size() != own->levels.size()) own->alt.resize(own->levels.size());
+    std::vector<LevelBuf> newL(own->levels.begin(), own->levels.end());
+    uint64_t *n_leaf_idx = own->leaf_idx, *n_leaf_v = own->leaf_v;
+    uint32_t* n_leaf_r = own->leaf_r;
+    std::vector<int> new_cur((size_t)max_m, -1);
+    for (int t = 0; t < max_m; t++) {
+        auto& A = own->alt[t];
+        const int dstb = A.cur == 0 ? 1 : 0;
+        const size_t n_new = own->levels[t].n + lvl[t].size();
+        if (A.cap[dstb] < n_new) {
+            const size_t cap = n_new + 4096 + n_new / 64;
+            HIPCHK(A.buf[dstb].alloc(level_alt_bytes(cap)));
+            A.cap[dstb] = cap;
+        }
+        level_alt_spans(A.buf[dstb].p, A.cap[dstb], newL[t], &n_leaf_idx, &n_leaf_v, &n_leaf_r, t == 0);
+        newL[t].n = n_new;
+        new_cur[t] = dstb;
+    }
+    auto view_of = [&](const std::vector<LevelBuf>& Ls, int t, uint64_t* li, uint64_t* lv_, uint32_t* lr) {
+        const LevelBuf& L = Ls[t];
+        LevelView lv;
+        lv.n = L.n;
+        lv.idx = t == 0 ? li : L.idx.p; lv.v = t == 0 ? lv_ : L.v.p; lv.r = t == 0 ? lr : L.r.p;
+        lv.C = L.C.p; lv.H = L.H.p; lv.padC = L.padC.p; lv.padH = L.padH.p; lv.padr = L.padr.p; lv.has_pad = L.has_pad.p; lv.parent = L.parent.p; lv.ext = nullptr;
+        return lv;
+    };
+    const uint32_t* d_lvl = (const uint32_t*)(d + o_lvl);
+    for (int t = 0; t < max_m; t++) {
+        LevelView src = view_of(std::vector<LevelBuf>(own->levels.begin(), own->levels.end()), t, own->leaf_idx, own->leaf_v, own->leaf_r);
+        LevelView dst = view_of(newL, t, n_leaf_idx, n_leaf_v, n_leaf_r);
+        const size_t n_old = own->levels[t].n;
+        if (n_old)
+            hipLaunchKernelGGL(k_tree_relayout, dim3(nblk(n_old, 256)), dim3(256), 0, st, src, dst, n_old, d_lvl + lvl_off[t], (uint32_t)lvl[t].size(),
+                               d_lvl + lvl_off[t + 1], (uint32_t)lvl[t + 1].size(), 0);
+        LAUNCH_CHECK();
+    }
+    // adopt the new storage, refresh the device-side views
+    for (int t = 0; t < max_m; t++) { own->levels[t] = newL[t]; own->alt[t].cur = new_cur[t]; }
+    own->leaf_idx = n_leaf_idx; own->leaf_v = n_leaf_v; own->leaf_r = n_leaf_r;
+    std::vector<LevelView> hv((size_t)H + 1);
+    for (int t = 0; t <= H; t++) hv[t] = own->view(t, nullptr);
+    HIPCHK(hipMemcpyAsync(own->d_views.p, hv.data(), hv.size() * sizeof(LevelView), hipMemcpyHostToDevice, st));
+    TreeInsArgs I{k, H, (const uint64_t*)(d + o_idx), (const uint64_t*)(d + o_v), (const uint32_t*)(d + o_r), (const uint32_t*)(d + o_m),
+                  (const uint32_t*)(d + o_new), (uint32_t*)(d + o_pos), (int32_t*)(d + o_dP), (uint64_t*)(d + o_dv), (uint32_t*)(d + o_dr),
+                  (const uint32_t*)(d + o_seed)};
+    hipLaunchKernelGGL(k_tree_ins_chain, dim3((unsigned)k), dim3(64), 0, st, ctx->tv, own->d_views.p, I);
+    LAUNCH_CHECK();
+    TreeUpdArgs U{k, H, (const uint64_t*)(d + o_idx), (const uint64_t*)(d + o_v), (const uint32_t*)(d + o_r), (uint32_t*)(d + o_pos), (int32_t*)(d + o_dP),
+                  (uint64_t*)(d + o_dv), (uint32_t*)(d + o_dr), (uint32_t*)(d + o_flag), nullptr, (const uint32_t*)(d + o_m)};
+    hipLaunchKernelGGL(k_tree_upd_nodes, dim3(nblk(k * (size_t)H, 64)), dim3(64), 0, st, own->d_views.p, U);
+    LAUNCH_CHECK();
+    if (k <= 1024) {
+        hipLaunchKernelGGL(k_tree_upd_hash, dim3(1), dim3((unsigned)align_up(k, 64)), 0, st, ctx->tv.digest, own->d_views.p, U, 0, H);
+        LAUNCH_CHECK();
+    } else {
+        for (int lv = 0; lv < H; lv++) {
+            hipLaunchKernelGGL(k_tree_upd_hash, dim3(nblk(k, 256)), dim3(256), 0, st, ctx->tv.digest, own->d_views.p, U, lv, lv + 1);
+            LAUNCH_CHECK();
+        }
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    for (size_t j = 0; j < k; j++) { own->n_real += hm[j]; own->n_pad += (uint64_t)hm[j] - 2 + 0; }     // m - 1 new padding nodes, one dropped
     *done = true;
     return DAPOL_OK;
 }
@@ -636,9 +781,36 @@ int32_t dapol_tree_update(dapol_tree* tree, size_t k, const uint64_t* leaf_idx, 
                 sr.insert(sr.end(), r32 + (size_t)u * 32, r32 + (size_t)u * 32 + 32);
             }
             bool done = false;
-            int32_t rc = tree_update_incremental(own, si.size(), si, sv, sr, &done);
+            std::vector<uint8_t> found;
+            int32_t rc = tree_update_incremental(own, si.size(), si, sv, sr, &done, &found);
             if (rc != DAPOL_OK) return rc;
-            if (done) return DAPOL_OK;
+            if (done) { own->last_update_path = 1; return DAPOL_OK; }
+            // Some indexes are new.  Up to 4,096 new leaves whose new chains are disjoint are inserted in place (the level arrays
+            // that gain nodes are rewritten in order, nothing is recomputed for the nodes that merely move); then the leaves that
+            // did exist are replaced as above.  Otherwise nothing has been written and the rebuild below takes the whole batch.
+            std::vector<uint64_t> ni, nv, ei, ev;
+            std::vector<uint8_t> nr, er;
+            for (size_t b = 0; b < si.size(); b++) {
+                auto& di = found[b] ? ei : ni; auto& dv_ = found[b] ? ev : nv; auto& dr_ = found[b] ? er : nr;
+                di.push_back(si[b]); dv_.push_back(sv[b]);
+                dr_.insert(dr_.end(), sr.begin() + b * 32, sr.begin() + b * 32 + 32);
+            }
+            const int H = tree->height;
+            bool in_range = true;
+            for (uint64_t x : ni) if (tree->index_bits < 64 && (x >> tree->index_bits)) in_range = false;         // (the rebuild reports the error)
+            if (tree->shard_bits) in_range = false;                                                              // shard trees: top bits must match; leave to the rebuild's checks
+            if (!ni.empty() && ni.size() <= 4096 && in_range && H >= 1 && !knob("DAPOL_NO_INCREMENTAL_INSERT")) {
+                rc = tree_insert_incremental(own, ni.size(), ni, nv, nr, &done);
+                if (rc != DAPOL_OK) return rc;
+                if (done) {
+                    own->last_update_path = 2;
+                    if (ei.empty()) return DAPOL_OK;
+                    rc = tree_update_incremental(own, ei.size(), ei, ev, er, &done);
+                    if (rc != DAPOL_OK) return rc;
+                    if (done) { own->last_update_path = 3; return DAPOL_OK; }
+                    return fail(DAPOL_ERR_INVALID_ARGUMENT, "internal: a leaf found before the insert was not found after it");
+                }
+            }
         }
     }
     const size_t n0 = tree->levels[0].n;
@@ -685,6 +857,14 @@ int32_t dapol_tree_update(dapol_tree* tree, size_t k, const uint64_t* leaf_idx, 
     if (rc != DAPOL_OK) return rc;                          // the old tree stays as it was
     fresh.holds_ctx = own->holds_ctx;
     *own = std::move(fresh);
+    own->last_update_path = 0;
+    return DAPOL_OK;
+}
+// What the last dapol_tree_update on this tree did: 0 = rebuilt the tree, 1 = replaced existing leaves in place, 2 = inserted new
+// leaves in place, 3 = both.  (Diagnostics: the result is the same tree whichever path ran.)
+int32_t dapol_tree_last_update_path(dapol_tree* tree, int32_t* path) {
+    if (!tree || !path) return fail(DAPOL_ERR_INVALID_ARGUMENT, "null argument");
+    *path = static_cast<dapol_tree_owned*>(tree)->last_update_path;
     return DAPOL_OK;
 }
 

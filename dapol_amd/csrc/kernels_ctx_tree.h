@@ -333,6 +333,8 @@ struct TreeUpdArgs {
     uint64_t* dv;              // [k]
     uint32_t* dr;              // [k][8]            Montgomery form
     uint32_t* missing;         // != 0: some leaf index is not in the tree (the caller rebuilds instead)
+    uint8_t* found;            // [k] (may be null): per update, whether its leaf exists
+    const uint32_t* first;     // [k] (may be null = 1): lowest level whose EXISTING node this update changes by its delta
 };
 // U0: where the updated leaves are (nothing is written to the tree until every index has been found)
 __global__ __launch_bounds__(64) void k_tree_upd_find(const LevelView* views, TreeUpdArgs U) {
@@ -345,7 +347,8 @@ __global__ __launch_bounds__(64) void k_tree_upd_find(const LevelView* views, Tr
         const size_t mid = (lo + hi) >> 1;
         if (L0.idx[mid] < want) lo = mid + 1; else hi = mid;
     }
-    if (lo >= L0.n || L0.idx[lo] != want) { atomicOr(U.missing, 1u); return; }
+    if (lo >= L0.n || L0.idx[lo] != want) { atomicOr(U.missing, 1u); if (U.found) U.found[j] = 0; return; }
+    if (U.found) U.found[j] = 1;
     uint32_t* pos = U.pos + j * (size_t)(U.height + 1);
     size_t p = lo;
     pos[0] = (uint32_t)p;
@@ -388,6 +391,7 @@ __global__ __launch_bounds__(64) void k_tree_upd_nodes(const LevelView* views, T
     const size_t j = t / (size_t)U.height;
     const int k = 1 + (int)(t - j * (size_t)U.height);
     const size_t stride = (size_t)U.height + 1;
+    if (U.first && k < (int)U.first[j]) return;                     // (an inserted leaf: its own new nodes below that level)
     const uint32_t p = U.pos[j * stride + k];
     if (j > 0 && U.pos[(j - 1) * stride + k] == p) return;          // an earlier update of the run owns this node
     ge_p3 sum, q, s;
@@ -441,6 +445,189 @@ __global__ __launch_bounds__(1024) void k_tree_upd_hash(int digest, const LevelV
             }
         }
         if (gridDim.x == 1) __syncthreads();                       // (several blocks: one launch per level instead)
+    }
+}
+
+// ------------------------------------------------------------------------------------- incremental insert
+// A NEW leaf x changes the structure, but only along its own path and only below the first ancestor that exists already: the
+// nodes (x >> t) for t < m are new -- each the merge of the one below with a padding sibling made for its position -- and at
+// level m - 1 the new node's sibling S is a real node whose padding sibling (at the new node's position) goes away.  From level m
+// upwards the ancestors exist and move by a delta, exactly as in the replacement path: dP = P_chain_top - P_old_pad, dr alike,
+// dv = v.  The level arrays are compact and sorted, so a level that gains nodes is rewritten out of place (k_tree_relayout: every
+// existing node moves up by the number of insertions before it, parent pointers follow the next level's moves); no commitment is
+// recomputed for it.  Leaves whose new chains would share a node (two new leaves under one new subtree) are left to the rebuild.
+//   I1  k_tree_ins_plan   per new leaf: chain length m, insertion position at every level below m, position of the first
+//                         existing ancestor; flags chains that share a node
+//   I2  k_tree_relayout   per level that gains nodes: the level's arrays in their new order (existing nodes only)
+//   I3  k_tree_ins_chain  a wavefront per new leaf, lane t = chain node t: padding siblings, prefix sums of their points,
+//                         encodings; writes the new nodes, drops S's padding sibling, leaves the delta for the levels above
+//   then U2 / U3 of the replacement path (k_tree_upd_nodes from level m, k_tree_upd_hash from the leaves).
+struct TreeInsPlan {
+    size_t k;
+    int height;
+    const uint64_t* idx;       // [k] sorted, distinct, all NEW
+    uint32_t* m;               // [k] chain length (1..height)
+    uint32_t* inspos;          // [k][height + 1]: t < m: lower-bound position in level t (old layout); [m]: position of the existing ancestor
+    uint32_t* conflict;        // != 0: two chains share a new node
+};
+__global__ __launch_bounds__(64) void k_tree_ins_plan(const LevelView* views, TreeInsPlan P) {
+    const size_t j = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (j >= P.k) return;
+    const uint64_t x = P.idx[j];
+    uint32_t* out = P.inspos + j * (size_t)(P.height + 1);
+    int m = P.height;
+    for (int t = 0; t <= P.height; t++) {
+        const LevelView L = views[t];
+        const uint64_t want = t < 64 ? x >> t : 0;
+        size_t lo = 0, hi = L.n;
+        while (lo < hi) {
+            const size_t mid = (lo + hi) >> 1;
+            if (L.idx[mid] < want) lo = mid + 1; else hi = mid;
+        }
+        out[t] = (uint32_t)lo;
+        if (lo < L.n && L.idx[lo] == want) { m = t; break; }
+    }
+    P.m[j] = (uint32_t)m;
+    if (m == 0) atomicOr(P.conflict, 2u);          // (the leaf exists: the caller partitions wrongly)
+    if (j > 0) {                                    // shares a new node with its left neighbour?
+        const uint64_t y = P.idx[j - 1];
+        for (int t = 0; t < m; t++)
+            if ((t < 64 ? x >> t : 0) == (t < 64 ? y >> t : 0)) { atomicOr(P.conflict, 1u); break; }
+    }
+}
+// Existing nodes of one level to their new positions.  ins_pos: sorted old-layout lower-bound positions of the nodes this level
+// gains (n_ins of them); next_ins_pos / n_next: the same for the level above (parent pointers move with it).
+__device__ __forceinline__ uint32_t count_le(const uint32_t* a, uint32_t n, uint32_t x) {      // # of a[i] <= x, a sorted
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (a[mid] <= x) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+__global__ __launch_bounds__(256) void k_tree_relayout(LevelView src, LevelView dst, size_t n_old, const uint32_t* ins_pos, uint32_t n_ins,
+                                                       const uint32_t* next_ins_pos, uint32_t n_next, int is_root_level) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_old) return;
+    const size_t d = i + count_le(ins_pos, n_ins, (uint32_t)i);
+    dst.idx[d] = src.idx[i];
+    dst.v[d] = src.v[i];
+    uint32_t w[8];
+    ld8(w, src.r + i * 8); st8(dst.r + d * 8, w);
+    ld8(w, src.C + i * 8); st8(dst.C + d * 8, w);
+    ld8(w, src.H + i * 8); st8(dst.H + d * 8, w);
+    dst.has_pad[d] = src.has_pad[i];
+    if (src.has_pad[i]) {
+        ld8(w, src.padC + i * 8); st8(dst.padC + d * 8, w);
+        ld8(w, src.padH + i * 8); st8(dst.padH + d * 8, w);
+        ld8(w, src.padr + i * 8); st8(dst.padr + d * 8, w);
+    }
+    if (!is_root_level) {
+        const uint32_t pq = src.parent[i];
+        dst.parent[d] = pq + (n_next ? count_le(next_ins_pos, n_next, pq) : 0u);
+    }
+}
+struct TreeInsArgs {
+    size_t k;
+    int height;
+    const uint64_t* idx; const uint64_t* v; const uint32_t* r;     // the new leaves
+    const uint32_t* m;                                              // [k]
+    const uint32_t* newpos;                                         // [k][height + 1]: t < m: position of chain node t in the NEW layout; [m]: of the existing ancestor
+    uint32_t* pos;                                                  // [k][height + 1] out: node positions at every level (new layout), for U2 / U3
+    int32_t* dP; uint64_t* dv; uint32_t* dr;                        // out: the delta for levels >= m
+    const uint32_t* pad_seed;                                       // [8]
+};
+// one wavefront per new leaf; lane t < m handles chain node t
+__global__ __launch_bounds__(64) void k_tree_ins_chain(TableView tbl, const LevelView* views, TreeInsArgs I) {
+    const size_t j = blockIdx.x;
+    const int t = threadIdx.x, m = (int)I.m[j];
+    const uint64_t x = I.idx[j];
+    const uint32_t* np = I.newpos + j * (size_t)(I.height + 1);
+    // the leaf's own point and reduced blinding (every lane: cheaper than a broadcast of 36 + 8 words)
+    uint32_t rl[8];
+    ld8(rl, I.r + j * 8);
+    rl[7] &= 0x7fffffffu;                          // Scalar::from_bits
+    ge_p3 P0;
+    ge_identity(P0);
+    tbl_fixed_mul_add_u64(P0, tbl, tbl.row_B(0), I.v[j]);
+    tbl_fixed_mul_add(P0, tbl, tbl.row_Bb(0), rl);
+    sc r0;
+    sc_to_mont(r0, rl);
+    // lane t: the padding sibling of chain node t (needed for t < m - 1), Paddable::padding at (t, (x >> t) ^ 1)
+    const bool has_pad = t < m - 1;
+    ge_p3 Pp;
+    ge_identity(Pp);
+    sc rp;
+    sc_zero(rp);
+    uint32_t rB[8] = {0}, cB[8] = {0}, hB[8] = {0};
+    if (has_pad) {
+        uint32_t seed[8], wide[16];
+        for (int q = 0; q < 8; q++) seed[q] = I.pad_seed[q];
+        seed_wide(wide, seed, 1u, (uint64_t)t, (x >> t) ^ 1ull);
+        sc_from_wide(rp, wide);
+        sc_from_mont(rB, rp);
+        tbl_fixed_mul_add(Pp, tbl, tbl.row_Bb(0), rB);
+        ge_compress(cB, Pp);
+        node_hash32(tbl.digest, hB, cB);
+    }
+    // inclusive prefix sums over the lanes: S_t = sum_{u <= t} pad(u) (points and blindings); chain node t = leaf + S_{t-1}
+    ge_p3 S = Pp;
+    sc rs = rp;
+    for (int off = 1; off < 64; off <<= 1) {
+        ge_p3 o, q;
+        sc ro, rq;
+        for (int i = 0; i < FE_NL; i++) {
+            o.X.v[i] = __shfl_up(S.X.v[i], off, 64); o.Y.v[i] = __shfl_up(S.Y.v[i], off, 64);
+            o.Z.v[i] = __shfl_up(S.Z.v[i], off, 64); o.T.v[i] = __shfl_up(S.T.v[i], off, 64);
+        }
+        for (int i = 0; i < 8; i++) ro.v[i] = (uint32_t)__shfl_up((int)rs.v[i], off, 64);
+        if (t >= off) { ge_add(q, S, o); S = q; sc_add(rq, rs, ro); rs = rq; }
+    }
+    ge_p3 E;                                        // exclusive: S_{t-1}
+    sc re;
+    for (int i = 0; i < FE_NL; i++) {
+        E.X.v[i] = __shfl_up(S.X.v[i], 1, 64); E.Y.v[i] = __shfl_up(S.Y.v[i], 1, 64);
+        E.Z.v[i] = __shfl_up(S.Z.v[i], 1, 64); E.T.v[i] = __shfl_up(S.T.v[i], 1, 64);
+    }
+    for (int i = 0; i < 8; i++) re.v[i] = (uint32_t)__shfl_up((int)rs.v[i], 1, 64);
+    if (t >= m) return;
+    ge_p3 N;
+    sc rn;
+    if (t == 0) { N = P0; rn = r0; }
+    else { ge_add(N, P0, E); sc_add(rn, r0, re); }
+    uint32_t cN[8], hN[8], rN[8];
+    ge_compress(cN, N);
+    sc_from_mont(rN, rn);
+    const LevelView L = views[t];
+    const size_t d = np[t];
+    L.idx[d] = x >> t;
+    L.v[d] = I.v[j];
+    st8(L.r + d * 8, t == 0 ? rl : rN);             // a leaf keeps its blinding as given (possibly >= l); parents hold the reduced sum
+    st8(L.C + d * 8, cN);
+    if (t == 0) { node_hash32(tbl.digest, hN, cN); st8(L.H + d * 8, hN); }       // (parents' hashes: k_tree_upd_hash, level by level)
+    L.has_pad[d] = has_pad ? 1 : 0;
+    if (has_pad) { st8(L.padC + d * 8, cB); st8(L.padH + d * 8, hB); st8(L.padr + d * 8, rB); }
+    L.parent[d] = np[t + 1];
+    uint32_t* pos = I.pos + j * (size_t)(I.height + 1);
+    pos[t] = (uint32_t)d;
+    if (t == m - 1) {
+        // the sibling S of the chain's top node is real and adjacent in the sorted level; its padding sibling goes away
+        const size_t s = ((x >> t) & 1ull) ? d - 1 : d + 1;
+        uint32_t oc[8], orr[8];
+        ld8(oc, L.padC + s * 8);
+        ld8(orr, L.padr + s * 8);
+        L.has_pad[s] = 0;
+        ge_p3 po, npo, dd;
+        (void)ge_decompress(po, oc);
+        ge_neg(npo, po);
+        ge_add(dd, N, npo);
+        st_p3(I.dP + j * 40, dd);
+        sc mo, md;
+        sc_to_mont(mo, orr);
+        sc_sub(md, rn, mo);
+        for (int i = 0; i < 8; i++) I.dr[j * 8 + i] = md.v[i];
+        I.dv[j] = I.v[j];
+        // positions of the existing ancestors, by the (already moved) parent pointers
+        size_t p = np[m];
+        pos[m] = (uint32_t)p;
+        for (int q = m; q < I.height; q++) { p = views[q].parent[p]; pos[q + 1] = (uint32_t)p; }
     }
 }
 

@@ -155,6 +155,9 @@ int32_t dapol_tree_destroy(dapol_tree* tree);
  * are keyed by position, so the reference test's build-vs-update root equality, src/tests.rs:48, holds exactly).
  * Only for trees from dapol_tree_build / dapol_tree_build_shard.  On error the tree is unchanged. */
 int32_t dapol_tree_update(dapol_tree* tree, size_t k, const uint64_t* leaf_idx, const uint64_t* v, const uint8_t* r32);
+/* What the last dapol_tree_update on this tree did: 0 = rebuilt, 1 = replaced existing leaves in place, 2 = inserted new leaves in
+ * place, 3 = both (diagnostics; the tree is the same whichever path ran). */
+int32_t dapol_tree_last_update_path(dapol_tree* tree, int32_t* path);
 /* Dapol::root_raw / Dapol::root (src/dapol/mod.rs:134-141). Any out pointer may be NULL. */
 int32_t dapol_tree_root(dapol_tree* tree, uint8_t C32[32], uint8_t H32[32], uint64_t* v, uint8_t r32[32]);
 int32_t dapol_tree_node_count(dapol_tree* tree, uint64_t* real_nodes, uint64_t* padding_nodes);

@@ -320,6 +320,76 @@ def test_incremental_update_equals_build_every_level(gpu_ctx, hip_lib, k):
     want.close()
 
 
+@pytest.mark.parametrize("k_new,k_old", [(1, 0), (5, 0), (64, 0), (300, 40), (3, 3)])
+def test_incremental_insert_equals_build_every_level(gpu_ctx, hip_lib, k_new, k_old):
+    """dapol_tree_update with NEW indexes (what the reference's update loop does, src/tests.rs:41-48: the tree grows leaf by leaf):
+    the levels that gain nodes are rewritten in order on the device, the new chains and their padding siblings are made, the
+    padding node the chain replaces goes away, and the existing ancestors move by a delta.  The tree must equal dapol_tree_build
+    over the enlarged leaf set at EVERY level -- indexes, values, blindings, commitments, hashes, padding siblings, node counts --
+    also for batches that mix new and existing indexes, and by the rebuild path (DAPOL_NO_INCREMENTAL_INSERT=1)."""
+    import os
+    rng = np.random.default_rng(7000 + 10 * k_new + k_old)
+    height, n = 24, 20000
+    idx_all, v_all, r_all = _rand_leaves(rng, height, n + k_new)
+    na = len(idx_all)                                               # (_rand_leaves drops duplicate indexes)
+    new_sel = rng.choice(na, size=k_new, replace=False)
+    new_sel = np.unique(new_sel)
+    old_mask = np.ones(na, bool)
+    old_mask[new_sel] = False
+    idx0, v0, r0 = idx_all[old_mask], v_all[old_mask], r_all[old_mask]
+    v2, r2 = v_all.copy(), r_all.copy()
+    rep = rng.choice(np.nonzero(old_mask)[0], size=k_old, replace=False) if k_old else np.zeros(0, np.int64)
+    v2[rep] = rng.integers(0, 2**40, size=len(rep), dtype=np.uint64)
+    r2[rep] = rng.integers(0, 256, size=(len(rep), 32), dtype=np.uint8)
+    r2[rep, 31] &= 0x7F
+    want = hip_lib.Tree(gpu_ctx, height, idx_all, v2, r2, SEED)
+    upd = np.concatenate([new_sel, rep])
+    order = rng.permutation(len(upd))
+    for env in ({}, {"DAPOL_NO_INCREMENTAL_INSERT": "1"}):
+        tr = hip_lib.Tree(gpu_ctx, height, idx0, v0, r0, SEED)
+        os.environ.update(env)
+        try:
+            tr.update(idx_all[upd][order], v2[upd][order], r2[upd][order])
+        finally:
+            for key in env:
+                os.environ.pop(key, None)
+        assert tr.root() == want.root() and tr.node_count() == want.node_count(), env
+        assert tr.last_update_path() == (0 if env else (3 if k_old else 2))            # random 24-bit indexes: no two new chains share a node
+        for level in range(height + 1):
+            for a, b in zip(tr.level_nodes(level), want.level_nodes(level)):
+                assert np.array_equal(a, b), (env, level)
+        C, H, pv, pr = tr.paths(idx_all[new_sel][:4])                # the grown tree serves proofs of its new leaves
+        C2, H2, pv2, pr2 = want.paths(idx_all[new_sel][:4])
+        assert np.array_equal(C, C2) and np.array_equal(H, H2) and np.array_equal(pv, pv2) and np.array_equal(pr, pr2)
+        tr.close()
+    want.close()
+
+
+def test_tree_grows_leaf_by_leaf_like_the_reference_test(gpu_ctx, hip_lib, ref):
+    """src/tests.rs:41-48 at its own shape (height 10): a tree grown from one leaf by 60 single-leaf updates -- every one an
+    incremental insert, repeated inserts ping-ponging the level buffers -- equals build() over the same liabilities at every level
+    after every tenth update, and the C oracle's root at the end."""
+    rng = np.random.default_rng(41)
+    height, n = 10, 61
+    idx, v, r = _rand_leaves(rng, height, n)
+    order = rng.permutation(n)
+    tr = hip_lib.Tree(gpu_ctx, height, idx[order[:1]], v[order[:1]], r[order[:1]], SEED)
+    for i in range(1, n):
+        e = order[i:i + 1]
+        tr.update(idx[e], v[e], r[e])
+        assert tr.last_update_path() == 2
+        if i % 10 == 0 or i == n - 1:
+            have = np.sort(order[:i + 1])
+            want = hip_lib.Tree(gpu_ctx, height, idx[have], v[have], r[have], SEED)
+            assert tr.root() == want.root() and tr.node_count() == want.node_count(), i
+            for level in range(height + 1):
+                for a, b in zip(tr.level_nodes(level), want.level_nodes(level)):
+                    assert np.array_equal(a, b), (i, level)
+    t = _ref_tree(ref, height, idx, v, r)
+    assert tr.root() == _ref_root(ref, t)
+    ref.ref_tree_free(t)
+
+
 def test_incremental_update_at_2e20_leaves(gpu_ctx, hip_lib):
     """one leaf and 64 leaves replaced in the headline tree (2^20 leaves, height 32): root, value sum and the
     sampled paths equal a fresh build's; a batch that also holds a NEW index takes the rebuild and still agrees; the in-place
@@ -339,6 +409,7 @@ def test_incremental_update_at_2e20_leaves(gpu_ctx, hip_lib):
         tr.update(idx[sel], v2[sel], r2[sel])                      # warm (scratch allocation)
         t0 = time.perf_counter()
         tr.update(idx[sel], v2[sel], r2[sel])
+        assert tr.last_update_path() == 1
         dt = time.perf_counter() - t0
         assert dt < 0.010, "incremental update of %d leaves took %.2f ms" % (k, dt * 1e3)
     want = hip_lib.Tree(gpu_ctx, height, idx, v2, r2, SEED)
@@ -346,9 +417,12 @@ def test_incremental_update_at_2e20_leaves(gpu_ctx, hip_lib):
     probe = np.concatenate([idx[sel][:8], idx[::n // 8][:8]])
     for a, b in zip(tr.paths(probe), want.paths(probe)):
         assert np.array_equal(a, b)
-    # a new index among the updates: rebuild path, same tree as building from scratch
+    # a new index among the updates: inserted in place (12 levels of 2^20 nodes each move up by one), same tree as building from scratch
     new_idx = np.array([idx[3] + 1, idx[10]], np.uint64)           # idx[3] + 1 is free in the strided layout
+    t0 = time.perf_counter()
     tr.update(new_idx, np.array([77, 88], np.uint64), r[:2])
+    assert tr.last_update_path() == 3
+    assert time.perf_counter() - t0 < 0.060, "incremental insert into the 2^20-leaf tree took %.1f ms" % ((time.perf_counter() - t0) * 1e3)
     i3 = np.concatenate([idx, new_idx[:1]])
     o = np.argsort(i3, kind="stable")
     v3 = np.concatenate([v2, [77]]).astype(np.uint64)
