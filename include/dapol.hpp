@@ -61,6 +61,13 @@ class Context {                                // PedersenGens::default() + Bull
   public:
     // digest = the node hash D of Dapol<D, R>: DAPOL_DIGEST_BLAKE3 or DAPOL_DIGEST_BLAKE2S
     explicit Context(int device = 0, int max_parties = 32, int digest = DAPOL_DIGEST_BLAKE3) { check(dapol_ctx_create(device, max_parties, digest, &h_)); }
+    // ... with settings (dapol_options: zeros = the library's own choices; options.struct_size is filled in here)
+    Context(int device, int max_parties, int digest, dapol_options options) {
+        options.struct_size = (int32_t)sizeof(dapol_options);
+        check(dapol_ctx_create_opts(device, max_parties, digest, &options, &h_));
+    }
+    dapol_options options() const { dapol_options o{}; check(dapol_ctx_get_options(h_, &o)); return o; }
+    void set_options(dapol_options o) { o.struct_size = (int32_t)sizeof(dapol_options); check(dapol_ctx_set_options(h_, &o)); }
     ~Context() { dapol_ctx_destroy(h_); }
     Context(const Context&) = delete;
     Context& operator=(const Context&) = delete;
