@@ -102,6 +102,11 @@ struct dapol_ctx {
     hipStream_t stream = nullptr;
     hipStream_t side[3] = {nullptr, nullptr, nullptr};   // further pipelines of the range prover (several chunks in flight)
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    // Opt-in experiment (DAPOL_MSM_SERIAL=1, measured slower): the generator-stationary MSMs of ALL chunks in flight through ONE
+    // stream, one sweep at a time, the other chunks' scalar kernels beside it.  ev_msm_pre / _post[chunk lane] order a chunk's own
+    // stream around its MSMs.
+    hipStream_t msm_stream = nullptr;
+    hipEvent_t ev_msm_pre[4] = {nullptr, nullptr, nullptr, nullptr}, ev_msm_post[4] = {nullptr, nullptr, nullptr, nullptr};
     DevBuf<int32_t> table;       // window tables
     DevBuf<uint32_t> gens_comp;  // compressed base points of every row (for dapol_ctx_generator)
     TableView tv{};
@@ -201,6 +206,11 @@ int32_t dapol_ctx_create_opts(int32_t device, int32_t max_parties, int32_t diges
         HIPCHK(hipStreamCreate(&c->side[i]));
         HIPCHK(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
     }
+    HIPCHK(hipStreamCreate(&c->msm_stream));
+    for (int i = 0; i < 4; i++) {
+        HIPCHK(hipEventCreateWithFlags(&c->ev_msm_pre[i], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_msm_post[i], hipEventDisableTiming));
+    }
     const int P = max_parties;
     // window width: the widest (<= 17 bits: wider measured slower, profiles/r01_wbits_ab4.txt) whose tables fit the budget --
     // DAPOL_TABLE_GB if set, else 40 GB but never more than 30 % of the memory that is free right now (a second context on
@@ -282,6 +292,11 @@ int32_t dapol_ctx_destroy(dapol_ctx* ctx) {
         if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
     }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->msm_stream) (void)hipStreamDestroy(ctx->msm_stream);
+    for (int i = 0; i < 4; i++) {
+        if (ctx->ev_msm_pre[i]) (void)hipEventDestroy(ctx->ev_msm_pre[i]);
+        if (ctx->ev_msm_post[i]) (void)hipEventDestroy(ctx->ev_msm_post[i]);
+    }
     delete ctx;
     return DAPOL_OK;
 }

@@ -1195,6 +1195,7 @@ def test_every_proving_strategy_gives_the_same_bytes(gpu_ctx, n_bits, m):
                 # the generator-stationary sweep of large calls (kernels_range_gs.h), forced onto this small batch
                 {"DAPOL_GS": "1", "DAPOL_NO_SPLIT": "1"}, {"DAPOL_GS": "1", "DAPOL_NO_SPLIT": "1", "DAPOL_GS_TILE": "4"},
                 {"DAPOL_GS": "1", "DAPOL_NO_SPLIT": "1", "DAPOL_GS_TILE": "64", "DAPOL_CHUNK": "16", "DAPOL_STREAMS": "2"},
+                {"DAPOL_GS": "1", "DAPOL_NO_SPLIT": "1", "DAPOL_CHUNK": "16", "DAPOL_STREAMS": "2", "DAPOL_MSM_SERIAL": "1"},
                 {"DAPOL_GS": "1", "DAPOL_NO_SPLIT": "1", "DAPOL_NO_TAIL": "1"}, {"DAPOL_GS": "1", "DAPOL_NO_SPLIT": "1", "DAPOL_CHUNK": "5", "DAPOL_TAIL_N": "32"},
                 {"DAPOL_QUAD_MAX_WAVES": "1000000"}, {"DAPOL_QUAD_MAX_WAVES": "1000000", "DAPOL_SMALL_TAIL": "1"}, {"DAPOL_QUAD_MAX_WAVES": "1000000", "DAPOL_SMALL_SPLIT": "8"}):
         os.environ.update(env)
@@ -1230,6 +1231,17 @@ def test_options_struct_and_env_knob_gate(hip_lib):
         assert ctx.range_prove_batch(n_bits, m, v, r, nonce_seed=SEED, stream_id=sid).tobytes() == base
         got = ctx.get_options()
         assert got.window_bits == 12 and got.gs_tile_rows == opt.gs_tile_rows and got.tail_length == opt.tail_length      # creation-time fields stay
+    # the fields really select the schedule: the workload's statistics count the dominant kernel's launches per bracketed MSM
+    idx, vv, rr = _rand_leaves(np.random.default_rng(9), 8, 40)
+    w = hip_lib.Workload(ctx, 8, idx, vv, rr)
+    w.build(SEED)
+    ctx.set_options(hip_lib.Options(generator_stationary=1, small_call_max=1, gs_tile_rows=8))
+    st_gs = w.prove(SEED, 64)
+    ctx.set_options(hip_lib.Options(generator_stationary=-1, small_call_max=1))
+    st_ps = w.prove(SEED, 64)
+    assert st_gs.msm_kernels == st_gs.msm_launches * 2 * (512 // 8) and st_ps.msm_kernels == st_ps.msm_launches      # N = 8 x 64 terms per list
+    assert st_gs.checksum == st_ps.checksum
+    ctx.set_options(hip_lib.Options())
     with pytest.raises(hip_lib.DapolError):
         ctx.set_options(hip_lib.Options(gs_tile_rows=6))
     with pytest.raises(hip_lib.DapolError):
