@@ -296,8 +296,8 @@ __global__ __launch_bounds__(64) void k_rp_A(RangeArgs A, TableView tbl) {
 // A list (L or R of one proof) is owned by LPL lanes; a lane walks the nwin signed W-bit windows from the top with W shared
 // doublings per window (Straus) and, per window, its terms of the list: digit -> one 128-byte entry of the generator's table row
 // (a random HBM line: the rows of a 17-bit table are 8.4 MB each, 35 GB in all) -> one mixed addition.  The lanes' partial sums
-// meet in a shuffle reduction (wave_reduce_point: no LDS, no barrier).  This is the form of calls BELOW one full chunk -- mid-size
-// and small calls, the tail argument over a proof's own tables, the verifier's generator MSM; calls of at least one full chunk run
+// meet in a shuffle reduction (wave_reduce_point: no LDS, no barrier).  This is the form of calls of fewer than 8,192 proofs -- mid-size
+// and small calls --, of the tail argument over a proof's own tables and of the verifier's generator MSM; calls of at least 8,192 proofs run
 // the plain rounds and the materialisation generator-stationary instead (kernels_range_gs.h), which reads the same table rows
 // out of the Infinity Cache.
 #ifndef DAPOL_MSM_OCC

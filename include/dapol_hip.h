@@ -82,7 +82,7 @@ typedef struct {
     int32_t window_bits;              /* creation: width of the fixed-base windows, 8..20 (0: widest <= 17 whose tables fit table_gb) */
     double  table_gb;                 /* creation: budget of the window tables in GB (0: 40 GB, at most 30 % of the free memory) */
     int32_t high_half_rows;           /* creation: 0 auto, 1 on, -1 off: second table row per generator (halves the window steps of lanes that cannot share doublings) */
-    int32_t generator_stationary;     /* 0 auto (calls of >= one full chunk), 1 every call that is not a small one, -1 never */
+    int32_t generator_stationary;     /* 0 auto (calls of >= 8,192 proofs), 1 every call that is not a small one, -1 never */
     int32_t gs_tile_rows;             /* rows per launch of the generator-stationary sweep (multiple of 4; 0: 16) */
     int32_t streams;                  /* chunks in flight, 1..4 (0: 2) */
     int64_t chunk_proofs;             /* proofs per chunk (0: whole rounds of resident wavefronts, 65,536 on MI355X) */
