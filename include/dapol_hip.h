@@ -88,7 +88,7 @@ typedef struct {
     int64_t chunk_proofs;             /* proofs per chunk (0: whole rounds of resident wavefronts, 65,536 on MI355X) */
     double  scratch_gb;               /* scratch budget of the range prover / verifier in GB (0: 130 GB, at most what is free beyond 8 GB) */
     int32_t tail_length;              /* length T of the hybrid inner-product argument's tail: 32 / 64 / 128 / 256, -1 = no tail (0: 64) */
-    int32_t small_call_max;           /* calls of up to this many proofs take the latency shapes (0: 4,096) */
+    int32_t small_call_max;           /* calls of up to this many proofs take the latency shapes (0: 8,191) */
     int32_t verify_batch_min;         /* fewest proofs the verifier checks as ONE random linear combination (0: 112) */
     int64_t update_incremental_max;   /* dapol_tree_update: most replaced leaves re-merged in place (0: 65,536; -1: always rebuild) */
 } dapol_options;

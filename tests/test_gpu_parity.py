@@ -1259,6 +1259,31 @@ def test_options_struct_and_env_knob_gate(hip_lib):
         L.dapol_env_knobs(old)
 
 
+def test_call_size_regimes_give_the_same_bytes(gpu_ctx, hip_lib):
+    """The three regimes of a prove call -- latency shapes (up to 8,191 proofs), the generator-stationary sweep (from 8,192), and the
+    proof-stationary throughput shapes they replace -- at the sizes where one hands over to the next: 5,000 and 8,192 proofs of 64 bits
+    x 32 parties, each under its default and forced into the other regimes; one digest per setting."""
+    import hashlib
+    import os
+    n_bits, m = 64, 32
+    for b, envs in ((5000, ({}, {"DAPOL_NO_SPLIT": "1"}, {"DAPOL_GS": "1", "DAPOL_SMALL_MAX": "4096"})),
+                    (8192, ({}, {"DAPOL_GS": "0"}, {"DAPOL_SMALL_MAX": "8192"}))):
+        rng = np.random.default_rng(b)
+        v = rng.integers(0, 2**63, size=(b, m), dtype=np.uint64)
+        r = rng.integers(0, 256, size=(b, m, 32), dtype=np.uint8)
+        r[:, :, 31] &= 0x0F
+        sid = np.arange(b, dtype=np.uint64)
+        digests = set()
+        for env in envs:
+            os.environ.update(env)
+            try:
+                digests.add(hashlib.sha256(gpu_ctx.range_prove_batch(n_bits, m, v, r, nonce_seed=SEED, stream_id=sid).tobytes()).hexdigest())
+            finally:
+                for k in env:
+                    os.environ.pop(k, None)
+        assert len(digests) == 1, b
+
+
 # ------------------------------------------------------------------------------- soundness of the cross-proof batch check
 def _forged_cancelling_pair(pyref, seed):
     """Two 8-bit, one-party proofs that are each INVALID but whose residuals cancel in a random linear combination whose
