@@ -4,8 +4,15 @@
 //   index      = first of  idx_k = be64(D^k(index_seed)[..8]) >> (64 - height), k = 1..128, not taken yet (:408-441)
 //   blinding   = Scalar::from_bits(D(audit_id || "blind_seed" || external_id))  (:377-385)
 // The hashing is embarrassingly parallel.  "Not taken yet" is order dependent in the reference (an entity only
-// competes with the entities BEFORE it in the input), so the rare colliders are resolved by one lane in input
-// order -- exactly the sequential semantics -- while everybody else keeps its first candidate.
+// competes with the entities BEFORE it in the input).  That order is kept WITHOUT walking the entities one by one
+// (k_leaf_claim_first / k_leaf_settle below): every entity claims its candidate in a table of slots whose owner can
+// only become an EARLIER entity (atomicMin on the input position); an entity that finds its slot owned by an earlier
+// one moves to its next candidate; repeat until nobody moves.  Every move is forced by an earlier entity that holds
+// the slot for good (it leaves only for one earlier still), so each entity walks a prefix of the walk the sequential
+// loop gives it, and the fixed point is the sequential result -- also for the failing entity of FailedToMapIndex
+// (the earliest one that runs out of its 128 candidates).  Near the sparsity bound Dapol::new allows (2^height = 2 n)
+// almost half of the entities collide: the one-lane resolution this replaces took 6.7 s for 2^20 liabilities at
+// height 21 (profiles/r04l_leaf_bound.txt); it remains for height 64 (whose indexes leave no spare key for "empty").
 #pragma once
 #include <hip/hip_runtime.h>
 #include "hash.h"
@@ -172,6 +179,71 @@ __global__ void k_leaf_resolve(LeafArgs A, LeafResolve R) {
         }
         if (!placed) { A.err[2] = 1; A.err[3] = e; return; }  // DapolError::FailedToMapIndex
     }
+}
+
+// ------------------------------------------------------------------------- parallel collision resolution
+struct LeafTable {
+    unsigned long long* key;   // [size] slot index, LEAF_EMPTY_KEY = free (indexes are < 2^63 here: height < 64)
+    uint32_t* owner;           // [size] input position of the earliest entity that has claimed the slot (0xFFFFFFFF: none yet)
+    uint32_t mask;             // size - 1
+    uint32_t* pos;             // [n] table position of the entity's current candidate
+    uint32_t* tries;           // [n] candidates drawn so far (1 = the first)
+    uint32_t* flags;           // [0] somebody moved this round, [1] table full (fall back to the one-lane path)
+};
+#define LEAF_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
+// Claims slot x for entity e; returns the previous owner (> e or 0xFFFFFFFF: e owns it now; < e: an earlier entity does).
+__device__ __forceinline__ uint32_t leaf_claim(const LeafTable& T, uint64_t x, uint32_t e, uint32_t& hp_out) {
+    uint32_t hp = (uint32_t)((x * 0x9E3779B97F4A7C15ull) >> 32) & T.mask;
+    for (uint32_t probes = 0; probes <= T.mask; probes++) {
+        unsigned long long k = T.key[hp];
+        if (k == LEAF_EMPTY_KEY) {
+            k = atomicCAS(&T.key[hp], LEAF_EMPTY_KEY, (unsigned long long)x);
+            if (k == LEAF_EMPTY_KEY) k = x;
+        }
+        if (k == x) { hp_out = hp; return atomicMin(&T.owner[hp], e); }
+        hp = (hp + 1) & T.mask;
+    }
+    atomicOr(&T.flags[1], 1u);
+    hp_out = 0;
+    return 0;                                        // (reads as "lost"; the caller sees flags[1])
+}
+__global__ void k_leaf_claim_first(LeafArgs A, LeafTable T) {
+    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= A.n) return;
+    uint32_t hp;
+    (void)leaf_claim(T, A.cand[e], (uint32_t)e, hp);
+    T.pos[e] = hp;
+    T.tries[e] = 1;
+}
+// One round: every entity whose slot now belongs to an earlier entity draws candidates until it owns one (for now).
+__global__ void k_leaf_settle(LeafArgs A, LeafTable T) {
+    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= A.n) return;
+    if (T.owner[T.pos[e]] == (uint32_t)e) return;
+    uint32_t st[8], tries = T.tries[e], hp = 0;
+    for (int i = 0; i < 8; i++) st[i] = A.idx_state[e * 8 + i];
+    uint64_t x = 0;
+    for (;;) {
+        if (tries >= LEAF_MAX_RETRIES) {             // DapolError::FailedToMapIndex: the earliest such entity is the one the reference stops at
+            atomicOr(&A.err[2], 1u);
+            atomicMin(&A.err[3], (uint32_t)e);
+            break;
+        }
+        Digest d;
+        dg_init(d, A.kind);
+        dg_update_words(d, st, 8);
+        dg_final(d, st);
+        tries++;
+        x = leaf_index_of(st, A.height);
+        const uint32_t prev = leaf_claim(T, x, (uint32_t)e, hp);
+        if (T.flags[1]) break;
+        if (prev > (uint32_t)e) break;               // ours (until an earlier entity comes for it)
+    }
+    for (int i = 0; i < 8; i++) A.idx_state[e * 8 + i] = st[i];
+    A.cand[e] = x;
+    T.pos[e] = hp;
+    T.tries[e] = tries;
+    T.flags[0] = 1;
 }
 
 }  // namespace dapol

@@ -739,6 +739,15 @@ def test_leaf_derivation_near_the_sparsity_bound(gpu_ctx, hip_lib):
     assert np.array_equal(out["v"], vals[order])
     for p in range(0, n, 97):
         assert out["r"][p].tobytes() == want_r[int(order[p])].to_bytes(32, "little")
+    # the one-lane resolution the claim / settle rounds replaced gives the same arrays
+    import os
+    os.environ["DAPOL_LEAF_SERIAL"] = "1"
+    try:
+        ser = gpu_ctx.build_leaf_nodes(list(zip(ids, eids, [int(x) for x in vals])), seed, height, hip_lib.DIGEST_BLAKE2S)
+    finally:
+        os.environ.pop("DAPOL_LEAF_SERIAL", None)
+    for key in ("leaf_idx", "v", "r", "order", "idx_by_entity"):
+        assert np.array_equal(ser[key], out[key]), key
 
 
 def test_leaf_derivation_at_2e20(gpu_ctx, hip_lib, pyref):
