@@ -219,14 +219,17 @@ __global__ void k_leaf_claim_first(LeafArgs A, LeafTable T) {
 __global__ void k_leaf_settle(LeafArgs A, LeafTable T) {
     size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= A.n) return;
+    uint32_t tries = T.tries[e];
+    if (tries > LEAF_MAX_RETRIES) return;            // parked: out of candidates in an earlier round
     if (T.owner[T.pos[e]] == (uint32_t)e) return;
-    uint32_t st[8], tries = T.tries[e], hp = 0;
+    uint32_t st[8], hp = T.pos[e];
     for (int i = 0; i < 8; i++) st[i] = A.idx_state[e * 8 + i];
-    uint64_t x = 0;
+    uint64_t x = A.cand[e];
     for (;;) {
-        if (tries >= LEAF_MAX_RETRIES) {             // DapolError::FailedToMapIndex: the earliest such entity is the one the reference stops at
-            atomicOr(&A.err[2], 1u);
-            atomicMin(&A.err[3], (uint32_t)e);
+        if (tries >= LEAF_MAX_RETRIES) {             // DapolError::FailedToMapIndex.  The entity parks (it holds no slot); the rounds go on
+            atomicOr(&A.err[2], 1u);                 // to the fixed point, so that err[3] ends as the EARLIEST such entity -- the one the
+            atomicMin(&A.err[3], (uint32_t)e);       // reference's loop stops at (the entities before it are where that loop puts them)
+            tries = LEAF_MAX_RETRIES + 1;
             break;
         }
         Digest d;
