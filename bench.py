@@ -88,10 +88,13 @@ def algorithmic_bytes(height, n_bits, log2_n):
     return prove, tree
 
 
-def synth_inputs(n_total, height, first, count):
-    """benches/dapol.rs:160-175 + src/dapol/node.rs:101-105: strided leaves, value = random u32, random blinding."""
+def synth_inputs(n_total, height, first, count, n_bits=64):
+    """benches/dapol.rs:160-175 + src/dapol/node.rs:101-105: strided leaves, value = random u32, random blinding.  (With range proofs
+    narrower than 64 bits the values shrink so that every subtree sum -- what the proofs are about -- stays inside the range.)"""
     rng = np.random.Generator(np.random.PCG64(0xD4901))
     v_all = rng.integers(0, 1 << 32, size=n_total, dtype=np.uint64)
+    if n_bits < 64:
+        v_all %= np.uint64(max(1, min(1 << 32, (1 << n_bits) // max(1, n_total))))
     r_all = rng.integers(0, 256, size=(n_total, 32), dtype=np.uint8)
     r_all[:, 31] &= 0x0F                                         # < 2^252 < l: canonical scalars
     stride = (1 << height) // n_total
@@ -326,7 +329,7 @@ def mode_prove(args):
 
     n_total, n_per_gpu, lg_total, scaling = plan_workload(args, world)
     height, n_bits = args.height, args.n_bits
-    idx, v, r = synth_inputs(n_total, height, rank * n_per_gpu, n_per_gpu)
+    idx, v, r = synth_inputs(n_total, height, rank * n_per_gpu, n_per_gpu, n_bits)
     ctx = capi.Context(local_rank, _np2(height))
     log("context ready (generators + window tables)")
     comm_device = "cuda" if backend == "nccl" else "cpu"
