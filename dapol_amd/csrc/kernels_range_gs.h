@@ -23,77 +23,74 @@
 
 namespace dapol {
 
-// W-bit field of a 256-bit integer (eight words) at bit offset o
-__device__ __forceinline__ uint32_t sc_bits(const uint32_t* x, int o, int W) {
-    const int wd = o >> 5, sh = o & 31;
-    const uint32_t lo = wd < 8 ? x[wd] >> sh : 0u;
-    const uint32_t hi = (sh && wd + 1 < 8) ? (x[wd + 1] << (32 - sh)) : 0u;
-    return (lo | hi) & ((1u << W) - 1);
-}
-// Signed radix-2^W digits of FOUR canonical scalars (the terms at sweep positions 4 * sp4 .. 4 * sp4 + 3 of proof p), one
-// 16-byte store per window.  Same recoding as sc_recode_w.
-__device__ __forceinline__ void write_digits_gs4(const RangeArgs& A, size_t p, size_t sp4, const uint32_t (*c)[8]) {
+// Signed radix-2^W digits of ONE canonical scalar (the term at sweep position sp of proof p): component sp & 3 of the quad's
+// 16-byte element, one 4-byte store per window.  Same recoding as sc_recode_w; the scalar is shifted down a window at a time
+// (static register indexes only).
+__device__ __forceinline__ void write_digits_gs(const RangeArgs& A, size_t p, int sp, const uint32_t* c) {
     const size_t L = A.B * (size_t)A.nwin;
-    dapol_v4i* out = reinterpret_cast<dapol_v4i*>(A.dig) + sp4 * L + p;
+    int32_t* out = reinterpret_cast<int32_t*>(A.dig) + ((((size_t)(sp >> 2)) * L + p) << 2) + (sp & 3);
+    const size_t wstride = A.B * (size_t)4;
     const int W = A.wbits, NW = A.nwin, half = 1 << (W - 1);
-    int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    const uint32_t mask = (1u << W) - 1;
+    uint32_t x[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) x[i] = c[i];
+    int carry = 0;
+#pragma nounroll
     for (int w = 0; w < NW; w++) {
-        const int o = w * W;
-        const bool last = w == NW - 1;
-        int b0 = (int)sc_bits(c[0], o, W) + c0, b1 = (int)sc_bits(c[1], o, W) + c1, b2 = (int)sc_bits(c[2], o, W) + c2, b3 = (int)sc_bits(c[3], o, W) + c3;
-        c0 = (b0 >= half && !last) ? 1 : 0; c1 = (b1 >= half && !last) ? 1 : 0; c2 = (b2 >= half && !last) ? 1 : 0; c3 = (b3 >= half && !last) ? 1 : 0;
-        dapol_v4i d = {b0 - (c0 << W), b1 - (c1 << W), b2 - (c2 << W), b3 - (c3 << W)};
-        out[(size_t)w * A.B] = d;
+        const int b = (int)(x[0] & mask) + carry;
+        carry = (b >= half && w != NW - 1) ? 1 : 0;
+        out[(size_t)w * wstride] = b - (carry << W);
+#pragma unroll
+        for (int i = 0; i < 7; i++) x[i] = (x[i] >> W) | (x[i + 1] << (32 - W));
+        x[7] >>= W;
     }
 }
 
-// Thread -> (proof p, sweep quad): p runs fastest so that the stores above are contiguous over a wavefront.
-// grid = ceil(cb * (2N / 4) / 64) blocks of 64.
-__device__ __forceinline__ bool gs_thread(const RangeArgs& A, size_t& p, size_t& sp4) {
+// Thread -> (proof p, sweep position sp).  The four positions of a quad run fastest: four adjacent lanes read the four scalars
+// of ONE 128-byte line of a proof's vector (the line is fetched once, by one pair of load instructions) and write the four
+// components of ONE 16-byte digit element; then the proofs, so that a wavefront's store is 256 contiguous bytes per window.
+// grid = ceil(cb * 2N / 64) blocks of 64.
+__device__ __forceinline__ bool gs_thread(const RangeArgs& A, size_t& p, int& sp) {
     const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
-    sp4 = t / A.B;
-    p = t - sp4 * A.B;
+    const size_t quad = t >> 2, sp4 = quad / A.B;
+    p = quad - sp4 * A.B;
+    sp = (int)(4 * sp4) + (int)(t & 3);
     return sp4 < (size_t)(2 * A.N) / 4;
 }
 
 // K0 (generator-stationary layout): nonces s_L, s_R + the S commitment's digits
 __global__ __launch_bounds__(64) void k_rp_nonces_gs(RangeArgs A) {
-    size_t p, sp4;
-    if (!gs_thread(A, p, sp4)) return;
-    const int sp = (int)(4 * sp4), side = sp >= A.N ? 1 : 0, q0 = sp - side * A.N;
-    uint32_t c[4][8];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int q = q0 + k, j = q / A.n, ii = q - j * A.n;
-        const uint32_t slot = (uint32_t)(j * (2 * A.n + 2) + 2 + ii + (side ? A.n : 0));
-        sc s;
-        tape_scalar(s, A, p, slot);
-        st_sc((side ? A.s2 : A.s1) + p * A.N + q, s);
-        sc_from_mont(c[k], s);
-    }
-    write_digits_gs4(A, p, sp4, c);
+    size_t p;
+    int sp;
+    if (!gs_thread(A, p, sp)) return;
+    const int side = sp >= A.N ? 1 : 0, q = sp - side * A.N;
+    const int j = q / A.n, ii = q - j * A.n;
+    const uint32_t slot = (uint32_t)(j * (2 * A.n + 2) + 2 + ii + (side ? A.n : 0));
+    sc s;
+    tape_scalar(s, A, p, slot);
+    st_sc((side ? A.s2 : A.s1) + p * A.N + q, s);
+    uint32_t c[8];
+    sc_from_mont(c, s);
+    write_digits_gs(A, p, sp, c);
 }
 
 // K5 (generator-stationary layout): round-k MSM scalars -> digits
 __global__ __launch_bounds__(64) void k_rp_round_prep_gs(RangeArgs A, int round) {
-    size_t p, sp4;
-    if (!gs_thread(A, p, sp4)) return;
-    const int sp = (int)(4 * sp4), side = sp >= A.N ? 1 : 0, q0 = sp - side * A.N;
+    size_t p;
+    int sp;
+    if (!gs_thread(A, p, sp)) return;
+    const int side = sp >= A.N ? 1 : 0, q = sp - side * A.N;
     const int lgh = A.lgN - 1 - round, half = 1 << lgh;
-    uint32_t c[4][8];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        bool isH;
-        const int j = term_generator(round, A.N, A.lgN, side, q0 + k, isH);
-        const int off = j & (half - 1);
-        const bool upper = (j >> lgh) & 1;
-        const int vi = upper ? off : off + half;       // G_R pairs with a_L, G_L with a_R; H'_L with b_R, H'_R with b_L
-        sc v, pr;
-        ld_sc(v, (isH ? A.b : A.a) + p * A.N + vi);
-        coeff_times(pr, A, p, round, j, isH, v);       // the canonical product a_i * s_j (coefficient tables or vectors)
-        for (int i = 0; i < 8; i++) c[k][i] = pr.v[i];
-    }
-    write_digits_gs4(A, p, sp4, c);
+    bool isH;
+    const int j = term_generator(round, A.N, A.lgN, side, q, isH);
+    const int off = j & (half - 1);
+    const bool upper = (j >> lgh) & 1;
+    const int vi = upper ? off : off + half;           // G_R pairs with a_L, G_L with a_R; H'_L with b_R, H'_R with b_L
+    sc v, pr;
+    ld_sc(v, (isH ? A.b : A.a) + p * A.N + vi);
+    coeff_times(pr, A, p, round, j, isH, v);           // the canonical product a_i * s_j (coefficient tables or vectors)
+    write_digits_gs(A, p, sp, pr.v);
 }
 
 // The sweep: rows q0 .. q0 + nq - 1 (terms of list `side`, nq a multiple of 4) added into every accumulator lane.
@@ -133,11 +130,15 @@ __global__ __launch_bounds__(64, 4) void k_rp_msm_gs(RangeArgs A, TableView tbl,
     }
 }
 
-// P_side[p] = sum_w 2^(W w) * acc[w * cb + p]: Horner from the top window, one lane per proof.
-__global__ __launch_bounds__(64) void k_rp_gs_combine(RangeArgs A, int side, const int32_t* __restrict__ accs) {
+// P_side[p] = sum_w 2^(W w) * acc_side[w * cb + p]: Horner from the top window, one lane per (side, proof) -- both lists of a
+// round in one launch (accs: the two sides' accumulators, side_words apart).
+__global__ __launch_bounds__(64) void k_rp_gs_combine(RangeArgs A, const int32_t* __restrict__ accs, size_t side_words) {
     const size_t L = A.B * (size_t)A.nwin;
-    const size_t p = (size_t)blockIdx.x * 64 + threadIdx.x;
-    if (p >= A.B) return;
+    const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (t >= 2 * A.B) return;
+    const int side = t >= A.B ? 1 : 0;
+    const size_t p = t - (size_t)side * A.B;
+    accs += (size_t)side * side_words;
     auto load = [&](ge_p3& r, int w) {
         const int32_t* ap = accs + (size_t)w * A.B + p;
         for (int i = 0; i < FE_NL; i++) {
@@ -145,14 +146,14 @@ __global__ __launch_bounds__(64) void k_rp_gs_combine(RangeArgs A, int side, con
             r.Z.v[i] = ap[(size_t)(2 * FE_NL + i) * L]; r.T.v[i] = ap[(size_t)(3 * FE_NL + i) * L];
         }
     };
-    ge_p3 acc, t, r;
+    ge_p3 acc, t2, r;
     load(acc, A.nwin - 1);
 #pragma nounroll
     for (int w = A.nwin - 2; w >= 0; w--) {
 #pragma nounroll
         for (int d = 0; d < A.wbits; d++) ge_dbl(acc, acc, d == A.wbits - 1);
-        load(t, w);
-        ge_add(r, acc, t);
+        load(t2, w);
+        ge_add(r, acc, t2);
         acc = r;
     }
     st_p3((side ? A.P1 : A.P0) + p * 40, acc);
@@ -167,20 +168,16 @@ __global__ __launch_bounds__(64) void k_rp_gs_combine(RangeArgs A, int side, con
 // Digits: sweep position sp = side * N + i * (N / T) + k  <->  term q = i + k T, same dig4 layout as above.
 enum { MAT_GROUP = 16 };
 
-// grid = ceil(cb * (2N / 4) / 64) blocks of 64
+// grid = ceil(cb * 2N / 64) blocks of 64
 __global__ __launch_bounds__(64) void k_rp_mat_prep_gs(RangeArgs A) {
-    size_t p, sp4;
-    if (!gs_thread(A, p, sp4)) return;
-    const int sp = (int)(4 * sp4), side = sp >= A.N ? 1 : 0, rem = sp - side * A.N;
-    const int per = A.N / A.tail_n, cls = rem / per, k0 = rem - cls * per;
-    uint32_t c[4][8];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        sc s;
-        coeff_plain(s, A, p, A.mat_round, cls + (k0 + k) * A.tail_n, side != 0);   // plain form
-        for (int i = 0; i < 8; i++) c[k][i] = s.v[i];
-    }
-    write_digits_gs4(A, p, sp4, c);
+    size_t p;
+    int sp;
+    if (!gs_thread(A, p, sp)) return;
+    const int side = sp >= A.N ? 1 : 0, rem = sp - side * A.N;
+    const int per = A.N / A.tail_n, cls = rem / per, k = rem - cls * per;
+    sc s;
+    coeff_plain(s, A, p, A.mat_round, cls + k * A.tail_n, side != 0);          // plain form
+    write_digits_gs(A, p, sp, s.v);
 }
 
 // One class, one half (0: the generators' own rows, digits of window w; 1: their high-half rows, digits of window w + LW).
