@@ -246,8 +246,8 @@ def plan_steps(steps_req, warm_req, t_step, seconds_left):
 def plan_workload(args, world):
     """(entities in total, per GPU, log2 of the total, "strong" | "weak").  The metric is quoted on 2^20 leaves at 1 / 2 / 4 / 8
     GPUs, so the TOTAL is what --log2-entities (default 20) or --log2-entities-total names and N > 1 divides it (strong
-    scaling); --weak keeps 2^--log2-entities per GPU.  At N = 1 the two are the same thing (reported as "weak": per-GPU work
-    fixed, as the contract's default)."""
+    scaling); --weak keeps 2^--log2-entities per GPU.  At N = 1 the two are the same workload; the label is the one of the SERIES
+    the line belongs to, so that the lines of N = 1, 2, 4, 8 agree: "strong" unless --weak."""
     if world & (world - 1):
         raise SystemExit("the number of GPUs must be a power of two (each rank owns one top-level subtree)")
     if args.weak and args.log2_entities_total is None:
@@ -257,7 +257,7 @@ def plan_workload(args, world):
     n_total = 1 << lg_total
     if n_total % world or n_total // world < 1:
         raise SystemExit("2^%d entities cannot be divided over %d GPUs" % (lg_total, world))
-    return n_total, n_total // world, lg_total, ("strong" if world > 1 else "weak")
+    return n_total, n_total // world, lg_total, "strong"
 
 
 def kernel_src_sha():
@@ -775,7 +775,7 @@ def mode_verify(args):
         if B_total % world:
             raise SystemExit("--verify-proofs must be a multiple of the number of GPUs")
         B = B_total // world
-    scaling = "weak" if (args.weak or world == 1) else "strong"
+    scaling = "weak" if args.weak else "strong"
     ctx = capi.Context(local_rank, m)
     comm_device = "cuda" if backend == "nccl" else "cpu"
     comm, comm_ranks, comm_err = (None, None, None)

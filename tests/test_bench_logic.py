@@ -19,7 +19,7 @@ def _args(**kw):
 def test_default_workload_is_the_metrics_configuration_at_every_n():
     """BASELINE.json: "2^20 leaves, 1/2/4/8 GPU" -- the total stays 2^20 and N divides it (strong scaling); configs[3] is
     --log2-entities-total 22 on 8 GPUs; --weak keeps the per-GPU size instead."""
-    assert bench.plan_workload(_args(), 1) == (1 << 20, 1 << 20, 20, "weak")
+    assert bench.plan_workload(_args(), 1) == (1 << 20, 1 << 20, 20, "strong")       # the label of the series: N = 1, 2, 4, 8 agree
     for n in (2, 4, 8):
         assert bench.plan_workload(_args(), n) == (1 << 20, (1 << 20) // n, 20, "strong")
     assert bench.plan_workload(_args(log2_entities_total=22), 8) == (1 << 22, 1 << 19, 22, "strong")
