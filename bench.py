@@ -788,10 +788,17 @@ def mode_verify(args):
                 reduce_path = "dapol_comm_allreduce_u64 MIN (ncclAllReduce inside libdapol_hip.so)"
 
     def verdict_and(all_ok):
+        nonlocal comm, comm_ranks, comm_err, reduce_path
         if world == 1:
             return all_ok
         if comm is not None:
-            return int(comm.allreduce([all_ok], capi.REDUCE_MIN)[0])
+            try:
+                return int(comm.allreduce([all_ok], capi.REDUCE_MIN)[0])
+            except capi.DapolError as e:                  # a failed collective fails on every rank: abort (never destroy) and switch together
+                comm_err = repr(e)
+                comm.abort()
+                comm, comm_ranks = None, None
+                reduce_path = "torch.distributed all_reduce MIN (%s), after the library's collective failed" % ("RCCL" if comm_device == "cuda" else "gloo")
         t = torch.tensor([all_ok], dtype=torch.int64, device=comm_device)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return int(t.item())

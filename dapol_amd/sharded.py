@@ -119,13 +119,28 @@ class ShardedProver:
         if self.comm is not None:
             self.exchange_path = "dapol_shard_exchange (ncclAllGather inside libdapol_hip.so)"
 
+    def _drop_comm(self, err):
+        """A collective of the library's communicator failed mid-run (it timed out or RCCL reported an asynchronous error):
+        abort the communicator -- never destroy it, a destroy waits for peers -- and carry on over torch.distributed.  A failed
+        collective fails on every rank of it (same call, same deadline), so the ranks switch together."""
+        self.comm_error = repr(err)
+        try:
+            self.comm.abort()
+        except Exception:
+            pass
+        self.comm, self.comm_ranks = None, None
+        self.exchange_path = "torch.distributed all_gather (%s), after the library's collective failed" % ("RCCL" if self.comm_device == "cuda" else "gloo")
+
     def _exchange(self, root):
         if self.world == 1:
             self.root, self.upper = root, None
             return
         if self.comm is not None:
-            self.root, self.upper = self.comm.exchange(root)                                             # RCCL over xGMI, in the library
-            return
+            try:
+                self.root, self.upper = self.comm.exchange(root)                                         # RCCL over xGMI, in the library
+                return
+            except capi.DapolError as e:
+                self._drop_comm(e)
         buf = exchange_records(self.dist, self.torch, pack_record(root), self.world, self.comm_device)
         recs = unpack_records(buf, self.world)
         self.root, self.upper = top_levels(self.ctx, recs, self.rank)
@@ -139,12 +154,16 @@ class ShardedProver:
             root, st = self.w.build(pad_seed)
             self._exchange(root)
             st = self.w.prove(nonce_seed, n_bits, upper=self.upper, stats=st)
+        local = st.checksum
         if self.world > 1 and self.comm is not None:
-            st.checksum = int(self.comm.allreduce([st.checksum], capi.REDUCE_SUM)[0])                    # ncclAllReduce, wrapping sum
-        elif self.world > 1:
+            try:
+                st.checksum = int(self.comm.allreduce([local], capi.REDUCE_SUM)[0])                      # ncclAllReduce, wrapping sum
+            except capi.DapolError as e:
+                self._drop_comm(e)
+        if self.world > 1 and self.comm is None:
             t = self.torch
             # final reduce of the aggregated proof transcript checksum (wrapping 64-bit sum, carried as two 32-bit halves)
-            cs = t.tensor([st.checksum & 0xFFFFFFFF, st.checksum >> 32], dtype=t.int64, device=self.comm_device)
+            cs = t.tensor([local & 0xFFFFFFFF, local >> 32], dtype=t.int64, device=self.comm_device)
             self.dist.all_reduce(cs)
             st.checksum = (int(cs[0].item()) + (int(cs[1].item()) << 32)) & 0xFFFFFFFFFFFFFFFF
         return st

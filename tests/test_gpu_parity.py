@@ -492,6 +492,67 @@ def test_sharded_equals_single_gpu(gpu_ctx, hip_lib, shard_bits):
         assert pC.tobytes() == fC[sel].tobytes() and pH.tobytes() == fH[sel].tobytes()
 
 
+def test_sharded_prover_falls_back_when_a_library_collective_fails(gpu_ctx, hip_lib):
+    """A collective of the library's communicator that fails mid-run (DapolError out of dapol_shard_exchange /
+    dapol_comm_allreduce_u64: a timeout, an asynchronous RCCL error) aborts that communicator -- never destroys it -- and the step
+    completes over torch.distributed: same root as the single-GPU tree, the checksum reduced over the other transport."""
+    import torch
+    from dapol_amd import sharded
+    height, n_bits = 7, 8
+    rng = np.random.default_rng(77)
+    idx = np.sort(np.concatenate([rng.choice(1 << (height - 1), size=3, replace=False).astype(np.uint64) + np.uint64(s << (height - 1)) for s in range(2)]))
+    v = rng.integers(0, 4, size=len(idx), dtype=np.uint64)
+    r = rng.integers(0, 256, size=(len(idx), 32), dtype=np.uint8)
+    r[:, 31] &= 0x0F
+    full = hip_lib.Tree(gpu_ctx, height, idx, v, r, SEED)
+    sel = (idx >> np.uint64(height - 1)) == 0
+    rec1 = sharded.pack_record(hip_lib.Tree(gpu_ctx, height, idx[~sel], v[~sel], r[~sel], SEED, shard_bits=1).root())
+
+    class Dist:                                          # a two-rank group whose other rank is replayed
+        def __init__(self, other):
+            self.other = other
+
+        def all_gather(self, out, mine):
+            out[0].copy_(mine)
+            out[1].copy_(torch.from_numpy(rec1))
+
+        def all_reduce(self, t, op=None):
+            t += torch.tensor(self.other, dtype=t.dtype)
+
+    class BadComm:
+        def __init__(self, fail_exchange):
+            self.fail_exchange, self.aborted, self.good = fail_exchange, False, None
+
+        def exchange(self, root):
+            if self.fail_exchange:
+                raise hip_lib.DapolError(17, "ncclAllGather did not complete within the deadline")
+            recs = sharded.unpack_records(np.stack([sharded.pack_record(root), rec1]), 2)
+            return sharded.top_levels(gpu_ctx, recs, 0)
+
+        def allreduce(self, words, op=None):
+            raise hip_lib.DapolError(17, "ncclAllReduce: unhandled system error")
+
+        def abort(self):
+            self.aborted = True
+
+    def run(comm, other):
+        p = sharded.ShardedProver(gpu_ctx, height, idx[sel], v[sel], r[sel], rank=0, world=2, dist=Dist(other), torch=torch, comm_device="cpu")
+        p.comm = comm
+        return p, p.step(SEED, SEED, n_bits)
+
+    p0, st0 = run(None, [0, 0])                          # the torch.distributed transport from the start: this rank's own checksum
+    assert p0.root == full.root()
+    for fail_exchange in (True, False):                  # the exchange fails / the exchange works and the final reduce fails
+        bad = BadComm(fail_exchange)
+        p, st = run(bad, [5, 7])
+        assert bad.aborted and p.comm is None and p.comm_ranks is None
+        assert "failed" in p.exchange_path and "nccl" in p.comm_error
+        assert p.root == full.root()
+        assert st.checksum == (st0.checksum + 5 + (7 << 32)) & 0xFFFFFFFFFFFFFFFF
+        st2 = p.step(SEED, SEED, n_bits)                 # and the next step stays on the fallback
+        assert st2.checksum == st.checksum and p.root == full.root()
+
+
 # ------------------------------------------------------------------------------------------------ workload (bench path)
 def test_padding_nodes_and_empty_shard(gpu_ctx, hip_lib, pyref):
     """Paddable::padding as an entry point: equals the oracle's positional padding node and the node the tree builder
