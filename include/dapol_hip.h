@@ -313,7 +313,11 @@ int32_t dapol_verify_batch_checked(dapol_ctx* ctx, int32_t height, size_t k, con
  *                          (ncclCommInitRankConfig, blocking = 0) and polled with ncclCommGetAsyncError.
  *   dapol_comm_create_timeout  ... up to a deadline: a communicator that has not come up after timeout_ms is aborted
  *                          (ncclCommAbort) and the call returns DAPOL_ERR_COMM, so that one absent rank cannot hang the others
- *                          inside ncclCommInitRank for good; timeout_ms <= 0 waits without a deadline.
+ *                          inside ncclCommInitRank for good; timeout_ms <= 0 waits without a deadline.  The communicator keeps
+ *                          the deadline for its COLLECTIVES: a dapol_shard_exchange / dapol_comm_allreduce_u64 that has not
+ *                          completed after timeout_ms, or during which RCCL reports an asynchronous error, aborts the
+ *                          communicator (which ends an RCCL kernel waiting for a peer), returns DAPOL_ERR_COMM, and every
+ *                          later call on the handle fails at once -- the host falls back to another transport or exits.
  *   dapol_comm_abort       the failure path (ncclCommAbort): tear down without waiting for the peers, once the ranks have
  *                          agreed not to use this communicator; dapol_comm_destroy is the orderly end (finalize + destroy).
  *   dapol_comm_count       the number of ranks as RCCL reports it (ncclCommCount)

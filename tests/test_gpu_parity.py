@@ -1752,6 +1752,15 @@ def test_rccl_exchange_one_rank_and_top_levels(gpu_ctx, hip_lib):
     assert comm.allreduce([5, 2**64 - 1]).tolist() == [5, 2**64 - 1]
     assert comm.allreduce([7], hip_lib.REDUCE_MIN).tolist() == [7]
     comm.close()
+    # ... and created with a deadline, which its collectives then keep (completion polled on an event, the communicator's
+    # asynchronous state watched meanwhile; on expiry the communicator is aborted and the call returns DAPOL_ERR_COMM)
+    comm = hip_lib.Comm(gpu_ctx, hip_lib.comm_unique_id(), 0, 1, timeout_s=30.0)
+    assert comm.count() == 1
+    for _ in range(3):
+        root, upper = comm.exchange(full.root())
+        assert root == full.root() and len(upper[2]) == 0
+        assert comm.allreduce([11, 2**63], hip_lib.REDUCE_SUM).tolist() == [11, 2**63]
+    comm.close()
     recs = []
     for s in range(8):
         sel = (idx >> np.uint64(height - sb)) == s
