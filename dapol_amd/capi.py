@@ -32,7 +32,7 @@ class Options(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_int32), ("window_bits", ctypes.c_int32), ("table_gb", ctypes.c_double), ("high_half_rows", ctypes.c_int32),
                 ("generator_stationary", ctypes.c_int32), ("gs_tile_rows", ctypes.c_int32), ("streams", ctypes.c_int32), ("chunk_proofs", ctypes.c_int64),
                 ("scratch_gb", ctypes.c_double), ("tail_length", ctypes.c_int32), ("small_call_max", ctypes.c_int32), ("verify_batch_min", ctypes.c_int32),
-                ("update_incremental_max", ctypes.c_int64)]
+                ("update_incremental_max", ctypes.c_int64), ("gs_slices", ctypes.c_int32), ("reserved0", ctypes.c_int32)]
 
     def __init__(self, **kw):
         super().__init__()

@@ -142,6 +142,7 @@ static bool options_ok(const dapol_options* o) {
     if (o->streams < 0 || o->streams > 4 || o->chunk_proofs < 0 || o->table_gb < 0 || o->scratch_gb < 0) return false;
     if (o->tail_length && o->tail_length != -1 && o->tail_length != 32 && o->tail_length != 64 && o->tail_length != 128 && o->tail_length != 256) return false;
     if (o->small_call_max < 0 || o->verify_batch_min < 0 || o->update_incremental_max < -1) return false;
+    if (o->gs_slices != 0 && o->gs_slices != 1 && o->gs_slices != 2 && o->gs_slices != 4 && o->gs_slices != 8 && o->gs_slices != 16) return false;
     return true;
 }
 int32_t dapol_ctx_create(int32_t device, int32_t max_parties, int32_t digest_id, dapol_ctx** out) {

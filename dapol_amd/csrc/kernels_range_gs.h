@@ -94,19 +94,22 @@ __global__ __launch_bounds__(64) void k_rp_round_prep_gs(RangeArgs A, int round)
 }
 
 // The sweep: rows q0 .. q0 + nq - 1 (terms of list `side`, nq a multiple of 4) added into every accumulator lane.
-// first: the accumulators start at the identity; else they are loaded from acc (SoA: word k of lane l at acc[k * L + l]).
-__global__ __launch_bounds__(64, 4) void k_rp_msm_gs(RangeArgs A, TableView tbl, int round, int side, int q0, int nq, int first, int32_t* __restrict__ accs) {
-    const size_t L = A.B * (size_t)A.nwin;
+// first: the accumulators start at the identity; else they are loaded from acc (SoA: word k of lane l at acc[k * Ltot + l]).
+// SLICES (calls of a few thousand proofs, whose B * nwin lanes cannot fill the chip): gridDim.y slices of a list, slice s sweeping
+// rows s * slice_rows + q0 ... into its own accumulators (lane s * L + l of Ltot = L * gridDim.y); k_rp_gs_sum_slices adds them up.
+__global__ __launch_bounds__(64, 4) void k_rp_msm_gs(RangeArgs A, TableView tbl, int round, int side, int q0, int nq, int first, int32_t* __restrict__ accs, int slice_rows) {
+    const size_t L = A.B * (size_t)A.nwin, Ltot = L * gridDim.y;
     const size_t lane = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (lane >= L) return;
+    q0 += (int)blockIdx.y * slice_rows;
     ge_p3 acc;
-    int32_t* ap = accs + lane;
+    int32_t* ap = accs + (size_t)blockIdx.y * L + lane;
     if (first) ge_identity(acc);
     else {
 #pragma unroll
         for (int i = 0; i < FE_NL; i++) {
-            acc.X.v[i] = ap[(size_t)i * L]; acc.Y.v[i] = ap[(size_t)(FE_NL + i) * L];
-            acc.Z.v[i] = ap[(size_t)(2 * FE_NL + i) * L]; acc.T.v[i] = ap[(size_t)(3 * FE_NL + i) * L];
+            acc.X.v[i] = ap[(size_t)i * Ltot]; acc.Y.v[i] = ap[(size_t)(FE_NL + i) * Ltot];
+            acc.Z.v[i] = ap[(size_t)(2 * FE_NL + i) * Ltot]; acc.T.v[i] = ap[(size_t)(3 * FE_NL + i) * Ltot];
         }
     }
     const dapol_v4i* dg = reinterpret_cast<const dapol_v4i*>(A.dig) + ((size_t)(side * A.N + q0) >> 2) * L + lane;
@@ -120,20 +123,49 @@ __global__ __launch_bounds__(64, 4) void k_rp_msm_gs(RangeArgs A, TableView tbl,
         d4.x = d4.y; d4.y = d4.z; d4.z = d4.w;
         if ((i & 3) == 3) d4 = dn;
         bool isH;
-        const int j = term_generator(round, A.N, A.lgN, side, q0 + i, isH);      // (uniform over the launch)
+        const int j = term_generator(round, A.N, A.lgN, side, q0 + i, isH);      // (uniform over a block)
         tbl_madd(acc, tbl, gen_row(tbl, A.n, j, isH), d);
     }
 #pragma unroll
     for (int i = 0; i < FE_NL; i++) {
-        ap[(size_t)i * L] = acc.X.v[i]; ap[(size_t)(FE_NL + i) * L] = acc.Y.v[i];
-        ap[(size_t)(2 * FE_NL + i) * L] = acc.Z.v[i]; ap[(size_t)(3 * FE_NL + i) * L] = acc.T.v[i];
+        ap[(size_t)i * Ltot] = acc.X.v[i]; ap[(size_t)(FE_NL + i) * Ltot] = acc.Y.v[i];
+        ap[(size_t)(2 * FE_NL + i) * Ltot] = acc.Z.v[i]; ap[(size_t)(3 * FE_NL + i) * Ltot] = acc.T.v[i];
+    }
+}
+
+// Slices of a sweep -> slice 0: one lane per (side, window, proof), nslice - 1 additions.  accs: both sides' accumulators,
+// side_words apart, each SoA over Ltot = L * nslice lanes.
+__global__ __launch_bounds__(64) void k_rp_gs_sum_slices(RangeArgs A, int32_t* __restrict__ accs, size_t side_words, int nslice) {
+    const size_t L = A.B * (size_t)A.nwin, Ltot = L * (size_t)nslice;
+    const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (t >= 2 * L) return;
+    const int side = t >= L ? 1 : 0;
+    int32_t* ap = accs + (size_t)side * side_words + (t - (size_t)side * L);
+    auto load = [&](ge_p3& r, int s) {
+        const int32_t* q = ap + (size_t)s * L;
+        for (int i = 0; i < FE_NL; i++) {
+            r.X.v[i] = q[(size_t)i * Ltot]; r.Y.v[i] = q[(size_t)(FE_NL + i) * Ltot];
+            r.Z.v[i] = q[(size_t)(2 * FE_NL + i) * Ltot]; r.T.v[i] = q[(size_t)(3 * FE_NL + i) * Ltot];
+        }
+    };
+    ge_p3 acc, o, r;
+    load(acc, 0);
+#pragma nounroll
+    for (int s = 1; s < nslice; s++) {
+        load(o, s);
+        ge_add(r, acc, o);
+        acc = r;
+    }
+    for (int i = 0; i < FE_NL; i++) {
+        ap[(size_t)i * Ltot] = acc.X.v[i]; ap[(size_t)(FE_NL + i) * Ltot] = acc.Y.v[i];
+        ap[(size_t)(2 * FE_NL + i) * Ltot] = acc.Z.v[i]; ap[(size_t)(3 * FE_NL + i) * Ltot] = acc.T.v[i];
     }
 }
 
 // P_side[p] = sum_w 2^(W w) * acc_side[w * cb + p]: Horner from the top window, one lane per (side, proof) -- both lists of a
-// round in one launch (accs: the two sides' accumulators, side_words apart).
-__global__ __launch_bounds__(64) void k_rp_gs_combine(RangeArgs A, const int32_t* __restrict__ accs, size_t side_words) {
-    const size_t L = A.B * (size_t)A.nwin;
+// round in one launch (accs: the two sides' accumulators, side_words apart; SoA over L * nslice lanes, the sums in slice 0).
+__global__ __launch_bounds__(64) void k_rp_gs_combine(RangeArgs A, const int32_t* __restrict__ accs, size_t side_words, int nslice) {
+    const size_t Ltot = A.B * (size_t)A.nwin * (size_t)nslice;
     const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (t >= 2 * A.B) return;
     const int side = t >= A.B ? 1 : 0;
@@ -142,8 +174,8 @@ __global__ __launch_bounds__(64) void k_rp_gs_combine(RangeArgs A, const int32_t
     auto load = [&](ge_p3& r, int w) {
         const int32_t* ap = accs + (size_t)w * A.B + p;
         for (int i = 0; i < FE_NL; i++) {
-            r.X.v[i] = ap[(size_t)i * L]; r.Y.v[i] = ap[(size_t)(FE_NL + i) * L];
-            r.Z.v[i] = ap[(size_t)(2 * FE_NL + i) * L]; r.T.v[i] = ap[(size_t)(3 * FE_NL + i) * L];
+            r.X.v[i] = ap[(size_t)i * Ltot]; r.Y.v[i] = ap[(size_t)(FE_NL + i) * Ltot];
+            r.Z.v[i] = ap[(size_t)(2 * FE_NL + i) * Ltot]; r.T.v[i] = ap[(size_t)(3 * FE_NL + i) * Ltot];
         }
     };
     ge_p3 acc, t2, r;
@@ -167,6 +199,9 @@ __global__ __launch_bounds__(64) void k_rp_gs_combine(RangeArgs A, const int32_t
 // per launch so that the Horner chains (W (LW - 1) doublings, the same work the proof-stationary kernel does) fill the chip.
 // Digits: sweep position sp = side * N + i * (N / T) + k  <->  term q = i + k T, same dig4 layout as above.
 enum { MAT_GROUP = 16 };
+// accumulator slots of a chunk (MAT_GROUP classes, or 2 lists x up to GS_MAX_SLICES slices); lanes that fill the chip (3,072 wavefronts)
+enum { GS_ACC_SLOTS = 32, GS_MAX_SLICES = 16, GS_FULL_LANES = 3072 * 64 };
+static_assert(GS_ACC_SLOTS >= MAT_GROUP && GS_ACC_SLOTS >= 2 * GS_MAX_SLICES, "accumulator slots");
 
 // grid = ceil(cb * 2N / 64) blocks of 64
 __global__ __launch_bounds__(64) void k_rp_mat_prep_gs(RangeArgs A) {
@@ -182,10 +217,13 @@ __global__ __launch_bounds__(64) void k_rp_mat_prep_gs(RangeArgs A) {
 
 // One class, one half (0: the generators' own rows, digits of window w; 1: their high-half rows, digits of window w + LW).
 // accs: this class's slot, SoA over LM = cb * LW lanes (lane = w * cb + p).
+// gridDim.y classes per launch (cls + blockIdx.y, each in its own slot) when the lanes of one class cannot fill the chip.
 __global__ __launch_bounds__(64, 4) void k_rp_mat_gs(RangeArgs A, TableView tbl, int side, int cls, int hi, int LW, int32_t* __restrict__ accs) {
     const size_t LM = A.B * (size_t)LW, L = A.B * (size_t)A.nwin;
     const size_t lane = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (lane >= LM) return;
+    cls += (int)blockIdx.y;
+    accs += (size_t)blockIdx.y * 4 * FE_NL * LM;
     const int w = (int)(lane / A.B);
     const size_t p = lane - (size_t)w * A.B;
     const int wd = w + (hi ? LW : 0);

@@ -82,7 +82,7 @@ typedef struct {
     int32_t window_bits;              /* creation: width of the fixed-base windows, 8..20 (0: widest <= 17 whose tables fit table_gb) */
     double  table_gb;                 /* creation: budget of the window tables in GB (0: 40 GB, at most 30 % of the free memory) */
     int32_t high_half_rows;           /* creation: 0 auto, 1 on, -1 off: second table row per generator (halves the window steps of lanes that cannot share doublings) */
-    int32_t generator_stationary;     /* 0 auto (calls of >= 8,192 proofs), 1 every call that is not a small one, -1 never */
+    int32_t generator_stationary;     /* 0 auto (calls of more than small_call_max proofs over >= 1,024 generators a side), 1 every call that is not a small one, -1 never */
     int32_t gs_tile_rows;             /* rows per launch of the generator-stationary sweep (multiple of 4; 0: 16) */
     int32_t streams;                  /* chunks in flight, 1..4 (0: 2) */
     int64_t chunk_proofs;             /* proofs per chunk (0: whole rounds of resident wavefronts, 65,536 on MI355X) */
@@ -91,6 +91,8 @@ typedef struct {
     int32_t small_call_max;           /* calls of up to this many proofs take the latency shapes (0: 8,191) */
     int32_t verify_batch_min;         /* fewest proofs the verifier checks as ONE random linear combination (0: 112) */
     int64_t update_incremental_max;   /* dapol_tree_update: most replaced leaves re-merged in place (0: 65,536; -1: always rebuild) */
+    int32_t gs_slices;                /* slices of a list swept side by side by the generator-stationary MSM: 1, 2, 4, 8, 16 (0: as many as fill the chip) */
+    int32_t reserved0;                /* 0 */
 } dapol_options;
 int32_t dapol_ctx_create_opts(int32_t device, int32_t max_parties, int32_t digest_id, const dapol_options* options, dapol_ctx** out);
 int32_t dapol_ctx_get_options(dapol_ctx* ctx, dapol_options* out);      /* the stored settings (zeros = defaults) + window_bits / high_half_rows as built */

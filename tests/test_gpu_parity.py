@@ -1264,6 +1264,8 @@ def test_every_proving_strategy_gives_the_same_bytes(gpu_ctx, n_bits, m):
                 {"DAPOL_NO_FS_PARTS": "1"}, {"DAPOL_NO_SIDE_A": "1"},
                 # the generator-stationary sweep of large calls (kernels_range_gs.h), forced onto this small batch
                 {"DAPOL_GS": "1", "DAPOL_NO_SPLIT": "1"}, {"DAPOL_GS": "1", "DAPOL_NO_SPLIT": "1", "DAPOL_GS_TILE": "4"},
+                {"DAPOL_GS": "1", "DAPOL_NO_SPLIT": "1", "DAPOL_GS_SLICES": "1", "DAPOL_GS_MAT_CPL": "1"}, {"DAPOL_GS": "1", "DAPOL_NO_SPLIT": "1", "DAPOL_GS_SLICES": "2", "DAPOL_GS_MAT_CPL": "3"},
+                {"DAPOL_GS": "1", "DAPOL_NO_SPLIT": "1", "DAPOL_GS_SLICES": "4", "DAPOL_GS_TILE": "12", "DAPOL_CHUNK": "7", "DAPOL_STREAMS": "2"},
                 {"DAPOL_GS": "1", "DAPOL_NO_SPLIT": "1", "DAPOL_GS_TILE": "64", "DAPOL_CHUNK": "16", "DAPOL_STREAMS": "2"},
                 {"DAPOL_GS": "1", "DAPOL_NO_SPLIT": "1", "DAPOL_CHUNK": "16", "DAPOL_STREAMS": "2", "DAPOL_MSM_SERIAL": "1"},
                 {"DAPOL_GS": "1", "DAPOL_NO_SPLIT": "1", "DAPOL_NO_TAIL": "1"}, {"DAPOL_GS": "1", "DAPOL_NO_SPLIT": "1", "DAPOL_CHUNK": "5", "DAPOL_TAIL_N": "32"},
@@ -1305,15 +1307,20 @@ def test_options_struct_and_env_knob_gate(hip_lib):
     idx, vv, rr = _rand_leaves(np.random.default_rng(9), 8, 40)
     w = hip_lib.Workload(ctx, 8, idx, vv, rr)
     w.build(SEED)
-    ctx.set_options(hip_lib.Options(generator_stationary=1, small_call_max=1, gs_tile_rows=8))
+    ctx.set_options(hip_lib.Options(generator_stationary=1, small_call_max=1, gs_tile_rows=8, gs_slices=1))
     st_gs = w.prove(SEED, 64)
+    ctx.set_options(hip_lib.Options(generator_stationary=1, small_call_max=1, gs_tile_rows=8))        # 40 proofs: sixteen slices of each list side by side
+    st_gs8 = w.prove(SEED, 64)
     ctx.set_options(hip_lib.Options(generator_stationary=-1, small_call_max=1))
     st_ps = w.prove(SEED, 64)
     assert st_gs.msm_kernels == st_gs.msm_launches * 2 * (512 // 8) and st_ps.msm_kernels == st_ps.msm_launches      # N = 8 x 64 terms per list
-    assert st_gs.checksum == st_ps.checksum
+    assert st_gs8.msm_kernels == st_gs8.msm_launches * 2 * (512 // 8 // 16)
+    assert st_gs.checksum == st_ps.checksum == st_gs8.checksum
     ctx.set_options(hip_lib.Options())
     with pytest.raises(hip_lib.DapolError):
         ctx.set_options(hip_lib.Options(gs_tile_rows=6))
+    with pytest.raises(hip_lib.DapolError):
+        ctx.set_options(hip_lib.Options(gs_slices=3))
     with pytest.raises(hip_lib.DapolError):
         hip_lib.Context(0, 8, options=hip_lib.Options(window_bits=30))
     # the gate: with the knobs off an absurd variable is not even read; with them on it is (and rejected)

@@ -9,9 +9,8 @@ from dapol_amd import capi
 SEED = bytes(range(32))
 ctx = capi.Context(0, 32)
 n_bits, m = 64, 32
-CFGS = [("default", {}), ("gs tile 16", {"DAPOL_GS": "1", "DAPOL_SMALL_MAX": "1024", "DAPOL_GS_TILE": "16"}),
-        ("gs tile 64", {"DAPOL_GS": "1", "DAPOL_SMALL_MAX": "1024", "DAPOL_GS_TILE": "64"}),
-        ("gs tile 256", {"DAPOL_GS": "1", "DAPOL_SMALL_MAX": "1024", "DAPOL_GS_TILE": "256"})]
+G = {"DAPOL_GS": "1", "DAPOL_SMALL_MAX": "64"}
+CFGS = [("default", {}), ("latency shapes", {"DAPOL_SMALL_MAX": "8191"})] + [("gs %d slices" % k, dict(G, DAPOL_GS_SLICES=str(k))) for k in (1, 2, 4, 8, 16)]
 for b in [int(x) for x in sys.argv[1:]]:
     rng = np.random.default_rng(b)
     v = rng.integers(0, 2**63, size=(b, m), dtype=np.uint64)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised soak of the generator-stationary prover against the C oracle: random (bits, parties) shapes with at least 1,024 generators per
-side, random batch sizes between 8,192 and 40,000 proofs (one or several chunks, ragged last chunks), random values and blindings; six
+side, random batch sizes between 1,024 and 40,000 proofs (sliced sweeps below 65,536) (one or several chunks, ragged last chunks), random values and blindings; six
 random proofs of every batch compared byte for byte with oracle/ref_dapol.c, all six verified on the GPU, one tampered copy rejected.
 usage: tools/soak_gs.py [cases] [seed]"""
 import ctypes
@@ -25,7 +25,7 @@ ctx = capi.Context(0, 64)
 SEED = bench.NONCE_SEED
 for case in range(cases):
     n_bits, m = [(64, 32), (64, 16), (32, 32), (32, 64), (16, 64), (64, 64)][int(rng.integers(0, 6))]
-    b = int(rng.integers(8192, 40001)) if n_bits * m <= 2048 else int(rng.integers(8192, 14001))
+    b = int(rng.integers(1024, 40001)) if n_bits * m <= 2048 else int(rng.integers(1024, 14001))
     if rng.integers(0, 4) == 0:
         os.environ["DAPOL_CHUNK"] = str(int(rng.integers(3000, 20000)))         # several (ragged) chunks on two streams
     vmax = (1 << n_bits) if n_bits < 64 else (1 << 63)
