@@ -1264,6 +1264,8 @@ def test_every_proving_strategy_gives_the_same_bytes(gpu_ctx, n_bits, m):
                 {"DAPOL_NO_FS_PARTS": "1"}, {"DAPOL_NO_SIDE_A": "1"},
                 # the generator-stationary sweep of large calls (kernels_range_gs.h), forced onto this small batch
                 {"DAPOL_GS": "1", "DAPOL_NO_SPLIT": "1"}, {"DAPOL_GS": "1", "DAPOL_NO_SPLIT": "1", "DAPOL_GS_TILE": "4"},
+                {"DAPOL_GS": "1", "DAPOL_NO_SPLIT": "1", "DAPOL_FS_SHAPE": "0"}, {"DAPOL_GS": "1", "DAPOL_NO_SPLIT": "1", "DAPOL_FS_SHAPE": "1", "DAPOL_TAIL_LPL": "8"},
+                {"DAPOL_GS": "1", "DAPOL_NO_SPLIT": "1", "DAPOL_FS_SHAPE": "2", "DAPOL_TAIL_LPL": "4"},
                 {"DAPOL_GS": "1", "DAPOL_NO_SPLIT": "1", "DAPOL_GS_SLICES": "1", "DAPOL_GS_MAT_CPL": "1"}, {"DAPOL_GS": "1", "DAPOL_NO_SPLIT": "1", "DAPOL_GS_SLICES": "2", "DAPOL_GS_MAT_CPL": "3"},
                 {"DAPOL_GS": "1", "DAPOL_NO_SPLIT": "1", "DAPOL_GS_SLICES": "4", "DAPOL_GS_TILE": "12", "DAPOL_CHUNK": "7", "DAPOL_STREAMS": "2"},
                 {"DAPOL_GS": "1", "DAPOL_NO_SPLIT": "1", "DAPOL_GS_TILE": "64", "DAPOL_CHUNK": "16", "DAPOL_STREAMS": "2"},
@@ -1337,13 +1339,15 @@ def test_options_struct_and_env_knob_gate(hip_lib):
 
 
 def test_call_size_regimes_give_the_same_bytes(gpu_ctx, hip_lib):
-    """The three regimes of a prove call -- latency shapes (up to 8,191 proofs), the generator-stationary sweep (from 8,192), and the
-    proof-stationary throughput shapes they replace -- at the sizes where one hands over to the next: 5,000 and 8,192 proofs of 64 bits
-    x 32 parties, each under its default and forced into the other regimes; one digest per setting."""
+    """The regimes of a prove call -- latency shapes (up to 1,023 proofs of this shape), the generator-stationary sweep (from 1,024: in
+    16 / 8 / 4 slices below 65,536 proofs, with the Fiat-Shamir shapes and tail lanes of its size), and the proof-stationary throughput
+    shapes they replace -- at sizes where one hands over to the next: 1,100, 5,000 and 8,192 proofs of 64 bits x 32 parties, each under
+    its default and forced into the other regimes; one digest per size."""
     import hashlib
     import os
     n_bits, m = 64, 32
-    for b, envs in ((5000, ({}, {"DAPOL_NO_SPLIT": "1"}, {"DAPOL_GS": "1", "DAPOL_SMALL_MAX": "4096"})),
+    for b, envs in ((1100, ({}, {"DAPOL_SMALL_MAX": "8191"}, {"DAPOL_GS": "0", "DAPOL_NO_SPLIT": "1"}, {"DAPOL_GS_SLICES": "1", "DAPOL_FS_SHAPE": "0"})),
+                    (5000, ({}, {"DAPOL_SMALL_MAX": "8191"}, {"DAPOL_GS": "0", "DAPOL_NO_SPLIT": "1"}, {"DAPOL_GS_SLICES": "2", "DAPOL_FS_SHAPE": "0", "DAPOL_TAIL_LPL": "2"})),
                     (8192, ({}, {"DAPOL_GS": "0"}, {"DAPOL_SMALL_MAX": "8192"}))):
         rng = np.random.default_rng(b)
         v = rng.integers(0, 2**63, size=(b, m), dtype=np.uint64)
