@@ -12,7 +12,7 @@ n_bits, m = 64, 32
 G = {"DAPOL_GS": "1", "DAPOL_SMALL_MAX": "64"}
 CFGS = [("default", {}), ("latency shapes", {"DAPOL_SMALL_MAX": "8191"})] + [("gs %d slices" % k, dict(G, DAPOL_GS_SLICES=str(k))) for k in (1, 2, 4, 8, 16)]
 if os.environ.get("SWEEP_FS"):
-    CFGS = [("default", {})] + [("tail lpl %d" % k, {"DAPOL_TAIL_LPL": str(k)}) for k in (2, 4, 8)]
+    CFGS = [("default", {})] + [("tile %d" % k, {"DAPOL_GS_TILE": str(k)}) for k in (8, 16, 32, 64)]
 for b in [int(x) for x in sys.argv[1:]]:
     rng = np.random.default_rng(b)
     v = rng.integers(0, 2**63, size=(b, m), dtype=np.uint64)
