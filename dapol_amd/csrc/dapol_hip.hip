@@ -814,7 +814,12 @@ int32_t dapol_tree_update(dapol_tree* tree, size_t k, const uint64_t* leaf_idx, 
             const int H = tree->height;
             bool in_range = true;
             for (uint64_t x : ni) if (tree->index_bits < 64 && (x >> tree->index_bits)) in_range = false;         // (the rebuild reports the error)
-            if (tree->shard_bits) in_range = false;                                                              // shard trees: top bits must match; leave to the rebuild's checks
+            if (tree->shard_bits && in_range && !ni.empty()) {                                                   // shard trees: a new leaf must carry the shard's prefix (else the rebuild reports the error)
+                uint64_t first = 0;
+                HIPCHK(hipMemcpy(&first, tree->leaf_idx, 8, hipMemcpyDeviceToHost));
+                const int sh = tree->index_bits - tree->shard_bits;
+                for (uint64_t x : ni) if ((x >> sh) != (first >> sh)) in_range = false;
+            }
             if (!ni.empty() && ni.size() <= 4096 && in_range && H >= 1 && !knob("DAPOL_NO_INCREMENTAL_INSERT")) {
                 rc = tree_insert_incremental(own, ni.size(), ni, nv, nr, &done);
                 if (rc != DAPOL_OK) return rc;

@@ -365,6 +365,53 @@ def test_incremental_insert_equals_build_every_level(gpu_ctx, hip_lib, k_new, k_
     want.close()
 
 
+def _new_chains_share_a_node(old, new, height):
+    """k_tree_ins_plan's rule: a new leaf's chain runs up to its first ancestor that exists; two (neighbouring) new leaves whose
+    chains share a node are left to the rebuild."""
+    new = np.sort(new)
+    for a in range(1, len(new)):
+        m = next(t for t in range(height + 1) if np.any((old >> np.uint64(t)) == (new[a] >> np.uint64(t))))
+        if any((new[a] >> np.uint64(t)) == (new[a - 1] >> np.uint64(t)) for t in range(m)):
+            return True
+    return False
+
+
+@pytest.mark.parametrize("shard_bits,prefix", [(1, 1), (3, 5)])
+def test_incremental_update_of_a_shard_tree(gpu_ctx, hip_lib, shard_bits, prefix):
+    """A rank's subtree (dapol_tree_build_shard: global indexes, positional padding seeds, levels 0 .. height - shard_bits) takes the
+    same in-place paths: new leaves with the shard's prefix are inserted, existing ones replaced, and the tree equals a fresh shard
+    build over the enlarged set at every level; a new leaf of ANOTHER shard is refused (by the rebuild's checks) and leaves the tree alone."""
+    rng = np.random.default_rng(900 + shard_bits)
+    height, n = 24, 6000
+    idx_all, v_all, r_all = _rand_leaves(rng, height, n * (1 << shard_bits))
+    mine = (idx_all >> np.uint64(height - shard_bits)) == prefix
+    idx_s, v_s, r_s = idx_all[mine], v_all[mine], r_all[mine]
+    ns = len(idx_s)
+    new_sel = np.unique(rng.choice(ns, size=12, replace=False))
+    old_mask = np.ones(ns, bool)
+    old_mask[new_sel] = False
+    rep = rng.choice(np.nonzero(old_mask)[0], size=25, replace=False)
+    v2, r2 = v_s.copy(), r_s.copy()
+    v2[rep] = rng.integers(0, 2**40, size=len(rep), dtype=np.uint64)
+    r2[rep] = rng.integers(0, 256, size=(len(rep), 32), dtype=np.uint8)
+    r2[rep, 31] &= 0x7F
+    want = hip_lib.Tree(gpu_ctx, height, idx_s, v2, r2, SEED, shard_bits=shard_bits)
+    tr = hip_lib.Tree(gpu_ctx, height, idx_s[old_mask], v_s[old_mask], r_s[old_mask], SEED, shard_bits=shard_bits)
+    upd = rng.permutation(np.concatenate([new_sel, rep]))
+    tr.update(idx_s[upd], v2[upd], r2[upd])
+    assert tr.last_update_path() == (0 if _new_chains_share_a_node(idx_s[old_mask], idx_s[new_sel], height) else 3)
+    assert tr.root() == want.root() and tr.node_count() == want.node_count()
+    for level in range(height - shard_bits + 1):
+        for a, b in zip(tr.level_nodes(level), want.level_nodes(level)):
+            assert np.array_equal(a, b), level
+    other = idx_all[~mine][:1]
+    with pytest.raises(hip_lib.DapolError):
+        tr.update(other, v_all[~mine][:1], r_all[~mine][:1])
+    assert tr.root() == want.root() and tr.node_count() == want.node_count()
+    tr.close()
+    want.close()
+
+
 def test_tree_grows_leaf_by_leaf_like_the_reference_test(gpu_ctx, hip_lib, ref):
     """src/tests.rs:41-48 at its own shape (height 10): a tree grown from one leaf by 60 single-leaf updates -- every one an
     incremental insert, repeated inserts ping-ponging the level buffers -- equals build() over the same liabilities at every level
