@@ -1,7 +1,7 @@
 """The schedule of mid-size calls.  One dapol_range_prove_batch call of b proofs (64-bit, 32 parties), best of 3, under the library's
 defaults and with one knob forced at a time: --set=slices (default: latency shapes / whole sweep / 2..16 slices), --set=fs (Fiat-Shamir
 kernel shapes), --set=tail (lanes per list of the tail MSM), --set=tile (rows per tile launch).
-python tools/gs_small_sweep.py [--set=slices|fs|tail|tile] b [b ...]"""
+python tools/gs_small_sweep.py [--set=slices|fs|tail|tile|chunk] b [b ...]"""
 import os, sys, time
 os.environ.setdefault("DAPOL_ENV_KNOBS", "1")     # the library reads its DAPOL_* knobs only in a process that opts in
 import numpy as np
@@ -16,6 +16,7 @@ SETS = {
     "slices": [("default", {}), ("latency shapes", {"DAPOL_SMALL_MAX": "8191"})] + [("gs %d slices" % k, dict(G, DAPOL_GS_SLICES=str(k))) for k in (1, 2, 4, 8, 16)],
     "fs": [("default", {}), ("fs lane", {"DAPOL_FS_SHAPE": "0"}), ("fs pair", {"DAPOL_FS_SHAPE": "1"}), ("fs wavefront", {"DAPOL_FS_SHAPE": "2"})],
     "tail": [("default", {})] + [("tail lpl %d" % k, {"DAPOL_TAIL_LPL": str(k)}) for k in (2, 4, 8, 32)],
+    "chunk": [("default", {})] + [("chunk %d" % k, {"DAPOL_CHUNK": str(k)}) for k in (16384, 21846, 32768, 43691)],
     "tile": [("default", {})] + [("tile %d" % k, {"DAPOL_GS_TILE": str(k)}) for k in (8, 16, 32, 64)],
 }
 args = sys.argv[1:]
