@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Randomised soak of dapol_tree_update: random trees (height 4-40, 1-3,000 leaves), sequences of twelve updates that mix replaced and new
+"""Randomised soak of dapol_tree_update: random trees (height 4-40, 1-3,000 leaves; every third one a rank's SHARD of a taller tree:
+1-3 prefix bits above it, global indexes), sequences of twelve updates that mix replaced and new
 leaves (also duplicates inside a batch, neighbours, batches that fall back to the rebuild); after every update root and node counts, and
 after every fourth every node of every level, against a fresh dapol_tree_build of the same liabilities.  usage: tools/soak_tree_update.py [sequences] [seed]"""
 import os
@@ -29,11 +30,18 @@ def rand_r(k):
 for s in range(seqs):
     height = int(rng.integers(4, 41))
     space = 1 << height
+    sb = int(rng.integers(1, 4)) if s % 3 == 2 else 0                           # a shard tree: `height` local levels under sb prefix bits
+    base = int(rng.integers(0, 1 << sb)) << height
+    total_h = height + sb
+    if total_h > 62:
+        sb, base, total_h = 0, 0, height
+    mk = lambda keys_local: capi.Tree(ctx, total_h, keys_local + np.uint64(base), np.array([cur[int(i)][0] for i in keys_local], np.uint64),
+                                      np.stack([cur[int(i)][1] for i in keys_local]), SEED, shard_bits=sb)
     n = int(rng.integers(1, min(3000, space // 2) + 1))
     idx = np.sort(rng.choice(space, size=n, replace=False).astype(np.uint64)) if space <= (1 << 24) else np.unique(rng.integers(0, space, size=n, dtype=np.uint64))
     cur = {int(i): (int(rng.integers(0, 1 << 40)), rand_r(1)[0]) for i in idx}
     keys = np.array(sorted(cur), np.uint64)
-    tr = capi.Tree(ctx, height, keys, np.array([cur[int(i)][0] for i in keys], np.uint64), np.stack([cur[int(i)][1] for i in keys]), SEED)
+    tr = mk(keys)
     for step in range(12):
         k_new, k_old = int(rng.integers(0, 21)), int(rng.integers(0, 21))
         if len(cur) + k_new > space // 2:
@@ -55,12 +63,12 @@ for s in range(seqs):
         ui = np.array(upd, np.uint64)[order]
         uv = rng.integers(0, 1 << 40, size=len(upd), dtype=np.uint64)
         ur = rand_r(len(upd))
-        tr.update(ui, uv, ur)
+        tr.update(ui + np.uint64(base), uv, ur)
         paths[tr.last_update_path()] += 1
         for a, b, c in zip(ui, uv, ur):
             cur[int(a)] = (int(b), c)
         keys = np.array(sorted(cur), np.uint64)
-        want = capi.Tree(ctx, height, keys, np.array([cur[int(i)][0] for i in keys], np.uint64), np.stack([cur[int(i)][1] for i in keys]), SEED)
+        want = mk(keys)
         assert tr.root() == want.root() and tr.node_count() == want.node_count(), (s, step, height, len(cur))
         if step % 4 == 3:
             for level in range(height + 1):
