@@ -88,16 +88,21 @@ DAPOL_HD void seed_wide(uint32_t* out16, const uint32_t* seed8, uint32_t domain,
 }
 
 // Streaming digest D over a byte string assembled from parts (leaf derivation, src/dapol/mod.rs:323-441):
-// D = BLAKE3 (single chunk: at most 1024 bytes in total) or Blake2s-256 (the reference's KAT digest,
-// src/dapol/tests.rs:13,21).  Usage: dg_init, dg_update* (bytes), dg_final -> eight little-endian words.
+// D = BLAKE3 (any length: the chunk chaining values of inputs beyond 1024 bytes go through the caller's stack, see
+// dg_init_long) or Blake2s-256 (the reference's KAT digest, src/dapol/tests.rs:13,21).
+// Usage: dg_init / dg_init_long, dg_update* (bytes), dg_final -> eight little-endian words.
 enum : int { DG_BLAKE3 = 0, DG_BLAKE2S = 1 };
+enum : int { B3_STACK_DEPTH = 24 };   // subtree chaining values of up to 2^24 chunks = 16 GiB (inputs here are < 2^32 + 600 bytes)
 struct Digest {
     uint32_t h[8];
     uint32_t buf[16];
     uint32_t buflen;      // bytes in buf
-    uint32_t total;       // bytes compressed so far (before buf)
+    uint32_t total;       // bytes compressed so far (before buf); for BLAKE3: within the current chunk
     int kind;
-    bool overflow;        // BLAKE3 input longer than one chunk (unsupported here)
+    bool overflow;        // BLAKE3 input longer than one chunk on a digest without a stack (dg_init)
+    uint32_t chunks;      // BLAKE3: chunks completed so far (= the current chunk's counter)
+    uint32_t sp;          // BLAKE3: chaining values on the stack
+    uint32_t* stack;      // BLAKE3: [B3_STACK_DEPTH][8] owned by the caller, or nullptr (single-chunk inputs only)
 };
 DAPOL_HD void blake2s_compress(uint32_t* h, const uint32_t* m, uint32_t t, bool last) {
     const uint32_t IV[8] = {0x6A09E667u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au, 0x510E527Fu, 0x9B05688Cu, 0x1F83D9ABu, 0x5BE0CD19u};
@@ -167,17 +172,51 @@ DAPOL_HD void dg_init(Digest& d, int kind) {
     d.total = 0;
     d.kind = kind;
     d.overflow = false;
+    d.chunks = 0;
+    d.sp = 0;
+    d.stack = nullptr;
+}
+// A digest whose BLAKE3 input may exceed one 1024-byte chunk: stack = B3_STACK_DEPTH * 8 words of the caller's.
+DAPOL_HD void dg_init_long(Digest& d, int kind, uint32_t* stack) {
+    dg_init(d, kind);
+    d.stack = stack;
+}
+// BLAKE3 parent node: chaining value of (left || right)
+DAPOL_HD void blake3_parent(uint32_t* out16, const uint32_t* left8, const uint32_t* right8, uint32_t flags) {
+    uint32_t cv[8], m[16];
+    blake3_iv(cv);
+    for (int i = 0; i < 8; i++) { m[i] = left8[i]; m[8 + i] = right8[i]; }
+    blake3_compress(out16, cv, m, 0, 64, B3_PARENT | flags);
 }
 DAPOL_HD void dg_flush(Digest& d) {        // compress a FULL, non-final block
     if (d.kind == DG_BLAKE3) {
         uint32_t o[16];
-        if (d.total + 64 >= 1024) d.overflow = true;
-        blake3_compress(o, d.h, d.buf, 0, 64, d.total == 0 ? B3_CHUNK_START : 0u);
-        for (int i = 0; i < 8; i++) d.h[i] = o[i];
+        const bool chunk_end = d.total + 64 >= 1024;   // more input follows (the flush is lazy), so this chunk is not the last one
+        blake3_compress(o, d.h, d.buf, d.chunks, 64, (d.total == 0 ? B3_CHUNK_START : 0u) | (chunk_end ? B3_CHUNK_END : 0u));
+        if (!chunk_end) {
+            for (int i = 0; i < 8; i++) d.h[i] = o[i];
+            d.total += 64;
+        } else {
+            // the chunk's chaining value joins the stack of subtree roots: one merge per trailing zero bit of the new chunk count
+            d.chunks++;
+            if (!d.stack) d.overflow = true;
+            else {
+                for (uint32_t t = d.chunks; (t & 1u) == 0 && d.sp > 0; t >>= 1) {
+                    d.sp--;
+                    uint32_t p[16];
+                    blake3_parent(p, d.stack + 8 * d.sp, o, 0);
+                    for (int i = 0; i < 8; i++) o[i] = p[i];
+                }
+                if (d.sp < (uint32_t)B3_STACK_DEPTH) { for (int i = 0; i < 8; i++) d.stack[8 * d.sp + i] = o[i]; d.sp++; }
+                else d.overflow = true;
+            }
+            blake3_iv(d.h);
+            d.total = 0;
+        }
     } else {
         blake2s_compress(d.h, d.buf, d.total + 64, false);
+        d.total += 64;
     }
-    d.total += 64;
     d.buflen = 0;
     for (int i = 0; i < 16; i++) d.buf[i] = 0;
 }
@@ -196,7 +235,18 @@ DAPOL_HD void dg_update_words(Digest& d, const uint32_t* w, int nwords) {
 DAPOL_HD void dg_final(Digest& d, uint32_t* out8) {
     if (d.kind == DG_BLAKE3) {
         uint32_t o[16];
-        blake3_compress(o, d.h, d.buf, 0, d.buflen, (d.total == 0 ? B3_CHUNK_START : 0u) | B3_CHUNK_END | B3_ROOT);
+        const uint32_t flags = (d.total == 0 ? B3_CHUNK_START : 0u) | B3_CHUNK_END;
+        if (d.sp == 0) {
+            blake3_compress(o, d.h, d.buf, d.chunks, d.buflen, flags | B3_ROOT);       // a single chunk is its own root
+        } else {
+            blake3_compress(o, d.h, d.buf, d.chunks, d.buflen, flags);                 // the last chunk, then up the right edge of the tree
+            while (d.sp > 0) {
+                d.sp--;
+                uint32_t p[16];
+                blake3_parent(p, d.stack + 8 * d.sp, o, d.sp == 0 ? B3_ROOT : 0u);
+                for (int i = 0; i < 8; i++) o[i] = p[i];
+            }
+        }
         for (int i = 0; i < 8; i++) out8[i] = o[i];
     } else {
         blake2s_compress(d.h, d.buf, d.total + d.buflen, true);

@@ -32,6 +32,8 @@ struct LeafArgs {
     uint64_t* cand;          // [n]     candidate / final index
     uint32_t* blind;         // [n][8]
     uint32_t* err;           // [0] = digest overflow flag, [1] = duplicate id flag, [2] = failed-to-map flag, [3] = offending entity
+    int max_tries;           // MAX_INDEX_RETRIES = 128.  Lower only under the test knob DAPOL_LEAF_MAX_TRIES: with 2^height >= 2 n the
+                             // reference's FailedToMapIndex has probability < 2^-128 per entity, so no input reaches it at 128 tries
 };
 
 __device__ __forceinline__ uint64_t leaf_index_of(const uint32_t* st, int height) {
@@ -44,14 +46,16 @@ __global__ __launch_bounds__(64) void k_leaf_hash(LeafArgs A) {
     if (e >= A.n) return;
     Digest d;
     uint32_t aid[8], st[8], bl[8];
-    dg_init(d, A.kind);
+    uint32_t stack[B3_STACK_DEPTH * 8];                  // ids of any length (mod.rs:347-349, 358-360): BLAKE3 beyond one chunk chains
+                                                         // its chunks through this stack (private memory, touched by long inputs only)
+    dg_init_long(d, A.kind, stack);
     dg_update(d, A.seed, A.seed_len);
     dg_update(d, A.iid + A.iid_off[e], A.iid_off[e + 1] - A.iid_off[e]);
     bool ovf = d.overflow;
     dg_final(d, aid);
     const uint8_t t1[10] = {'i', 'n', 'd', 'e', 'x', '_', 's', 'e', 'e', 'd'};
     const uint8_t t2[10] = {'b', 'l', 'i', 'n', 'd', '_', 's', 'e', 'e', 'd'};
-    dg_init(d, A.kind);
+    dg_init_long(d, A.kind, stack);
     dg_update_words(d, aid, 8);
     dg_update(d, t1, 10);
     dg_update(d, A.eid + A.eid_off[e], A.eid_off[e + 1] - A.eid_off[e]);
@@ -60,7 +64,7 @@ __global__ __launch_bounds__(64) void k_leaf_hash(LeafArgs A) {
     dg_init(d, A.kind);                                  // first shuffle_index iteration: seed = D(seed)
     dg_update_words(d, st, 8);
     dg_final(d, st);
-    dg_init(d, A.kind);
+    dg_init_long(d, A.kind, stack);
     dg_update_words(d, aid, 8);
     dg_update(d, t2, 10);
     dg_update(d, A.eid + A.eid_off[e], A.eid_off[e + 1] - A.eid_off[e]);
@@ -149,7 +153,7 @@ __global__ void k_leaf_resolve(LeafArgs A, LeafResolve R) {
         uint32_t st[8];
         for (int i = 0; i < 8; i++) st[i] = A.idx_state[(size_t)e * 8 + i];
         bool placed = false;
-        for (int tries = 1; tries < LEAF_MAX_RETRIES && !placed; tries++) {      // the first try was the sorted candidate
+        for (int tries = 1; tries < A.max_tries && !placed; tries++) {      // the first try was the sorted candidate
             Digest d;
             dg_init(d, A.kind);
             dg_update_words(d, st, 8);
@@ -220,16 +224,16 @@ __global__ void k_leaf_settle(LeafArgs A, LeafTable T) {
     size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= A.n) return;
     uint32_t tries = T.tries[e];
-    if (tries > LEAF_MAX_RETRIES) return;            // parked: out of candidates in an earlier round
+    if (tries > (uint32_t)A.max_tries) return;       // parked: out of candidates in an earlier round
     if (T.owner[T.pos[e]] == (uint32_t)e) return;
     uint32_t st[8], hp = T.pos[e];
     for (int i = 0; i < 8; i++) st[i] = A.idx_state[e * 8 + i];
     uint64_t x = A.cand[e];
     for (;;) {
-        if (tries >= LEAF_MAX_RETRIES) {             // DapolError::FailedToMapIndex.  The entity parks (it holds no slot); the rounds go on
+        if (tries >= (uint32_t)A.max_tries) {        // DapolError::FailedToMapIndex.  The entity parks (it holds no slot); the rounds go on
             atomicOr(&A.err[2], 1u);                 // to the fixed point, so that err[3] ends as the EARLIEST such entity -- the one the
             atomicMin(&A.err[3], (uint32_t)e);       // reference's loop stops at (the entities before it are where that loop puts them)
-            tries = LEAF_MAX_RETRIES + 1;
+            tries = (uint32_t)A.max_tries + 1;
             break;
         }
         Digest d;

@@ -115,8 +115,9 @@ int32_t dapol_commit_hash_batch(dapol_ctx* ctx, size_t n, const uint64_t* v, con
  * (ids as concatenated bytes with n+1 offsets) -> for every liability its tree index and blinding factor, returned both
  * per input entity (idx_by_entity, may be NULL = the id_to_idx_map of mod.rs:388) and sorted by index, ready for
  * dapol_tree_build (mod.rs:396): leaf_idx_sorted / v_sorted / r32_sorted, with order_sorted[p] = input position of the
- * p-th leaf.  digest_id: DAPOL_DIGEST_BLAKE3 (ids up to one 1024-byte chunk per hash input) or DAPOL_DIGEST_BLAKE2S (the
- * digest of the reference's known-answer tests, src/dapol/tests.rs:13,21).  Collisions are resolved exactly as the
+ * p-th leaf.  digest_id: DAPOL_DIGEST_BLAKE3 or DAPOL_DIGEST_BLAKE2S (the digest of the reference's known-answer tests,
+ * src/dapol/tests.rs:13,21); ids of any length, as in the reference (mod.rs:347-349, 358-360) -- BLAKE3 inputs beyond one
+ * 1024-byte chunk go through the tree mode on the device.  Collisions are resolved exactly as the
  * reference does (an entity competes only with the entities before it in the input; up to 128 re-hashes).
  * Errors: DAPOL_ERR_TREE_HEIGHT_TOO_BIG, DAPOL_ERR_SPARSITY_TOO_SMALL (2^height < 2n), DAPOL_ERR_DUPLICATED_INTERNAL_ID,
  * DAPOL_ERR_FAILED_TO_MAP_INDEX. */

@@ -410,30 +410,48 @@ def blake3_compress(cv, block_words, counter, block_len, flags):
     return s
 
 
-def _blake3_single_chunk(data: bytes, key_words, base_flags, out_len):
-    assert len(data) <= 1024, "single-chunk BLAKE3 only (node hashes are 32 or 128 bytes)"
-    blocks = [data[i:i + 64] for i in range(0, len(data), 64)] or [b""]
+def _blake3_chunk(chunk: bytes, key_words, base_flags, counter):
+    """One chunk (<= 1024 bytes) -> (input chaining value, last block words, last block length, flags) of its final compression."""
+    blocks = [chunk[i:i + 64] for i in range(0, len(chunk), 64)] or [b""]
     cv = list(key_words)
     for i, blk in enumerate(blocks):
-        flags = base_flags
-        if i == 0:
-            flags |= B3_CHUNK_START
-        last = i == len(blocks) - 1
+        flags = base_flags | (B3_CHUNK_START if i == 0 else 0)
         words = list(struct.unpack("<16I", blk.ljust(64, b"\0")))
-        if not last:
-            cv = blake3_compress(cv, words, 0, 64, flags)[:8]
+        if i < len(blocks) - 1:
+            cv = blake3_compress(cv, words, counter, 64, flags)[:8]
         else:
-            flags |= B3_CHUNK_END | B3_ROOT
-            out = b""
-            ctr = 0
-            while len(out) < out_len:
-                out += struct.pack("<16I", *blake3_compress(cv, words, ctr, len(blk), flags))
-                ctr += 1
-            return out[:out_len]
+            return cv, words, counter, len(blk), flags | B3_CHUNK_END
+
+
+def _blake3_hash(data: bytes, key_words, base_flags, out_len):
+    """BLAKE3 of any length (the published tree mode: 1024-byte chunks, the left subtree of a node holds the largest power of two
+    of chunks that leaves the right one non-empty; the root compression carries ROOT and, for longer outputs, the block counter)."""
+    chunks = [data[i:i + 1024] for i in range(0, len(data), 1024)] or [b""]
+
+    def node(lo, hi):                                   # -> the final compression's inputs of the subtree over chunks[lo:hi]
+        if hi - lo == 1:
+            return _blake3_chunk(chunks[lo], key_words, base_flags, lo)
+        split = 1 << ((hi - lo - 1).bit_length() - 1)
+        left = blake3_compress(*node(lo, lo + split))[:8]
+        right = blake3_compress(*node(lo + split, hi))[:8]
+        return list(key_words), left + right, 0, 64, base_flags | B3_PARENT
+
+    cv, words, counter, blen, flags = node(0, len(chunks))
+    out, ctr = b"", 0
+    while len(out) < out_len:
+        # the root's counter field is the output block counter (a one-chunk input has chunk counter 0 anyway)
+        out += struct.pack("<16I", *blake3_compress(cv, words, ctr, blen, flags | B3_ROOT))
+        ctr += 1
+    return out[:out_len]
+
+
+def _blake3_single_chunk(data: bytes, key_words, base_flags, out_len):
+    assert len(data) <= 1024, "single-chunk BLAKE3 only (node hashes are 32 or 128 bytes)"
+    return _blake3_hash(data, key_words, base_flags, out_len)
 
 
 def blake3(data: bytes, out_len=32):
-    return _blake3_single_chunk(data, _B3_IV, 0, out_len)
+    return _blake3_hash(data, _B3_IV, 0, out_len)
 
 
 def blake3_keyed(key32: bytes, data: bytes, out_len=32):
@@ -992,8 +1010,8 @@ class DapolError(Exception):
     pass
 
 
-def shuffle_index(index_seed, height, taken, dg):
-    for _ in range(MAX_INDEX_RETRIES):
+def shuffle_index(index_seed, height, taken, dg, max_tries=MAX_INDEX_RETRIES):
+    for _ in range(max_tries):
         index_seed = digest(dg, index_seed)
         idx = int.from_bytes(index_seed[:8], "big") >> (64 - height)
         if idx not in taken:
@@ -1002,17 +1020,20 @@ def shuffle_index(index_seed, height, taken, dg):
     return None
 
 
-def build_leaf_nodes(liabilities, audit_seed, height, dg="blake3"):
-    """liabilities: [(internal_id bytes, external_id bytes, value)] -> (sorted [(idx, Node)], {iid: idx})."""
+def build_leaf_nodes(liabilities, audit_seed, height, dg="blake3", max_tries=MAX_INDEX_RETRIES):
+    """liabilities: [(internal_id bytes, external_id bytes, value)] -> (sorted [(idx, Node)], {iid: idx}).
+    max_tries: MAX_INDEX_RETRIES (mod.rs:29); lowered only by tests that want to reach FailedToMapIndex (mod.rs:369-370), which
+    the sparsity rule of Dapol::new keeps below probability 2^-128 per entity at 128 tries.  The exception carries the input
+    position and the audit id of the liability the reference's loop stops at (`FailedToMapIndex(audit_id, MAX_INDEX_RETRIES)`)."""
     id_map, taken, out = {}, set(), []
-    for iid, eid, value in liabilities:
+    for pos, (iid, eid, value) in enumerate(liabilities):
         if iid in id_map:
             raise DapolError("DuplicatedInternalId")
         audit_id = digest(dg, audit_seed, iid)
         index_seed = digest(dg, audit_id, b"index_seed", eid)
-        idx = shuffle_index(index_seed, height, taken, dg)
+        idx = shuffle_index(index_seed, height, taken, dg, max_tries)
         if idx is None:
-            raise DapolError("FailedToMapIndex")
+            raise DapolError("FailedToMapIndex", pos, audit_id)
         blind = scalar_from_bits(digest(dg, audit_id, b"blind_seed", eid))
         id_map[iid] = idx
         out.append((idx, node_new(value, blind, dg)))

@@ -142,11 +142,22 @@ void t_merlin(const char* app, int app_len, const char* label, int ll, const cha
 }
 void t_digest(int kind, const uint8_t* in, int n, uint8_t* out) {
     Digest d;
+    uint32_t stack[B3_STACK_DEPTH * 8];
+    dg_init_long(d, kind, stack);           // inputs of any length (BLAKE3 beyond one chunk: the chaining-value stack)
+    dg_update(d, in, (uint32_t)n);
+    uint32_t o[8];
+    dg_final(d, o);
+    st(out, o, 8);
+}
+// the single-chunk digest (no stack): returns 1 when the input overflowed one BLAKE3 chunk
+int t_digest_short(int kind, const uint8_t* in, int n, uint8_t* out) {
+    Digest d;
     dg_init(d, kind);
     dg_update(d, in, (uint32_t)n);
     uint32_t o[8];
     dg_final(d, o);
     st(out, o, 8);
+    return d.overflow ? 1 : 0;
 }
 // decompress(a) + decompress(b) (general addition of two decoded points), compressed
 void t_add_compressed(const uint8_t* a, const uint8_t* b, uint8_t* out) {

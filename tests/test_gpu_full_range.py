@@ -1,0 +1,299 @@
+"""The reference's whole legal input range on the GPU (round-3 verdict, item 1): inclusion proofs on trees HIGHER than 32
+(`MAX_TREE_HEIGHT` = 64, /root/reference/src/dapol/mod.rs:26; the bench sets aggregation_factor = tree_height,
+benches/dapol.rs:155, so a proof aggregates up to 64 parties -> 4,096 generators a side), leaf indexes with bit 63 set,
+`DapolError::FailedToMapIndex` produced on the device (mod.rs:369-370), and liability ids longer than one BLAKE3 chunk
+(mod.rs:347-349, 358-360 hash ids of any length).  Everything goes through the C ABI; the oracles only check."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+SEED = bytes(range(32))
+
+
+@pytest.fixture(scope="module")
+def ctx64(hip_lib):
+    """A context for up to 64 parties of 64 bits: 2 x 4,096 table rows.  At the default 40 GB table budget these are 16-bit
+    windows (4.2 MB a row), one window more than the 32-party context the headline runs on."""
+    c = hip_lib.Context(0, 64)
+    yield c
+    c.close()
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _leaves(rng, height, n, vmax, top_bit=False):
+    """n distinct sorted leaf indexes below 2^height; top_bit: half of them with the highest index bit set (>= 2^63 at height 64)."""
+    lo = rng.integers(0, 1 << min(height - 1, 62), size=4 * n, dtype=np.uint64)
+    if height - 1 > 62:
+        lo |= rng.integers(0, 2, size=4 * n, dtype=np.uint64) << np.uint64(62)
+    idx = np.unique(lo)[:n]
+    if top_bit:
+        idx[len(idx) // 2:] |= np.uint64(1) << np.uint64(height - 1)
+    else:
+        idx |= (rng.integers(0, 2, size=len(idx), dtype=np.uint64) << np.uint64(height - 1))
+    idx = np.unique(idx)
+    n = len(idx)
+    v = rng.integers(0, vmax, size=n, dtype=np.uint64)
+    r = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    r[:, 31] &= 0x0F
+    return idx, v, r
+
+
+def _oracle_entity_blob(ref, pyref, sib_v, sib_r, policy, agg, n_bits, stream):
+    """R::generate_proof of one entity (src/range/padding.rs:88-118 / splitting.rs:100-129) with the C oracle's prover: the
+    aggregated proofs, then the individual ones, one nonce stream across them (slot base advancing by m(2n+4))."""
+    name = "padding" if policy == 0 else "splitting"
+    plan, pos = pyref.policy_plan(name, len(sib_v), agg)
+    subs = [(s, c, m) for s, c, m in plan] + [(i, 1, 1) for i in range(pos, len(sib_v))]
+    out, slot = b"", 0
+    for start, cnt, m in subs:
+        v = np.zeros(m, np.uint64)
+        r = np.zeros((m, 32), np.uint8)
+        v[:cnt] = sib_v[start:start + cnt]
+        r[:cnt] = sib_r[start:start + cnt]
+        r[cnt:, 0] = 1                                     # (0, Scalar::one()), padding.rs:100-103
+        ps = ref.ref_range_proof_size(n_bits, m)
+        buf = ctypes.create_string_buffer(ps)
+        assert ref.ref_range_prove(n_bits, m, _p(v), _p(r), SEED, ctypes.c_uint64(int(stream)), ctypes.c_uint64(slot), None, 0, buf) == 0
+        out += buf.raw
+        slot += m * (2 * n_bits + 4)
+    return out
+
+
+# (height, policy, aggregation factor): aggregation = height (the bench's choice) under both policies, one below a power of two
+# (63 parties padded to 64 / split 32+16+8+4+2+1), and a factor that leaves individual 672-byte proofs
+CASES = [(33, 0, 33), (33, 1, 33), (40, 0, 40), (40, 1, 31), (64, 0, 64), (64, 1, 64), (64, 0, 63), (64, 1, 63), (48, 0, 36)]
+
+
+@pytest.mark.parametrize("height,policy,agg", CASES)
+def test_inclusion_proofs_above_height_32(ctx64, hip_lib, ref, pyref, height, policy, agg):
+    """dapol_prove_entities + dapol_verify_entities at heights 33..64 with 64-bit proofs: sampled proofs byte for byte against the
+    C oracle's prover (ref_range_prove), every proof verifying on the GPU AND with the oracle's verifier, tampering rejected."""
+    rng = np.random.default_rng(height * 131 + policy * 7 + agg)
+    idx, v, r = _leaves(rng, height, 9, vmax=2**40)
+    n = len(idx)
+    tr = hip_lib.Tree(ctx64, height, idx, v, r, SEED)
+    t = ref.ref_tree_build(height, ctypes.c_size_t(n), _p(idx), _p(v), _p(r), SEED, 0)
+    assert t is not None
+    t = ctypes.c_void_p(t)
+    oC, oH, orr, ov = [ctypes.create_string_buffer(32) for _ in range(3)] + [ctypes.c_uint64()]
+    ref.ref_tree_root(t, oC, oH, ctypes.byref(ov), orr)
+    rC, rH, rv, rr = tr.root()
+    assert (rC, rH, rv, rr) == (oC.raw, oH.raw, ov.value, orr.raw)
+    pC, pH, proofs = tr.prove_entities(idx, policy, agg, 64, SEED)
+    assert proofs.shape[1] == hip_lib.lib().dapol_entity_proof_size(height, policy, agg, 64)
+    _, _, sv, sr = tr.paths(idx)
+    for k in (0, n // 2, n - 1):                            # first / middle / last leaf (the last one has its top index bit set or not at random)
+        sC, sH, s_r, s_v = [ctypes.create_string_buffer(32 * height) for _ in range(3)] + [(ctypes.c_uint64 * height)()]
+        assert ref.ref_tree_path(t, ctypes.c_uint64(int(idx[k])), sC, sH, s_v, s_r) == 1
+        assert pC[k].tobytes() == sC.raw and pH[k].tobytes() == sH.raw and list(map(int, sv[k])) == list(s_v) and sr[k].tobytes() == s_r.raw
+        want = _oracle_entity_blob(ref, pyref, np.array(list(s_v), np.uint64), np.frombuffer(s_r.raw, np.uint8).reshape(height, 32), policy, agg, 64, idx[k])
+        assert proofs[k].tobytes() == want, (height, policy, agg, k)
+    ref.ref_tree_free(t)
+    # the oracle's verifier accepts the first aggregated proof of entity 0 over its (padded) sibling commitments
+    name = "padding" if policy == 0 else "splitting"
+    plan, _ = pyref.policy_plan(name, height, agg)
+    start, cnt, m = plan[0]
+    ps = ref.ref_range_proof_size(64, m)
+    Vs = pC[0, start:start + cnt].tobytes() + pyref.B_BLINDING.compress() * (m - cnt)
+    c7 = bytes([7]) + bytes(31)
+    assert ref.ref_range_verify(64, m, proofs[0, :ps].tobytes(), ctypes.c_size_t(ps), Vs, c7, 0) == 1
+    # DapolProof::verify on the GPU: every entity; a flipped range-proof bit, sibling hash or root fails exactly where it should
+    lC, lH = ctx64.commit_hash_batch(v, r)
+    args = (policy, agg, 64)
+    assert ctx64.verify_entities(height, idx, lC, lH, pC, pH, rC, rH, *args, proofs, verify_seed=SEED).all()
+    bad = proofs.copy()
+    bad[1, proofs.shape[1] - 3] ^= 4
+    assert list(ctx64.verify_entities(height, idx, lC, lH, pC, pH, rC, rH, *args, bad, verify_seed=SEED)) == [1, 0] + [1] * (n - 2)
+    badh = pH.copy()
+    badh[2, 0, 9] ^= 1                                      # the sibling next to the root
+    assert list(ctx64.verify_entities(height, idx, lC, lH, pC, badh, rC, rH, *args, proofs, verify_seed=SEED)) == [1, 1, 0] + [1] * (n - 3)
+    assert not ctx64.verify_entities(height, idx, lC, lH, pC, pH, rC, bytes([rH[0] ^ 1]) + rH[1:], *args, proofs, verify_seed=SEED).any()
+
+
+def test_height_64_top_bit_leaves_build_update_prove_verify(ctx64, hip_lib, ref, pyref):
+    """Leaf indexes >= 2^63 (the whole upper half of a height-64 tree) through build -> paths -> prove -> verify and through
+    dapol_tree_update (replace + insert, in place): the tree equals a fresh build at every level, proofs equal the oracle's."""
+    rng = np.random.default_rng(6464)
+    height = 64
+    idx, v, r = _leaves(rng, height, 40, vmax=2**32, top_bit=True)
+    n = len(idx)
+    assert (idx >> np.uint64(63)).sum() >= n // 2 - 1 and int(idx.max()) >= 2**63
+    full = hip_lib.Tree(ctx64, height, idx, v, r, SEED)
+    t = ctypes.c_void_p(ref.ref_tree_build(height, ctypes.c_size_t(n), _p(idx), _p(v), _p(r), SEED, 0))
+    oC, oH, orr, ov = [ctypes.create_string_buffer(32) for _ in range(3)] + [ctypes.c_uint64()]
+    ref.ref_tree_root(t, oC, oH, ctypes.byref(ov), orr)
+    assert full.root() == (oC.raw, oH.raw, ov.value, orr.raw)
+    assert sum(full.node_count()) == ref.ref_tree_node_count(t)
+    # grow a tree that lacks three leaves (two above 2^63, one below) by update(): batches of up to n/8 + 1 new leaves are inserted
+    # in place (dapol_tree_update), then three liabilities are replaced
+    hi_half = np.flatnonzero(idx >> np.uint64(63))
+    gone = np.array([1, hi_half[1], hi_half[-1]])
+    keep = np.setdiff1d(np.arange(n), gone)
+    part = hip_lib.Tree(ctx64, height, idx[keep], v[keep], r[keep], SEED)
+    part.update(idx[gone[::-1]], v[gone[::-1]], r[gone[::-1]])          # (unsorted on purpose)
+    assert part.last_update_path() in (2, 3)                # inserted in place, not rebuilt
+    assert part.root() == full.root()
+    assert part.node_count() == full.node_count()
+    for k in range(height + 1):
+        a, b = part.level_nodes(k), full.level_nodes(k)
+        oa, ob = np.argsort(a[0], kind="stable"), np.argsort(b[0], kind="stable")
+        for x, y in zip(a, b):
+            assert np.array_equal(np.asarray(x)[oa], np.asarray(y)[ob]), k
+    top = np.flatnonzero(idx >> np.uint64(63))
+    chg = np.array([top[0], top[-1], 0])
+    v2 = v.copy()
+    v2[chg] += np.uint64(5)
+    part.update(idx[chg], v2[chg], r[chg])
+    assert part.last_update_path() == 1
+    again = hip_lib.Tree(ctx64, height, idx, v2, r, SEED)
+    assert part.root() == again.root() and part.root()[2] == int(v2.sum())
+    # prove the top-half leaves on the updated tree; compare with the oracle's tree over the same leaves
+    ref.ref_tree_free(t)
+    t = ctypes.c_void_p(ref.ref_tree_build(height, ctypes.c_size_t(n), _p(idx), _p(v2), _p(r), SEED, 0))
+    sel = idx[top[:4]]
+    pC, pH, proofs = part.prove_entities(sel, 0, height, 64, SEED)
+    ps = ref.ref_range_proof_size(64, 64)
+    out = ctypes.create_string_buffer(ps * len(sel))
+    assert ref.ref_prove_entities_padding(t, ctypes.c_size_t(len(sel)), _p(sel), 64, SEED, 0, out) == 0
+    assert proofs.tobytes() == out.raw
+    ref.ref_tree_free(t)
+    rC, rH, _, _ = part.root()
+    lC, lH = ctx64.commit_hash_batch(v2[top[:4]], r[top[:4]])
+    assert ctx64.verify_entities(height, sel, lC, lH, pC, pH, rC, rH, 0, height, 64, proofs, verify_seed=SEED).all()
+    wrong = sel.copy()
+    wrong[0] ^= np.uint64(1) << np.uint64(63)               # the same proof presented for the mirror position below 2^63
+    assert list(ctx64.verify_entities(height, wrong, lC, lH, pC, pH, rC, rH, 0, height, 64, proofs, verify_seed=SEED)) == [0, 1, 1, 1]
+    with pytest.raises(hip_lib.DapolError) as e:
+        part.paths([int(idx[top[0]]) ^ 1])                  # a neighbour that holds no liability: Dapol::generate_proof -> None
+    assert e.value.code == 9
+
+
+def test_batch_proof_above_height_32(ctx64, hip_lib, pyref):
+    """Dapol::generate_proof_batch (mod.rs:172-190) for three leaves of a height-40 tree: more than 64 deduplicated siblings, so
+    the padding policy aggregates 64 of them and proves the rest individually; verifies on the GPU, a swapped sibling does not."""
+    rng = np.random.default_rng(4040)
+    height = 40
+    idx, v, r = _leaves(rng, height, 12, vmax=2**30)
+    tr = hip_lib.Tree(ctx64, height, idx, v, r, SEED)
+    rC, rH, _, _ = tr.root()
+    sel = idx[[1, 5, 10]]
+    S = len(hip_lib.batch_siblings(height, sel)[0])
+    assert S > 64
+    lC, lH = ctx64.commit_hash_batch(v[[1, 5, 10]], r[[1, 5, 10]])
+    for policy, agg in ((0, 64), (1, 63)):
+        level, index, sC, sH, blob = tr.prove_batch(sel, policy, agg, 64, SEED)
+        assert list(zip(map(int, level), map(int, index))) == pyref.batch_siblings(height, [int(x) for x in sel])
+        assert len(blob) == hip_lib.lib().dapol_entity_proof_size(S, policy, agg, 64)
+        assert ctx64.verify_batch(height, sel, lC, lH, sC, sH, rC, rH, policy, agg, 64, blob, verify_seed=SEED)
+        bad = sC.copy()
+        bad[3] = sC[4]
+        assert not ctx64.verify_batch(height, sel, lC, lH, bad, sH, rC, rH, policy, agg, 64, blob, verify_seed=SEED)
+
+
+def test_64_party_range_proofs_every_call_size_regime(ctx64, ref):
+    """m = 64 parties x 64 bits (N = 4,096 generators a side, 12 inner-product rounds) through the latency shapes (a few proofs),
+    the mid-size shapes and the generator-stationary sweep (>= 1,024 proofs): the same bytes as the C oracle for sampled proofs,
+    and the same bytes for a proof whichever regime computed it."""
+    rng = np.random.default_rng(64064)
+    n_bits, m, b = 64, 64, 1100
+    v = rng.integers(0, 2**63, size=(b, m), dtype=np.uint64)
+    v[0, 0] = 2**64 - 1
+    v[1, :] = 0
+    r = rng.integers(0, 256, size=(b, m, 32), dtype=np.uint8)
+    r[:, :, 31] &= 0x0F
+    sid = rng.integers(0, 2**64, size=b, dtype=np.uint64)
+    big = ctx64.range_prove_batch(n_bits, m, v, r, nonce_seed=SEED, stream_id=sid)              # sweep regime
+    small = ctx64.range_prove_batch(n_bits, m, v[:3], r[:3], nonce_seed=SEED, stream_id=sid[:3])  # latency shapes
+    mid = ctx64.range_prove_batch(n_bits, m, v[:70], r[:70], nonce_seed=SEED, stream_id=sid[:70])
+    assert small.tobytes() == big[:3].tobytes() and mid.tobytes() == big[:70].tobytes()
+    ps = ref.ref_range_proof_size(n_bits, m)
+    assert big.shape[1] == ps == 32 * (9 + 2 * 12)
+    for k in (0, 1, 2, 69, b - 1):
+        out = ctypes.create_string_buffer(ps)
+        assert ref.ref_range_prove(n_bits, m, _p(v[k]), _p(r[k]), SEED, ctypes.c_uint64(int(sid[k])), ctypes.c_uint64(0), None, 0, out) == 0
+        assert big[k].tobytes() == out.raw, k
+    C, _ = ctx64.commit_hash_batch(v[:70].reshape(-1), r[:70].reshape(-1, 32))
+    V = C.reshape(70, m, 32)
+    ok = ctx64.range_verify_batch(n_bits, m, mid, V, verify_seed=SEED)
+    assert ok.all()
+    bad = mid.copy()
+    bad[5, 100] ^= 1
+    V2 = V.copy()
+    V2[9, 63] = V[9, 62]
+    assert list(ctx64.range_verify_batch(n_bits, m, bad, V, verify_seed=SEED)) == [1] * 5 + [0] + [1] * 64
+    assert list(ctx64.range_verify_batch(n_bits, m, mid, V2, verify_seed=SEED)) == [1] * 9 + [0] + [1] * 60
+
+
+@pytest.mark.parametrize("digest", ["blake3", "blake2s"])
+@pytest.mark.parametrize("serial", [False, True])
+def test_failed_to_map_index_on_the_device(gpu_ctx, hip_lib, pyref, digest, serial):
+    """DapolError::FailedToMapIndex (mod.rs:369-370).  With 2^height >= 2 n (Dapol::new, :110-116) every try finds a free slot with
+    probability >= 1/2, so 128 tries fail with probability < 2^-128: no input reaches the error.  The test knob
+    DAPOL_LEAF_MAX_TRIES lowers the limit (read only because the tests opt in to DAPOL_ENV_KNOBS) -- the SAME code path, at the
+    sparsity bound where almost half of the entities collide.  The device names the entity the reference's sequential loop stops
+    at (both the claim / settle rounds and the one-lane walk), and with a limit that everybody survives the indexes are pyref's."""
+    dg = hip_lib.DIGEST_BLAKE3 if digest == "blake3" else hip_lib.DIGEST_BLAKE2S
+    height, n = 9, 256
+    liabs = [(b"int-%d" % i, b"ext-%d" % (i * 7), i + 1) for i in range(n)]
+    knobs = {"DAPOL_LEAF_SERIAL": "1"} if serial else {}
+    saved = {k: os.environ.get(k) for k in ("DAPOL_LEAF_MAX_TRIES", "DAPOL_LEAF_SERIAL")}
+    os.environ.update(knobs)
+    try:
+        seen = 0
+        for tries in (1, 2, 3, 5):
+            os.environ["DAPOL_LEAF_MAX_TRIES"] = str(tries)
+            try:
+                want, _ = pyref.build_leaf_nodes(liabs, b"audit", height, digest, max_tries=tries)
+                want_fail = None
+            except pyref.DapolError as e:
+                want_fail = e.args[1]
+            if want_fail is None:
+                out = gpu_ctx.build_leaf_nodes(liabs, b"audit", height, dg)
+                assert [int(x) for x in out["leaf_idx"]] == [i for i, _ in want]
+            else:
+                seen += 1
+                with pytest.raises(hip_lib.DapolError) as e:
+                    gpu_ctx.build_leaf_nodes(liabs, b"audit", height, dg)
+                assert e.value.code == 5
+                assert "within %d tries (liability %d in input order)" % (tries, want_fail) in str(e.value)
+        assert seen >= 2                                    # the error was really produced (1 and 2 tries cannot place 256 in 512)
+    finally:
+        for k, val in saved.items():
+            if val is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = val
+    out = gpu_ctx.build_leaf_nodes(liabs, b"audit", height, dg)        # the real limit: everybody maps
+    want, _ = pyref.build_leaf_nodes(liabs, b"audit", height, digest)
+    assert [int(x) for x in out["leaf_idx"]] == [i for i, _ in want]
+
+
+def test_liability_ids_of_any_length(gpu_ctx, hip_lib, pyref):
+    """mod.rs:347-349, 358-360 hash ids of any length.  BLAKE3 inputs beyond one 1,024-byte chunk go through the tree mode (chunk
+    chaining values + parent nodes, kernels_leaf.h / hash.h dg_init_long): ids of 0 ... 70,000 bytes, lengths around the chunk
+    and subtree boundaries, against pyref (whose BLAKE3 is pinned by tests/golden/blake3_long.json) -- indexes, blindings, order."""
+    rng = np.random.default_rng(1025)
+    seed = b"audit seed"
+    lens = [0, 1, 900, 1024 - len(seed), 1025 - len(seed), 1025, 2048, 2049 - len(seed), 3000, 4096, 5000, 8192, 8193, 20000, 70000]
+    liabs = []
+    for i, ln in enumerate(lens):
+        iid = bytes(rng.integers(0, 256, size=ln, dtype=np.uint8)) + bytes([i])          # distinct internal ids
+        eid = bytes(rng.integers(0, 256, size=lens[-1 - i], dtype=np.uint8))
+        liabs.append((iid, eid, 10 + i))
+    for dg_name, dg in (("blake3", hip_lib.DIGEST_BLAKE3), ("blake2s", hip_lib.DIGEST_BLAKE2S)):
+        out = gpu_ctx.build_leaf_nodes(liabs, seed, 40, dg)
+        want, id_map = pyref.build_leaf_nodes(liabs, seed, 40, dg_name)
+        assert [int(x) for x in out["leaf_idx"]] == [i for i, _ in want]
+        assert [int(x) for x in out["idx_by_entity"]] == [id_map[l[0]] for l in liabs]
+        assert [out["r"][k].tobytes() for k in range(len(want))] == [nd.r.to_bytes(32, "little") for _, nd in want]
+        assert [int(x) for x in out["v"]] == [nd.v for _, nd in want]
+    # a duplicated LONG internal id is still found (mod.rs:341-343)
+    with pytest.raises(hip_lib.DapolError) as e:
+        gpu_ctx.build_leaf_nodes(liabs + [(liabs[9][0], b"x", 1)], seed, 40, hip_lib.DIGEST_BLAKE3)
+    assert e.value.code == 4

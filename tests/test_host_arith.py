@@ -146,6 +146,18 @@ def test_hashes_and_transcript(host_shim, pyref):
         assert o.raw == hashlib.blake2s(m).digest(), n
         host_shim.t_digest(0, m, n, o)
         assert o.raw == R.blake3(m), n
+    # BLAKE3 beyond one chunk (dg_init_long: chunk chaining values + parent nodes) against vectors made by the BLAKE3 team's C code
+    # (tests/golden/blake3_long.json); the stack-less digest flags such inputs instead of hashing them wrongly
+    from conftest import load_golden
+    for vec in load_golden("blake3_long.json")["vectors"]:
+        n = vec["len"]
+        m = bytes(i % 251 for i in range(n))
+        o = buf(32)
+        host_shim.t_digest(0, m, n, o)
+        assert o.raw.hex() == vec["hash"], n
+        assert host_shim.t_digest_short(0, m, n, o) == (1 if n > 1024 else 0), n
+        host_shim.t_digest(1, m, n, o)
+        assert o.raw == hashlib.blake2s(m).digest(), n
     o = buf(64)
     host_shim.t_merlin(b"test protocol", 13, b"some label", 10, b"some data", 9, b"challenge", 9, o)
     t = R.Transcript(b"test protocol")

@@ -78,6 +78,16 @@ def test_blake3_official_vectors(pyref):
     assert pyref.blake3(inp).hex() == "42214739f095a406f3fc83deb889744ac00df831c10daa55189b5d121c855af7"
 
 
+def test_blake3_beyond_one_chunk(pyref):
+    """Tree mode (liability ids of any length, src/dapol/mod.rs:347-349): official input pattern at the official lengths and around
+    the chunk / subtree boundaries, against hashes made with the BLAKE3 team's own C code (tests/golden/gen_blake3_kat.py)."""
+    from conftest import load_golden
+    for vec in load_golden("blake3_long.json")["vectors"]:
+        assert pyref.blake3(bytes(i % 251 for i in range(vec["len"]))).hex() == vec["hash"], vec["len"]
+    # the 1,025-byte official vector, from the published test_vectors.json (independent of the generator above)
+    assert pyref.blake3(bytes(i % 251 for i in range(1025))).hex() == "d00278ae47eb27b34faecf67b4fe263f82d5412916c1ffd97c8cb7fb814b8444"
+
+
 def test_reference_index_kats(pyref):
     """src/dapol/tests.rs:30-85 (a->7, b->12, c->2, d->4), :24 (root value 26): Blake2s, seed "test", height 4."""
     liab = [(b"a", b"w", 3), (b"b", b"x", 5), (b"c", b"y", 7), (b"d", b"z", 11)]
