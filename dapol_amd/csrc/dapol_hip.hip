@@ -48,6 +48,7 @@ static int32_t fail(int32_t code, const char* msg) {
 // process has opted in -- DAPOL_ENV_KNOBS set to anything but "0", or dapol_env_knobs(1) -- so that a host embedding the library
 // does not inherit behaviour from stray variables; what an embedder may want to set is a field of dapol_options.
 static std::atomic<int> g_env_knobs{-1};          // -1: ask the environment
+static std::atomic<unsigned long long> g_fork_guard_waits{0};   // side streams a ForkGuard had to wait for (early returns between fork and join)
 static const char* knob(const char* name) {
     int on = g_env_knobs.load(std::memory_order_relaxed);
     if (on < 0) {
@@ -145,6 +146,38 @@ static bool options_ok(const dapol_options* o) {
     if (o->gs_slices != 0 && o->gs_slices != 1 && o->gs_slices != 2 && o->gs_slices != 4 && o->gs_slices != 8 && o->gs_slices != 16) return false;
     return true;
 }
+// A FORK hands kernels that read and write the context's scratch (or a call's own buffers) to a side stream; the matching JOIN makes
+// the context's stream wait for them.  An early return between the two -- any HIPCHK / LAUNCH_CHECK -- would leave those kernels
+// running while the caller's next call reuses the scratch, or after the call's buffers are freed.  This guard, one per forking
+// function, waits for every side stream that was forked and not yet joined when the function is left.  (Nothing to wait for on the
+// normal path: the join has closed it.)
+struct ForkGuard {
+    dapol_ctx* c;
+    bool open[3] = {false, false, false};
+    explicit ForkGuard(dapol_ctx* c_) : c(c_) {}
+    ForkGuard(const ForkGuard&) = delete;
+    ForkGuard& operator=(const ForkGuard&) = delete;
+    void forked(int i) { open[i] = true; }
+    void joined(int i) { open[i] = false; }
+    ~ForkGuard() {
+        for (int i = 0; i < 3; i++)
+            if (open[i]) { (void)hipStreamSynchronize(c->side[i]); g_fork_guard_waits.fetch_add(1, std::memory_order_relaxed); }
+    }
+};
+// Test knob (opt-in only, like every DAPOL_* variable): DAPOL_TEST_FAIL_AFTER_FORK=<site> makes the named site return an error right
+// after its fork, as a failed launch would -- tests/test_gpu_fault_paths.py then checks that the next call on the context is clean.
+#define FAULT_AFTER_FORK(site)                                                                                          \
+    do {                                                                                                                \
+        const char* e_ = knob("DAPOL_TEST_FAIL_AFTER_FORK");                                                            \
+        if (e_ && !strcmp(e_, site)) return fail(DAPOL_ERR_HIP, "injected failure after the fork at " site " (test knob)"); \
+    } while (0)
+
+int32_t dapol_diag_fork_guard_waits(uint64_t* count) {
+    if (!count) return fail(DAPOL_ERR_INVALID_ARGUMENT, "null argument");
+    *count = g_fork_guard_waits.load(std::memory_order_relaxed);
+    return DAPOL_OK;
+}
+
 int32_t dapol_ctx_create(int32_t device, int32_t max_parties, int32_t digest_id, dapol_ctx** out) {
     return dapol_ctx_create_opts(device, max_parties, digest_id, nullptr, out);
 }
@@ -355,6 +388,7 @@ struct dapol_tree {
     uint64_t n_pad = 0, n_real = 0;
     int index_bits = 0, shard_bits = 0;          // what the tree was built with (dapol_tree_update rebuilds with the same)
     uint8_t pad_seed[32] = {0};
+    bool invalid = false;              // an in-place update failed after its first write: root and leaves may disagree; every call refuses the tree
     DevBuf<LevelView> d_views;         // view(0..height, nullptr) on the device, for kernels that walk several levels
     LevelView view(int k, int32_t* ext) {
         LevelBuf& L = levels[k];
@@ -367,6 +401,20 @@ struct dapol_tree {
         lv.has_pad = L.has_pad.p; lv.parent = L.parent.p; lv.ext = ext;
         return lv;
     }
+};
+
+// dapol_tree_update re-merges in place; an error between its first write and its last (a HIP failure) leaves a tree whose upper
+// levels no longer match its leaves.  Such a tree is marked and every entry point refuses it, loudly, instead of proving from it.
+static int32_t tree_usable(const dapol_tree* t) {
+    if (t && t->invalid)
+        return fail(DAPOL_ERR_INVALID_ARGUMENT, "the tree was left inconsistent by an in-place update that failed midway: destroy it and build it again");
+    return DAPOL_OK;
+}
+#define TREE_USABLE(t) do { int32_t rc_ = tree_usable(t); if (rc_) return rc_; } while (0)
+struct TreePoison {                    // armed before the first write of an in-place update, disarmed when the last one has completed
+    dapol_tree* t;
+    bool armed = false;
+    ~TreePoison() { if (armed) t->invalid = true; }
 };
 
 // Builds the tree from device-resident leaf arrays (d_idx sorted; d_r is masked in place).  own==true: the tree
@@ -416,7 +464,7 @@ static int32_t tree_build_device(dapol_ctx* ctx, int index_bits, int shard_bits,
         }
         const size_t pad_at = need;
         need += pad_total;
-        HIPCHK(t->arena.alloc(need));
+        if (t->arena.n < need) HIPCHK(t->arena.alloc(need));      // (a workload hands the arena of its previous build on: no hipFree / hipMalloc per step)
         HIPCHK(hipMemsetAsync(t->arena.p + pad_at, 0, pad_total, st));
         size_t pad_off = pad_at;
         for (int k = 0; k <= height; k++) {
@@ -454,16 +502,20 @@ static int32_t tree_build_device(dapol_ctx* ctx, int index_bits, int shard_bits,
         HIPCHK(hipMemcpyAsync(t->d_views.p, hv.data(), hv.size() * sizeof(LevelView), hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(d_off, h_off.data(), h_off.size() * 4, hipMemcpyHostToDevice, st));
         // the leaves' commitments do not depend on the structure: they run on a side stream beside S and P
+        ForkGuard fg(ctx);
         HIPCHK(hipEventRecord(ctx->ev_fork, st));
         HIPCHK(hipStreamWaitEvent(ctx->side[0], ctx->ev_fork, 0));
+        fg.forked(0);
         hipLaunchKernelGGL(k_commit_hash, dim3(nblk(n, 64)), dim3(64), 0, ctx->side[0], ctx->tv, n, d_v, d_r, t->levels[0].C.p, t->levels[0].H.p, ext_all);
         LAUNCH_CHECK();
         HIPCHK(hipEventRecord(ctx->ev_join[0], ctx->side[0]));
+        FAULT_AFTER_FORK("tree");
         hipLaunchKernelGGL(k_tree_structure_small, dim3(1), dim3(1024), 0, st, height, t->d_views.p, cnt.p);
         LAUNCH_CHECK();
         hipLaunchKernelGGL(k_tree_padding_all, dim3(nblk(h_off[height], 64)), dim3(64), 0, st, ctx->tv, t->d_views.p, height, cnt.p, d_off, seed.p, extpad_all);
         LAUNCH_CHECK();
         HIPCHK(hipStreamWaitEvent(st, ctx->ev_join[0], 0));
+        fg.joined(0);
         for (int k = 0; k < height; k++) {
             hipLaunchKernelGGL(k_tree_sum_level, dim3(nblk(bound[k], 64)), dim3(64), 0, st, hv[k], hv[k + 1], k, cnt.p, ext_all + (size_t)h_off[k] * 40,
                                extpad_all + (size_t)h_off[k] * 40, ext_all + (size_t)h_off[k + 1] * 40);
@@ -609,6 +661,8 @@ static int32_t tree_update_incremental(dapol_tree_owned* own, size_t k, const st
     if (found_out) { found_out->resize(k); HIPCHK(hipMemcpyAsync(found_out->data(), d + o_found, k, hipMemcpyDeviceToHost, st)); }
     HIPCHK(hipStreamSynchronize(st));
     if (missing) return DAPOL_OK;                            // a new index: nothing has been written; the caller inserts or rebuilds
+    TreePoison poison{own, true};                            // from here on the leaves and the levels above are rewritten in place
+    if (knob("DAPOL_TEST_FAIL_UPDATE_MIDWAY")) return fail(DAPOL_ERR_HIP, "injected failure between the leaf update and the re-merge (test knob)");
     hipLaunchKernelGGL(k_tree_upd_leaves, dim3(nblk(k, 64)), dim3(64), 0, st, ctx->tv, own->d_views.p, U);
     LAUNCH_CHECK();
     if (H >= 1) {
@@ -625,6 +679,7 @@ static int32_t tree_update_incremental(dapol_tree_owned* own, size_t k, const st
         }
     }
     HIPCHK(hipStreamSynchronize(st));
+    poison.armed = false;
     *done = true;
     return DAPOL_OK;
 }
@@ -739,6 +794,7 @@ static int32_t tree_insert_incremental(dapol_tree_owned* own, size_t k, const st
         LAUNCH_CHECK();
     }
     // adopt the new storage, refresh the device-side views
+    TreePoison poison{own, true};                            // the tree's own state changes from here on
     for (int t = 0; t < max_m; t++) { own->levels[t] = newL[t]; own->alt[t].cur = new_cur[t]; }
     own->leaf_idx = n_leaf_idx; own->leaf_v = n_leaf_v; own->leaf_r = n_leaf_r;
     std::vector<LevelView> hv((size_t)H + 1);
@@ -764,6 +820,7 @@ static int32_t tree_insert_incremental(dapol_tree_owned* own, size_t k, const st
     }
     HIPCHK(hipStreamSynchronize(st));
     for (size_t j = 0; j < k; j++) { own->n_real += hm[j]; own->n_pad += (uint64_t)hm[j] - 2 + 0; }     // m - 1 new padding nodes, one dropped
+    poison.armed = false;
     *done = true;
     return DAPOL_OK;
 }
@@ -771,6 +828,7 @@ static int32_t tree_insert_incremental(dapol_tree_owned* own, size_t k, const st
 int32_t dapol_tree_update(dapol_tree* tree, size_t k, const uint64_t* leaf_idx, const uint64_t* v, const uint8_t* r32) {
     if (!tree || (k && (!leaf_idx || !v || !r32))) return fail(DAPOL_ERR_INVALID_ARGUMENT, "null argument");
     if (k == 0) return DAPOL_OK;
+    TREE_USABLE(tree);
     dapol_tree_owned* own = static_cast<dapol_tree_owned*>(tree);
     if (!own->leaves.idx.p) return fail(DAPOL_ERR_INVALID_ARGUMENT, "tree does not own its leaves (workload tree): rebuild the workload instead");
     dapol_ctx* ctx = tree->ctx;
@@ -829,6 +887,7 @@ int32_t dapol_tree_update(dapol_tree* tree, size_t k, const uint64_t* leaf_idx, 
                     rc = tree_update_incremental(own, ei.size(), ei, ev, er, &done);
                     if (rc != DAPOL_OK) return rc;
                     if (done) { own->last_update_path = 3; return DAPOL_OK; }
+                    own->invalid = true;                     // the new leaves are in, the replacements are not
                     return fail(DAPOL_ERR_INVALID_ARGUMENT, "internal: a leaf found before the insert was not found after it");
                 }
             }
@@ -1014,6 +1073,7 @@ int32_t dapol_tree_destroy(dapol_tree* tree) {
 
 int32_t dapol_tree_root(dapol_tree* tree, uint8_t C32[32], uint8_t H32[32], uint64_t* v, uint8_t r32[32]) {
     if (!tree) return fail(DAPOL_ERR_INVALID_ARGUMENT, "null tree");
+    TREE_USABLE(tree);
     HIPCHK(hipSetDevice(tree->ctx->device));
     LevelView lv = tree->view(tree->height, nullptr);
     if (C32) HIPCHK(hipMemcpy(C32, lv.C, 32, hipMemcpyDeviceToHost));
@@ -1025,6 +1085,7 @@ int32_t dapol_tree_root(dapol_tree* tree, uint8_t C32[32], uint8_t H32[32], uint
 
 int32_t dapol_tree_node_count(dapol_tree* tree, uint64_t* real_nodes, uint64_t* padding_nodes) {
     if (!tree) return fail(DAPOL_ERR_INVALID_ARGUMENT, "null tree");
+    TREE_USABLE(tree);
     if (real_nodes) *real_nodes = tree->n_real;
     if (padding_nodes) *padding_nodes = tree->n_pad;
     return DAPOL_OK;
@@ -1040,6 +1101,7 @@ static int32_t level_pad_flags(dapol_tree* tree, int level, std::vector<uint8_t>
 
 int32_t dapol_tree_level_size(dapol_tree* tree, int32_t level, uint64_t* n_real, uint64_t* n_pad) {
     if (!tree || level < 0 || level > tree->height) return fail(DAPOL_ERR_INVALID_ARGUMENT, "bad level");
+    TREE_USABLE(tree);
     HIPCHK(hipSetDevice(tree->ctx->device));
     std::vector<uint8_t> hp;
     int32_t rc = level_pad_flags(tree, level, hp);
@@ -1055,6 +1117,7 @@ int32_t dapol_tree_level_nodes(dapol_tree* tree, int32_t level, uint64_t* idx, u
                                uint8_t* is_pad) {
     if (!tree || level < 0 || level > tree->height || !idx || !v || !r32 || !C32 || !H32 || !is_pad)
         return fail(DAPOL_ERR_INVALID_ARGUMENT, "bad argument");
+    TREE_USABLE(tree);
     HIPCHK(hipSetDevice(tree->ctx->device));
     LevelView lv = tree->view(level, nullptr);
     size_t n = lv.n;
@@ -1089,6 +1152,7 @@ int32_t dapol_tree_level_nodes(dapol_tree* tree, int32_t level, uint64_t* idx, u
 
 // Gathers the siblings of b leaves into device buffers (any of which may be null).
 static int32_t tree_paths_device(dapol_tree* tree, size_t b, const uint64_t* d_leaf_idx, PathOut out, uint32_t* d_pos, int n_upper = 0) {
+    TREE_USABLE(tree);
     hipStream_t st = tree->ctx->stream;
     DevBuf<uint32_t> missing;
     HIPCHK(missing.alloc(1));

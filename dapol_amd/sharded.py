@@ -60,14 +60,30 @@ def top_levels(ctx, records, rank, merge=None):
     return (C[0].tobytes(), H[0].tobytes(), int(v[0]), r[0].tobytes()), upper
 
 
-def create_library_comm(ctx, rank, world, dist, torch, device, timeout_s=90.0):
+def agreement_group(dist, comm_device):
+    """The process group the ranks AGREE on (ok flags of the library's collectives).  It must not ride the transport that may have
+    just failed: when the default group is RCCL (comm_device "cuda") this is a side group over gloo / TCP with CPU tensors; a
+    default group that already is gloo serves as it is (None).  Collective: every rank calls it at the same point."""
+    if comm_device != "cuda":
+        return None
+    return dist.new_group(backend="gloo")
+
+
+def all_agree(dist, torch, group, ok):
+    """all-reduce MIN of one flag over the agreement group (a CPU tensor): True iff every rank said ok."""
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int64)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return int(flag.item()) == 1
+
+
+def create_library_comm(ctx, rank, world, dist, torch, device, timeout_s=90.0, group=None, agree=None):
     """The RCCL communicator INSIDE libdapol_hip.so for ranks that already share a torch.distributed group: rank 0 draws the
     128-byte id, a torch.distributed broadcast carries it, and every rank creates its end NON-BLOCKING with a deadline
     (dapol_comm_create_timeout: ncclCommInitRankConfig(blocking = 0) polled with ncclCommGetAsyncError; a communicator that has
-    not come up by the deadline is aborted inside the call, not abandoned).  The ranks then AGREE on the outcome (all-reduce MIN)
-    before anybody tears anything down: if any rank failed, the ranks that did get a communicator abort it (ncclCommAbort --
-    never a destroy that would wait for a peer that is gone) and all of them get (None, None, reason).
-    Returns (comm or None, ncclCommCount or None, error text or None)."""
+    not come up by the deadline is aborted inside the call, not abandoned).  The ranks then AGREE on the outcome (all-reduce MIN,
+    over the agreement group when one is given) before anybody tears anything down: if any rank failed, the ranks that did get a
+    communicator abort it (ncclCommAbort -- never a destroy that would wait for a peer that is gone) and all of them get
+    (None, None, reason).  Returns (comm or None, ncclCommCount or None, error text or None)."""
     comm, ranks, err, ok = None, None, None, 1
     try:
         uid = capi.comm_unique_id() if rank == 0 else bytes(capi.COMM_ID_BYTES)
@@ -79,13 +95,113 @@ def create_library_comm(ctx, rank, world, dist, torch, device, timeout_s=90.0):
             raise capi.DapolError(10, "ncclCommCount says %d ranks, expected %d" % (ranks, world))
     except Exception as e:
         err, ok = repr(e), 0
-    flag = torch.tensor([ok], dtype=torch.int64, device=device)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    if int(flag.item()) == 1:
+    if agree is not None:
+        everybody = agree(bool(ok))
+    else:
+        flag = torch.tensor([ok], dtype=torch.int64, device="cpu" if group is not None else device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        everybody = int(flag.item()) == 1
+    if everybody:
         return comm, ranks, None
     if comm is not None:
         comm.abort()
     return None, None, err or "another rank could not create its communicator"
+
+
+class ShardTransport:
+    """The two collectives of the sharded path -- the all-gather of the subtree-root records and the final reduce -- with their
+    fallback.  The first choice is the RCCL communicator inside libdapol_hip.so (`comm`); torch.distributed carries them otherwise
+    (gloo: CPU tests, two ranks sharing one GPU) and after the library's communicator has failed.
+
+    A failing collective does NOT fail on every rank by itself: the deadlines are per-rank wall clocks, and an asynchronous RCCL
+    error or a timeout can hit one rank while its peers complete the very same all-gather.  If each rank decided alone, one would
+    sit in a torch all_gather while the others went on to the library's all-reduce on a communicator the first has aborted --
+    mismatched collectives, i.e. the hang the deadline exists to prevent.  So after EVERY library collective the ranks all-reduce
+    (MIN) an ok flag over the agreement group (gloo, CPU tensors: never the transport in question) BEFORE the next collective;
+    only if somebody failed do they all abort their communicators -- never destroy: a destroy waits for peers -- and redo that
+    collective over torch.distributed, together.  One small gloo all-reduce per collective, two per step (tens of microseconds
+    against a step of seconds)."""
+
+    def __init__(self, ctx, rank, world, dist, torch, comm_device="cuda", merge=None):
+        self.ctx, self.rank, self.world, self.dist, self.torch, self.comm_device, self.merge = ctx, rank, world, dist, torch, comm_device, merge
+        self.comm, self.comm_ranks, self.comm_error = None, None, None
+        self.group = None                         # agreement group (None: the default group, which must then be a CPU-capable one)
+        self.agreements = 0                       # ok-flag all-reduces done so far (diagnostics / tests)
+        self.path = "none (single GPU)" if world == 1 else self._torch_path()
+
+    def _torch_path(self, after_failure=False):
+        return "torch.distributed (%s)%s" % ("RCCL" if self.comm_device == "cuda" else "gloo", ", after the library's collective failed" if after_failure else "")
+
+    def create_comm(self, timeout_s=90.0):
+        """Collective: every rank calls it.  Creates the agreement group, then the library's communicator."""
+        import os
+        if self.world == 1 or self.comm_device != "cuda" or os.environ.get("DAPOL_EXCHANGE", "").lower() == "torch":
+            return
+        self.group = agreement_group(self.dist, self.comm_device)
+        self.comm, self.comm_ranks, self.comm_error = create_library_comm(self.ctx, self.rank, self.world, self.dist, self.torch, self.comm_device,
+                                                                          timeout_s, agree=self.agree)
+        if self.comm is not None:
+            self.path = "libdapol_hip.so (RCCL inside the library)"
+
+    def agree(self, ok):
+        self.agreements += 1
+        return all_agree(self.dist, self.torch, self.group, ok)
+
+    def drop_comm(self, err):
+        """Every rank has agreed that a collective of the library's communicator failed somewhere: abort it, carry on over torch."""
+        self.comm_error = repr(err) if err is not None else "the collective failed on another rank"
+        try:
+            self.comm.abort()
+        except Exception:
+            pass
+        self.comm, self.comm_ranks = None, None
+        self.path = self._torch_path(after_failure=True)
+
+    def _library(self, call):
+        """Runs one collective of the library's communicator and the agreement after it.  -> (True, result) when EVERY rank's call
+        succeeded; (False, None) after the ranks have dropped their communicators together."""
+        res, err = None, None
+        try:
+            res = call()
+        except capi.DapolError as e:
+            err = e
+        if self.agree(err is None):
+            return True, res
+        self.drop_comm(err)
+        return False, None
+
+    def exchange(self, root):
+        """All-gather of the G subtree-root records + the replicated top levels -> (global root record, upper siblings of this rank)."""
+        if self.world == 1:
+            return root, None
+        if self.comm is not None:
+            ok, res = self._library(lambda: self.comm.exchange(root))                                 # RCCL over xGMI, in the library
+            if ok:
+                return res
+        buf = exchange_records(self.dist, self.torch, pack_record(root), self.world, self.comm_device)
+        return top_levels(self.ctx, unpack_records(buf, self.world), self.rank, merge=self.merge)
+
+    def reduce_u64(self, word, op="sum"):
+        """The final reduce of one 64-bit word: wrapping sum (proof-transcript checksums) or min (AND of 0/1 verdicts)."""
+        if self.world == 1:
+            return int(word)
+        if self.comm is not None:
+            ok, res = self._library(lambda: int(self.comm.allreduce([int(word)], capi.REDUCE_SUM if op == "sum" else capi.REDUCE_MIN)[0]))
+            if ok:
+                return res
+        t = self.torch
+        if op == "min":
+            x = t.tensor([int(word)], dtype=t.int64, device=self.comm_device)
+            self.dist.all_reduce(x, op=self.dist.ReduceOp.MIN)
+            return int(x.item())
+        cs = t.tensor([int(word) & 0xFFFFFFFF, int(word) >> 32], dtype=t.int64, device=self.comm_device)    # two 32-bit halves: no int64 overflow
+        self.dist.all_reduce(cs)
+        return (int(cs[0].item()) + (int(cs[1].item()) << 32)) & 0xFFFFFFFFFFFFFFFF
+
+    def close(self):
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None
 
 
 class ShardedProver:
@@ -102,70 +218,34 @@ class ShardedProver:
         self.w = capi.Workload(ctx, height, leaf_idx, v, r32, shard_bits=self.shard_bits) if len(self.idx) else None
         self.upper = None
         self.root = None
-        self.comm = None
-        self.comm_ranks = None                    # ncclCommCount of the library's communicator, when it carries the exchange
-        self.comm_error = None
-        self.exchange_path = "none (single GPU)"
-        if world > 1:
-            self.exchange_path = "torch.distributed all_gather (%s)" % ("RCCL" if comm_device == "cuda" else "gloo")
-            if comm_device == "cuda":
-                self._create_comm()
+        self.transport = ShardTransport(ctx, rank, world, dist, torch, comm_device)
+        self.transport.create_comm()
 
-    def _create_comm(self, timeout_s=90.0):
-        import os
-        if os.environ.get("DAPOL_EXCHANGE", "").lower() == "torch":
-            return
-        self.comm, self.comm_ranks, self.comm_error = create_library_comm(self.ctx, self.rank, self.world, self.dist, self.torch, self.comm_device, timeout_s)
-        if self.comm is not None:
-            self.exchange_path = "dapol_shard_exchange (ncclAllGather inside libdapol_hip.so)"
+    # the transport's state under the names bench.py and the tests read
+    comm = property(lambda self: self.transport.comm, lambda self, c: setattr(self.transport, "comm", c))
+    comm_ranks = property(lambda self: self.transport.comm_ranks)
+    comm_error = property(lambda self: self.transport.comm_error)
 
-    def _drop_comm(self, err):
-        """A collective of the library's communicator failed mid-run (it timed out or RCCL reported an asynchronous error):
-        abort the communicator -- never destroy it, a destroy waits for peers -- and carry on over torch.distributed.  A failed
-        collective fails on every rank of it (same call, same deadline), so the ranks switch together."""
-        self.comm_error = repr(err)
-        try:
-            self.comm.abort()
-        except Exception:
-            pass
-        self.comm, self.comm_ranks = None, None
-        self.exchange_path = "torch.distributed all_gather (%s), after the library's collective failed" % ("RCCL" if self.comm_device == "cuda" else "gloo")
-
-    def _exchange(self, root):
+    @property
+    def exchange_path(self):
+        t = self.transport
         if self.world == 1:
-            self.root, self.upper = root, None
-            return
-        if self.comm is not None:
-            try:
-                self.root, self.upper = self.comm.exchange(root)                                         # RCCL over xGMI, in the library
-                return
-            except capi.DapolError as e:
-                self._drop_comm(e)
-        buf = exchange_records(self.dist, self.torch, pack_record(root), self.world, self.comm_device)
-        recs = unpack_records(buf, self.world)
-        self.root, self.upper = top_levels(self.ctx, recs, self.rank)
+            return t.path
+        if t.comm is not None:
+            return "dapol_shard_exchange (ncclAllGather inside libdapol_hip.so)"
+        return t.path.replace("torch.distributed (", "torch.distributed all_gather (")
 
     def step(self, pad_seed, nonce_seed, n_bits=64):
         if self.w is None:
             C, H, r = self.ctx.padding_nodes(pad_seed, [self.height - self.shard_bits], [self.rank])
             root, st = (C[0].tobytes(), H[0].tobytes(), 0, r[0].tobytes()), capi.WorkloadStats()
-            self._exchange(root)
+            self.root, self.upper = self.transport.exchange(root)
         else:
             root, st = self.w.build(pad_seed)
-            self._exchange(root)
+            self.root, self.upper = self.transport.exchange(root)
             st = self.w.prove(nonce_seed, n_bits, upper=self.upper, stats=st)
-        local = st.checksum
-        if self.world > 1 and self.comm is not None:
-            try:
-                st.checksum = int(self.comm.allreduce([local], capi.REDUCE_SUM)[0])                      # ncclAllReduce, wrapping sum
-            except capi.DapolError as e:
-                self._drop_comm(e)
-        if self.world > 1 and self.comm is None:
-            t = self.torch
-            # final reduce of the aggregated proof transcript checksum (wrapping 64-bit sum, carried as two 32-bit halves)
-            cs = t.tensor([local & 0xFFFFFFFF, local >> 32], dtype=t.int64, device=self.comm_device)
-            self.dist.all_reduce(cs)
-            st.checksum = (int(cs[0].item()) + (int(cs[1].item()) << 32)) & 0xFFFFFFFFFFFFFFFF
+        # final reduce of the aggregated proof transcript checksum (wrapping 64-bit sum)
+        st.checksum = self.transport.reduce_u64(st.checksum, "sum")
         return st
 
     def sample_paths(self, leaf_ids, pad_seed, with_nodes=False):

@@ -105,6 +105,9 @@ int32_t dapol_ctx_destroy(dapol_ctx* ctx);
 int32_t dapol_ctx_generator(dapol_ctx* ctx, int32_t which, int32_t party, int32_t bit, uint8_t out32[32]);
 const char* dapol_strerror(int32_t code);
 const char* dapol_last_error(void);
+/* Diagnostics: how many times a call was left between a fork onto one of the context's side streams and the matching join (an error
+ * return) and therefore waited for that stream before returning, process-wide.  0 in a healthy run. */
+int32_t dapol_diag_fork_guard_waits(uint64_t* count);
 
 /* DapolNode::new (src/dapol/node.rs:29-45), batched: C_i = v_i*B + r_i*B_blinding (compressed), H_i = D(C_i).
  * r may be an unreduced Scalar::from_bits value (bit 255 clear; src/dapol/mod.rs:385). */
@@ -156,7 +159,11 @@ int32_t dapol_tree_destroy(dapol_tree* tree);
  * order -- a leaf is inserted, or replaces the liability already at its index (the last of several updates of one
  * index wins).  Afterwards the tree equals dapol_tree_build of the resulting leaf set bit for bit (padding nodes
  * are keyed by position, so the reference test's build-vs-update root equality, src/tests.rs:48, holds exactly).
- * Only for trees from dapol_tree_build / dapol_tree_build_shard.  On error the tree is unchanged. */
+ * Only for trees from dapol_tree_build / dapol_tree_build_shard.  An error reported before anything was written (bad arguments,
+ * an index outside the tree or the shard, an allocation that failed) leaves the tree unchanged.  Small batches are re-merged IN
+ * PLACE on the device; a HIP failure between the first and the last write of such an update leaves upper levels that no longer
+ * match the leaves: the tree is then marked invalid and every later call on it returns DAPOL_ERR_INVALID_ARGUMENT ("left
+ * inconsistent ...") -- destroy it and build it again. */
 int32_t dapol_tree_update(dapol_tree* tree, size_t k, const uint64_t* leaf_idx, const uint64_t* v, const uint8_t* r32);
 /* What the last dapol_tree_update on this tree did: 0 = rebuilt, 1 = replaced existing leaves in place, 2 = inserted new leaves in
  * place, 3 = both (diagnostics; the tree is the same whichever path ran). */

@@ -19,12 +19,14 @@ def test_bench_two_ranks_share_one_gpu(hip_lib):
         port = str(sk.getsockname()[1])
     env = dict(os.environ, DAPOL_BENCH_BACKEND="gloo", DAPOL_TABLE_GB="3", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
-           port, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log2-entities", "9", "--weak", "--height", "16", "--steps", "2", "--warmup", "1"]
+           port, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log2-entities", "9", "--weak", "--height", "16", "--steps", "2", "--warmup", "1", "--cpu-budget-s", "3"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak"
-    assert line["config"]["entities_total"] == 1024 and line["cpu_baseline"] is None
+    assert line["config"]["entities_total"] == 1024
+    assert line["cpu_baseline"]["kind"] == "port" and "rank 0" in line["cpu_baseline"]["note_multi_gpu"]      # a scaling line is self-contained
+    assert line["roofline"]["whole_step"]["achieved"] > 0
     assert line["parity"]["bit_exact"] and line["parity"]["proofs_compared"] > 0
     assert line["parity"]["inclusion_proofs_verified_on_gpu"] == line["parity"]["inclusion_proofs_checked"] == 512
     # the same 1,024 entities on one rank give the same aggregate checksum (the reduce of the per-rank transcripts)
@@ -43,7 +45,7 @@ def test_bench_gpus_2_without_a_launcher_spawns_its_ranks(hip_lib):
     defaults to the metric's configuration: STRONG scaling, --log2-entities names the TOTAL."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(DAPOL_BENCH_BACKEND="gloo", DAPOL_TABLE_GB="3")
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log2-entities", "10", "--height", "16", "--steps", "2", "--warmup", "1"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log2-entities", "10", "--height", "16", "--steps", "2", "--warmup", "1", "--cpu-budget-s", "3"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -53,7 +55,7 @@ def test_bench_gpus_2_without_a_launcher_spawns_its_ranks(hip_lib):
     assert line["config"]["entities_total"] == 1024 and line["config"]["entities_per_gpu"] == 512
     assert "strong scaling" in line["config"]["workload"] and "gloo" in line["config"]["exchange"]
     assert line["parity"]["bit_exact"] and line["parity"]["inclusion_proofs_verified_on_gpu"] == line["parity"]["inclusion_proofs_checked"]
-    assert line["secondary"] is None and line["cpu_baseline"] is None       # N = 1 legs
+    assert line["secondary"] is None and line["cpu_baseline"]["value"] > 0   # the secondary legs are N = 1 only; the CPU baseline is in every line
 
 
 @pytest.mark.gpu

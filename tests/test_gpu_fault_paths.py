@@ -1,0 +1,140 @@
+"""Error paths of the GPU library: what a failure in the MIDDLE of a call leaves behind.
+ * A call that forks work onto one of the context's side streams and returns early (a failed launch, a failed HIP call) must not
+   leave that work running on the context's scratch: the ForkGuard waits for it (dapol_diag_fork_guard_waits counts), and the
+   next call on the same context gives the oracle's bytes / the right verdicts.  Failures are injected right after each fork
+   through the opt-in test knob DAPOL_TEST_FAIL_AFTER_FORK (round-2 advisor finding, round-3 verdict item 8).
+ * dapol_tree_update re-merges in place; a failure between its first and last write leaves a tree that refuses every later
+   call instead of proving from upper levels that no longer match the leaves (round-3 advisor finding)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+SEED = bytes(range(32))
+
+
+def _waits(hip_lib):
+    c = ctypes.c_uint64(0)
+    assert hip_lib.lib().dapol_diag_fork_guard_waits(ctypes.byref(c)) == 0
+    return c.value
+
+
+class _knob:
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.saved = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update(self.kv)
+
+    def __exit__(self, *a):
+        for k, v in self.saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _small_tree(hip_lib, ctx, height=8, n=12, seed=3):
+    rng = np.random.default_rng(seed)
+    idx = np.sort(rng.choice(1 << height, size=n, replace=False).astype(np.uint64))
+    v = rng.integers(0, 8, size=n, dtype=np.uint64)
+    r = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    r[:, 31] &= 0x0F
+    return idx, v, r, hip_lib.Tree(ctx, height, idx, v, r, SEED)
+
+
+def test_an_error_after_a_fork_leaves_the_context_clean(hip_lib, ref):
+    ctx = hip_lib.Context(0, 8)
+    height, n_bits = 8, 8
+    idx, v, r, tr = _small_tree(hip_lib, ctx)
+    rC, rH, _, _ = tr.root()
+    pC, pH, proofs = tr.prove_entities(idx, 0, height, n_bits, SEED)          # the reference bytes of this context, before any fault
+    lC, lH = ctx.commit_hash_batch(v, r)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    t = ctypes.c_void_p(ref.ref_tree_build(height, ctypes.c_size_t(len(idx)), p(idx), p(v), p(r), SEED, 0))
+    want = ctypes.create_string_buffer(proofs.size)
+    assert ref.ref_prove_entities_padding(t, ctypes.c_size_t(len(idx)), p(idx), n_bits, SEED, 0, want) == 0
+    ref.ref_tree_free(t)
+    assert proofs.tobytes() == want.raw
+
+    def clean():
+        """The next calls on the context: oracle bytes from the prover, the right verdicts from the verifier, the same tree."""
+        _, _, again = tr.prove_entities(idx, 0, height, n_bits, SEED)
+        assert again.tobytes() == want.raw
+        bad = proofs.copy()
+        bad[3, 40] ^= 1
+        assert list(ctx.verify_entities(height, idx, lC, lH, pC, pH, rC, rH, 0, height, n_bits, bad, verify_seed=SEED)) == [1, 1, 1, 0] + [1] * (len(idx) - 4)
+        assert hip_lib.Tree(ctx, height, idx, v, r, SEED).root() == tr.root()
+
+    E = hip_lib.DapolError
+    # every forking site: (knob value, the call that reaches it)
+    big_v = np.random.default_rng(1).integers(0, 256, size=(1000, 2), dtype=np.uint64)
+    big_r = np.zeros((1000, 2, 32), np.uint8)
+    big_r[:, :, 0] = 7
+    sid = np.arange(1000, dtype=np.uint64)
+    few = slice(0, 4)
+    opts = hip_lib.Options(chunk_proofs=64, streams=2)
+    sites = [
+        ("tree", lambda: hip_lib.Tree(ctx, height, idx, v, r, SEED)),                                          # phased build: leaf commitments on side[0]
+        ("prove_A", lambda: tr.prove_entities(idx[few], 0, height, n_bits, SEED)),                             # small call: A commitment on side[2]
+        ("verify_paths", lambda: ctx.verify_entities(height, idx[few], lC[few], lH[few], pC[few], pH[few], rC, rH, 0, height, n_bits, proofs[few], verify_seed=SEED)),
+        ("verify_var", lambda: ctx.verify_entities(height, idx[few], lC[few], lH[few], pC[few], pH[few], rC, rH, 0, height, n_bits, proofs[few], verify_seed=SEED)),
+    ]
+    for site, call in sites:
+        before = _waits(hip_lib)
+        with _knob(DAPOL_TEST_FAIL_AFTER_FORK=site):
+            with pytest.raises(E) as e:
+                call()
+        assert e.value.code == 17 and "injected failure after the fork at " + site in str(e.value), site
+        assert _waits(hip_lib) == before + 1, site                             # the guard waited for exactly the forked stream
+        clean()
+    # the chunks in flight on the side streams of a multi-chunk prove call (3+ chunks of 64 proofs on two streams)
+    ctx.set_options(opts)
+    ok_bytes = ctx.range_prove_batch(8, 2, big_v, big_r, nonce_seed=SEED, stream_id=sid)
+    before = _waits(hip_lib)
+    with _knob(DAPOL_TEST_FAIL_AFTER_FORK="prove_lanes"):
+        with pytest.raises(E) as e:
+            ctx.range_prove_batch(8, 2, big_v, big_r, nonce_seed=SEED, stream_id=sid)
+    assert e.value.code == 17 and _waits(hip_lib) == before + 1
+    assert ctx.range_prove_batch(8, 2, big_v, big_r, nonce_seed=SEED, stream_id=sid).tobytes() == ok_bytes.tobytes()
+    ctx.set_options(hip_lib.Options())
+    clean()
+    # the bucket-method verifier decodes its points on side[0] (a batch of >= 112 proofs is checked as one combination)
+    C2, _ = ctx.commit_hash_batch(big_v.reshape(-1), big_r.reshape(-1, 32))
+    V2 = C2.reshape(1000, 2, 32)
+    with _knob(DAPOL_VERIFY_PIPPENGER_MIN="12288"):            # 1,000 proofs x 14 points: the bucket method
+        base = ctx.range_verify_batch(8, 2, ok_bytes, V2, verify_seed=SEED)
+        assert base.all()
+        before = _waits(hip_lib)
+        with _knob(DAPOL_TEST_FAIL_AFTER_FORK="verify_decode"):
+            with pytest.raises(E) as e:
+                ctx.range_verify_batch(8, 2, ok_bytes, V2, verify_seed=SEED)
+        assert e.value.code == 17 and _waits(hip_lib) == before + 1
+        bad2 = ok_bytes.copy()
+        bad2[150, 90] ^= 1
+        assert list(ctx.range_verify_batch(8, 2, bad2, V2, verify_seed=SEED)) == [1] * 150 + [0] + [1] * 849
+    clean()
+
+
+def test_failed_in_place_update_marks_the_tree_invalid(hip_lib):
+    ctx = hip_lib.Context(0, 8)
+    idx, v, r, tr = _small_tree(hip_lib, ctx, n=40, seed=9)
+    root0 = tr.root()
+    E = hip_lib.DapolError
+    with pytest.raises(E) as e:
+        tr.update([int(idx[0]) ^ 1 if (int(idx[0]) ^ 1) in set(map(int, idx)) else 1 << 20], [1], r[:1])      # index outside the tree: reported before any write
+    assert tr.root() == root0                                                 # ... the tree is unchanged and usable
+    with _knob(DAPOL_TEST_FAIL_UPDATE_MIDWAY="1"):
+        with pytest.raises(E) as e:
+            tr.update(idx[:2], v[:2] + np.uint64(1), r[:2])                    # fails between the leaf rewrite and the re-merge
+    assert e.value.code == 17
+    for call in (tr.root, tr.node_count, lambda: tr.paths(idx[:1]), lambda: tr.level_nodes(0), lambda: tr.update(idx[:1], v[:1], r[:1]),
+                 lambda: tr.prove_entities(idx[:1], 0, 8, 8, SEED), lambda: tr.prove_batch(idx[:2], 0, 3, 8, SEED)):
+        with pytest.raises(E) as e:
+            call()
+        assert e.value.code == 8 and "left inconsistent" in str(e.value)
+    tr.close()                                                                # destroying it is fine, and the context is unharmed
+    assert hip_lib.Tree(ctx, 8, idx, v, r, SEED).root() == root0

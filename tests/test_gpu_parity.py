@@ -563,7 +563,13 @@ def test_sharded_prover_falls_back_when_a_library_collective_fails(gpu_ctx, hip_
             out[0].copy_(mine)
             out[1].copy_(torch.from_numpy(rec1))
 
-        def all_reduce(self, t, op=None):
+        class ReduceOp:
+            MIN = "min"
+
+        def all_reduce(self, t, op=None, group=None):
+            if op == "min":                              # the agreement after a library collective: the replayed rank saw no error
+                self.agreements = getattr(self, "agreements", 0) + 1
+                return
             t += torch.tensor(self.other, dtype=t.dtype)
 
     class BadComm:
@@ -594,6 +600,7 @@ def test_sharded_prover_falls_back_when_a_library_collective_fails(gpu_ctx, hip_
         p, st = run(bad, [5, 7])
         assert bad.aborted and p.comm is None and p.comm_ranks is None
         assert "failed" in p.exchange_path and "nccl" in p.comm_error
+        assert p.dist.agreements == (1 if fail_exchange else 2)          # the ranks agreed after every library collective, none after the drop
         assert p.root == full.root()
         assert st.checksum == (st0.checksum + 5 + (7 << 32)) & 0xFFFFFFFFFFFFFFFF
         st2 = p.step(SEED, SEED, n_bits)                 # and the next step stays on the fallback

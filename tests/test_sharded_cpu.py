@@ -67,3 +67,106 @@ def test_two_rank_exchange_gloo():
     for p in ps:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+# ---------------------------------------------------------------------------------------- the agreed fallback (ShardTransport)
+class _FakeLibraryComm:
+    """Stands in for dapol_comm on a CPU box: the collective itself COMPLETES on every rank (carried by gloo here), and then this
+    rank's call may report a failure -- a per-rank deadline that fired, an asynchronous RCCL error -- as DapolError, exactly the
+    situation the agreement step exists for: one rank sees an error, its peers see success."""
+
+    def __init__(self, dist, torch, capi, sharded, rank, world, merge, fail_exchange=False, fail_allreduce=False):
+        self.dist, self.torch, self.capi, self.sharded, self.rank, self.world, self.merge = dist, torch, capi, sharded, rank, world, merge
+        self.fail_exchange, self.fail_allreduce, self.aborted, self.calls = fail_exchange, fail_allreduce, False, 0
+
+    def exchange(self, root):
+        self.calls += 1
+        buf = self.sharded.exchange_records(self.dist, self.torch, self.sharded.pack_record(root), self.world, "cpu")
+        if self.fail_exchange:
+            raise self.capi.DapolError(19, "ncclAllGather did not complete within 90000 ms (rank %d of %d): communicator aborted" % (self.rank, self.world))
+        return self.sharded.top_levels(None, self.sharded.unpack_records(buf, self.world), self.rank, merge=self.merge)
+
+    def allreduce(self, words, op=None):
+        self.calls += 1
+        if op == self.capi.REDUCE_MIN:
+            t = self.torch.tensor([int(w) for w in words], dtype=self.torch.int64)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+            return [int(x) for x in t]
+        t = self.torch.tensor([int(w) & 0xFFFFFFFF for w in words] + [int(w) >> 32 for w in words], dtype=self.torch.int64)
+        self.dist.all_reduce(t)
+        if self.fail_allreduce:
+            raise self.capi.DapolError(19, "ncclAllReduce: unhandled system error")
+        k = len(words)
+        return [(int(t[i]) + (int(t[k + i]) << 32)) & 0xFFFFFFFFFFFFFFFF for i in range(k)]
+
+    def abort(self):
+        self.aborted = True
+
+    def close(self):
+        pass
+
+
+def _agree_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch
+    import torch.distributed as dist
+    import pyref as R
+    from dapol_amd import capi, sharded
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    H, seed = 5, bytes(range(32))
+    leaves_all = [(i, R.node_new(3 + i, 1000 + i)) for i in (1, 6, 9, 13, 18, 29)]
+    full = R.Tree(H, leaves_all, seed)
+    node = full.levels[H - 1][rank]
+    sub_root = (node.C, node.H, node.v, R.scalar_bytes(node.r))
+    want_root = (full.root.C, full.root.H, full.root.v, R.scalar_bytes(full.root.r))
+    merge = _oracle_merge(R)
+    local = [0x1111222233334444, 0xF000000000000001][rank]          # per-rank "checksums": the wrapping sum overflows 64 bits
+    want_sum = (0x1111222233334444 + 0xF000000000000001) & 0xFFFFFFFFFFFFFFFF
+    out = {}
+    # (scenario, which rank's exchange fails, which rank's all-reduce fails): only ONE rank ever sees the error
+    for name, fx, fa in (("exchange fails on rank 0", 0, None), ("exchange fails on rank 1", 1, None), ("all-reduce fails on rank 1", None, 1),
+                         ("nothing fails", None, None)):
+        tr = sharded.ShardTransport(None, rank, world, dist, torch, comm_device="cpu", merge=merge)
+        fake = _FakeLibraryComm(dist, torch, capi, sharded, rank, world, merge, fail_exchange=(fx == rank), fail_allreduce=(fa == rank))
+        tr.comm, tr.comm_ranks = fake, world
+        ok = True
+        for step in range(2):                                        # the second step runs on whatever transport the first one left
+            root, upper = tr.exchange(sub_root)
+            cs = tr.reduce_u64(local, "sum")
+            ok &= root == want_root and cs == want_sum
+            ok &= upper[0][0].tobytes() == full.levels[H - 1][rank ^ 1].C
+        failed = fx is not None or fa is not None
+        # EVERY rank dropped its communicator (also the one whose own calls all succeeded), or nobody did
+        ok &= (tr.comm is None) == failed and fake.aborted == failed
+        ok &= ("after the library's collective failed" in tr.path) == failed
+        ok &= tr.agreements == ((1 if fx is not None else 2) if failed else 4)        # one agreement per library collective, none after the drop
+        ok &= fake.calls == ((1 if fx is not None else 2) if failed else 4)
+        if failed:
+            ok &= ("did not complete" in tr.comm_error or "unhandled" in tr.comm_error) if (fx == rank or fa == rank) else "another rank" in tr.comm_error
+        calls_before = fake.calls
+        ok &= tr.reduce_u64(rank, "min") == 0 and tr.reduce_u64(1, "min") == 1       # the verdict AND of bench.py --mode verify
+        ok &= fake.calls == calls_before + (0 if failed else 2)                       # through the library's communicator while it lives
+        out[name] = bool(ok)
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_one_rank_failing_makes_every_rank_fall_back_together():
+    """Round-3 verdict item 4 / advisor: a library collective that fails on ONE rank only (per-rank deadlines) must not split the
+    ranks.  Two gloo ranks, a stand-in communicator whose collective completes everywhere and then reports an error on one rank:
+    after the agreement both ranks abort, both redo the collective over torch.distributed, and both end every step with the same
+    root and the same checksum."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    ps = [ctx.Process(target=_agree_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+    assert [r for r, _ in res] == [0, 1]
+    for _, out in res:
+        assert out and all(out.values()), out
