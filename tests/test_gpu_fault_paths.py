@@ -64,12 +64,16 @@ def test_an_error_after_a_fork_leaves_the_context_clean(hip_lib, ref):
         """The next calls on the context: oracle bytes from the prover, the right verdicts from the verifier, the same tree."""
         _, _, again = tr.prove_entities(idx, 0, height, n_bits, SEED)
         assert again.tobytes() == want.raw
+        if small:
+            assert ctx.range_prove_batch(32, 8, small[0], small[1], nonce_seed=SEED, stream_id=[1, 2, 3, 4]).tobytes() == small[2].tobytes()
+            assert ctx.range_verify_batch(32, 8, small[2], small[3], verify_seed=SEED).all()
         bad = proofs.copy()
         bad[3, 40] ^= 1
         assert list(ctx.verify_entities(height, idx, lC, lH, pC, pH, rC, rH, 0, height, n_bits, bad, verify_seed=SEED)) == [1, 1, 1, 0] + [1] * (len(idx) - 4)
         assert hip_lib.Tree(ctx, height, idx, v, r, SEED).root() == tr.root()
 
     E = hip_lib.DapolError
+    small = []
     # every forking site: (knob value, the call that reaches it)
     big_v = np.random.default_rng(1).integers(0, 256, size=(1000, 2), dtype=np.uint64)
     big_r = np.zeros((1000, 2, 32), np.uint8)
@@ -77,18 +81,32 @@ def test_an_error_after_a_fork_leaves_the_context_clean(hip_lib, ref):
     sid = np.arange(1000, dtype=np.uint64)
     few = slice(0, 4)
     opts = hip_lib.Options(chunk_proofs=64, streams=2)
+    # a few proofs of 256 generators a side (32 bits x 8 parties): the latency shapes, which fork the A commitment / the proof's own points
+    sv = np.random.default_rng(2).integers(0, 2**32, size=(4, 8), dtype=np.uint64)
+    sr = np.zeros((4, 8, 32), np.uint8)
+    sr[:, :, 1] = 9
+    sC, _ = ctx.commit_hash_batch(sv.reshape(-1), sr.reshape(-1, 32))
+    sproofs = ctx.range_prove_batch(32, 8, sv, sr, nonce_seed=SEED, stream_id=[1, 2, 3, 4])
+    small[:] = [sv, sr, sproofs, sC.reshape(4, 8, 32)]
+    want32 = ctypes.create_string_buffer(sproofs.size)
+    assert ref.ref_range_prove_batch(32, 8, ctypes.c_size_t(4), p(sv), p(sr), SEED, p(np.array([1, 2, 3, 4], np.uint64)), ctypes.c_uint64(0), None, 0, want32) == 0
+    assert sproofs.tobytes() == want32.raw
     sites = [
         ("tree", lambda: hip_lib.Tree(ctx, height, idx, v, r, SEED)),                                          # phased build: leaf commitments on side[0]
-        ("prove_A", lambda: tr.prove_entities(idx[few], 0, height, n_bits, SEED)),                             # small call: A commitment on side[2]
+        ("prove_A", lambda: ctx.range_prove_batch(32, 8, sv, sr, nonce_seed=SEED, stream_id=[1, 2, 3, 4])),     # small call: A commitment on side[2]
         ("verify_paths", lambda: ctx.verify_entities(height, idx[few], lC[few], lH[few], pC[few], pH[few], rC, rH, 0, height, n_bits, proofs[few], verify_seed=SEED)),
-        ("verify_var", lambda: ctx.verify_entities(height, idx[few], lC[few], lH[few], pC[few], pH[few], rC, rH, 0, height, n_bits, proofs[few], verify_seed=SEED)),
+        ("verify_var", lambda: ctx.range_verify_batch(32, 8, sproofs, sC.reshape(4, 8, 32), verify_seed=SEED)),    # small call: own points on side[1]
     ]
     for site, call in sites:
         before = _waits(hip_lib)
+        err = None
         with _knob(DAPOL_TEST_FAIL_AFTER_FORK=site):
-            with pytest.raises(E) as e:
+            try:
                 call()
-        assert e.value.code == 17 and "injected failure after the fork at " + site in str(e.value), site
+            except E as ex:
+                err = ex
+        assert err is not None, "the call never reached the fork at " + site
+        assert err.code == 17 and "injected failure after the fork at " + site in str(err), site
         assert _waits(hip_lib) == before + 1, site                             # the guard waited for exactly the forked stream
         clean()
     # the chunks in flight on the side streams of a multi-chunk prove call (3+ chunks of 64 proofs on two streams)
