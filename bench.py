@@ -351,8 +351,9 @@ def mode_prove(args):
     # cold (allocations, code objects: ~3 s more) and would under-count what fits; further ones only if they fit
     deadline = T_PROC0 + args.budget_s
     # what follows the timed region, as measured on the driver's run of round 3 (BENCH_r03: 34 s in all): CPU baseline 10 s + parity /
-    # verification legs ~9 s + the N = 1 secondary legs ~15 s (+ ~20 s for the full-size host-buffer leg); 25 % on top
-    post_reserve = 1.25 * ((args.cpu_budget_s + 4.0 if not args.no_cpu_baseline else 0.0) + 9.0 + (35.0 if (world == 1 and not args.no_secondary) else 0.0))
+    # verification legs ~9 s + the N = 1 secondary legs ~15 s + ~22 s for the full-size host-buffer leg (which falls back to a 2^16 sample
+    # when the budget is short); 15 % on top
+    post_reserve = 1.15 * ((args.cpu_budget_s + 4.0 if not args.no_cpu_baseline else 0.0) + 9.0 + (37.0 if (world == 1 and not args.no_secondary) else 0.0))
     warm_req, steps_req = args.warmup, args.steps
     warm_done = 0
     t_step = None
@@ -499,7 +500,7 @@ def mode_prove(args):
     if world == 1 and not args.no_secondary and prover.w is not None:
         log("secondary legs (splitting policy, API layout, host-buffer entry points)")
         try:
-            secondary = secondary_legs(ctx, capi, prover, height, n_bits, idx, v, r, n_per_gpu)
+            secondary = secondary_legs(ctx, capi, prover, height, n_bits, idx, v, r, n_per_gpu, host_leg_deadline=deadline + 15.0, t_step_hint=ms_per_step / 1e3)
         except Exception as e:                                   # the headline line must not die with a secondary leg
             secondary = {"error": repr(e)}
     line = {
@@ -527,7 +528,7 @@ def mode_prove(args):
         dist.destroy_process_group()
 
 
-def secondary_legs(ctx, capi, prover, height, n_bits, idx, v, r, n_per_gpu):
+def secondary_legs(ctx, capi, prover, height, n_bits, idx, v, r, n_per_gpu, host_leg_deadline=None, t_step_hint=None):
     """SURVEY 8(d)'s secondary measurements, each on a BOUNDED sample of the same workload (the sample is named in the entry):
       splitting    the reference bench's other policy (benches/dapol.rs:71-78).  At aggregation_factor = height = 32 the splitting
                    plan is ONE 32-party proof -- the padding policy's proof, byte for byte -- so that is checked, and the two
@@ -590,19 +591,35 @@ def secondary_legs(ctx, capi, prover, height, n_bits, idx, v, r, n_per_gpu):
                          "prove_sample": "first 2^16 leaves in index order", "prove_entities_per_s": na / t_prove,
                          "sampled_proofs_verified": int(okv.sum()), "sampled_proofs_checked": int(len(okv))}
     wa.close()
-    # ---- host buffers (PCIe-inclusive)
-    nh = min(n_per_gpu, 1 << 16)
-    tree = capi.Tree(ctx, height, idx[:nh], v[:nh], r[:nh], PAD_SEED)
-    tree.prove_entities(idx[:1024], capi.POLICY_PADDING, height, n_bits, NONCE_SEED)
+    # ---- host buffers (PCIe-inclusive): the WHOLE workload once when the wall budget allows (~22 s at 2^20), else a 2^16 sample
+    full = host_leg_deadline is None or (host_leg_deadline - time.time()) >= 1.6 * (t_step_hint or 20.0) + 6.0
+    nh = n_per_gpu if full else min(n_per_gpu, 1 << 16)
+    tree = capi.Tree(ctx, height, idx[:1024], v[:1024], r[:1024], PAD_SEED)
+    tree.prove_entities(idx[:1024], capi.POLICY_PADDING, height, n_bits, NONCE_SEED)      # warm the call path
     tree.close()
     t0 = time.perf_counter()
     tree = capi.Tree(ctx, height, idx[:nh], v[:nh], r[:nh], PAD_SEED)                      # H2D of the entity arrays + build
+    t1 = time.perf_counter()
     pC, pH, proofs = tree.prove_entities(idx[:nh], capi.POLICY_PADDING, height, n_bits, NONCE_SEED)   # D2H: 2 x 32 x 32 B of path + 992 B of proof per entity
     t_host = time.perf_counter() - t0
+    t_build_host = t1 - t0
     tree.close()
-    out["host_buffers"] = {"sample": "2^%d entities through dapol_tree_build + dapol_prove_entities (host arrays in, paths and proofs back)" % (nh.bit_length() - 1),
-                           "entities_per_s": nh / t_host, "bytes_returned_per_entity": int(pC[0].nbytes + pH[0].nbytes + proofs[0].nbytes),
-                           "note": "PCIe-inclusive; never the headline `value` (inputs resident in HBM)"}
+    bytes_in = int(idx[:nh].nbytes + v[:nh].nbytes + r[:nh].nbytes)
+    bytes_out = int(pC.nbytes + pH.nbytes + proofs.nbytes)
+    del pC, pH, proofs
+    # what the copies alone cost: the same byte counts between PAGEABLE host memory (what a caller's arrays are) and the device
+    hin = torch.empty(bytes_in, dtype=torch.uint8)
+    sync(); t0 = time.perf_counter(); din = hin.cuda(); sync(); h2d_ms = 1e3 * (time.perf_counter() - t0)
+    dout = torch.empty(bytes_out, dtype=torch.uint8, device="cuda")
+    sync(); t0 = time.perf_counter(); hout = dout.cpu(); sync(); d2h_ms = 1e3 * (time.perf_counter() - t0)
+    del din, dout, hin, hout
+    out["host_buffers"] = {"sample": ("the whole workload: 2^%d entities" if nh == n_per_gpu else "2^%d entities") % (nh.bit_length() - 1) +
+                                     " through dapol_tree_build + dapol_prove_entities (host arrays in, paths and proofs back)",
+                           "full_workload": bool(nh == n_per_gpu), "entities_per_s": nh / t_host, "seconds": t_host, "tree_build_incl_h2d_ms": 1e3 * t_build_host,
+                           "bytes_in": bytes_in, "bytes_returned": bytes_out, "bytes_returned_per_entity": bytes_out // nh,
+                           "h2d_ms_same_bytes_pageable": h2d_ms, "d2h_ms_same_bytes_pageable": d2h_ms,
+                           "note": "PCIe-inclusive; never the headline `value` (inputs resident in HBM).  h2d / d2h: plain copies of the same byte "
+                                   "counts between pageable host memory and the device, timed on their own"}
     return out
 
 
@@ -825,13 +842,15 @@ def mode_verify(args):
         elapsed = float(tt.item())
     dt = elapsed / steps
     # one bad proof on ONE rank must turn the job's verdict
-    bad = proofs.copy()
-    if rank == world - 1:
-        bad[B // 3, 100] ^= 1
-    ok_bad = ctx.range_verify_batch(n, m, bad, Vs, verify_seed=seed)
-    and_bad = verdict_and(int(ok_bad.all()))
-    local_bad_found = bool(ok_bad[B // 3] == 0 and ok_bad.sum() == B - 1) if rank == world - 1 else bool(ok_bad.all())
-    lb = verdict_and(int(local_bad_found))
+    and_bad, lb = 0, 1
+    if not args.no_bad_proof_leg:
+        bad = proofs.copy()
+        if rank == world - 1:
+            bad[B // 3, 100] ^= 1
+        ok_bad = ctx.range_verify_batch(n, m, bad, Vs, verify_seed=seed)
+        and_bad = verdict_and(int(ok_bad.all()))
+        local_bad_found = bool(ok_bad[B // 3] == 0 and ok_bad.sum() == B - 1) if rank == world - 1 else bool(ok_bad.all())
+        lb = verdict_and(int(local_bad_found))
     verdict_reduce, comm_ranks, comm_err = reduce_path(), transport.comm_ranks, transport.comm_error
     transport.close()                  # every rank, together: they have just left the same reduce
     if rank != 0:
@@ -849,6 +868,19 @@ def mode_verify(args):
         t1 = time.perf_counter() - t0
         cpu = {"value": m / t1, "unit": "commitments/s", "cores": 1, "kind": "port", "sample": "one m=%d proof, tuned, single thread: %.2f s; verdict %d" % (m, t1, okc)}
     ab = proofs.shape[1] + m * 32
+    # HBM traffic of one verification pass: from the PMC passes of tools/profile_verify.sh, quoted only when they were taken on the
+    # kernel sources that are running and on this very shape (1,024 proofs of 1,024 parties on one GPU)
+    traffic, vpmc = None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "verify_pmc.json")) as f:
+            vp = json.load(f)
+        cur = vp.get("kernel_src_sha") == kernel_src_sha()
+        vpmc = {"file": "profiles/verify_pmc.json", "current_build": bool(cur), "dominant_kernel": vp.get("dominant_kernel"),
+                "dominant_share_of_kernel_time": vp.get("dominant_share_of_kernel_time"), "per_pass": vp.get("per_pass")}
+        if cur and world == 1 and B == 1024 and m == 1024:
+            traffic = (vp["per_pass"]["hbm_read_MB"] + vp["per_pass"]["hbm_write_MB"]) * 1e6
+    except (OSError, ValueError, KeyError):
+        pass
     print(json.dumps({"metric": "verification-only throughput, aggregated Bulletproofs (m=%d), commitments/s" % m, "value": B_total * m / dt,
                       "unit": "commitments/s", "n_gpus": world, "steps": steps, "warmup": max(1, args.warmup), "ms_per_step": dt * 1e3,
                       "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "data": "synthetic",
@@ -856,10 +888,15 @@ def mode_verify(args):
                       "config": {"workload": "%d proofs x m=%d x n=64 (proof %d bytes) in total, %d per GPU, host-inclusive, replicas of the verifier"
                                              % (B_total, m, proofs.shape[1], B),
                                  "verdict_reduce": verdict_reduce, "rccl_ranks_in_library_communicator": comm_ranks, "reduce_fallback_reason": comm_err},
-                      "all_verified": bool(all_and == 1), "one_bad_proof_turns_the_job_verdict": bool(and_bad == 0 and lb == 1),
+                      "all_verified": bool(all_and == 1), "one_bad_proof_turns_the_job_verdict": (None if args.no_bad_proof_leg else bool(and_bad == 0 and lb == 1)),
                       "roofline": {"bound": "hbm", "achieved": B * ab / 1e9 / dt, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                   "frac": B * ab / 1e9 / dt / PEAK_HBM_GBS, "traffic": None, "algorithmic_bytes_per_proof": ab,
-                                   "note": "per GPU: proof + commitment bytes of this rank's proofs / step time"},
+                                   "frac": B * ab / 1e9 / dt / PEAK_HBM_GBS, "traffic": traffic, "algorithmic_bytes_per_proof": ab,
+                                   "algorithmic_bytes_per_pass": B * ab, "traffic_over_algorithmic": (traffic / (B * ab)) if traffic else None,
+                                   "from_profiles": vpmc,
+                                   "note": "per GPU and per PASS (one verification of this rank's proofs; the step is a chain of ~40 launches, none of which "
+                                           "dominates): proof + commitment bytes / step time.  traffic = FETCH_SIZE x 2 + WRITE_SIZE summed over the verifier's "
+                                           "kernels of one pass (tools/profile_verify.sh), set only from PMC passes of the running build.  The floor of a pass is "
+                                           "the serial transcript replay: 253 dependent Keccak-f per proof, ~2.3 ms whatever the batch size"},
                       "cpu_baseline": cpu}), flush=True)
     if dist is not None:
         dist.barrier()
@@ -902,7 +939,13 @@ def mode_criterion(args):
     p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
     rng = np.random.default_rng(0xD4)
     n, n_bits, rows = 1024, 64, []
-    for height in (16, 24, 32):
+    ctx32, ctx64 = ctx, None
+    for height in (16, 24, 32, 64):
+        if height > 32:
+            # MAX_TREE_HEIGHT (src/dapol/mod.rs:26): aggregation_factor = height = 64 parties, 4,096 generators a side.  A context of
+            # its own: 2 x 4,096 table rows -- at the default 40 GB budget these are 16-bit windows (16 of them instead of 15).
+            ctx32.close()
+            ctx = ctx64 = capi.Context(0, 64)
         idx, v, r = synth_inputs(n, height, 0, n)
         tree = capi.Tree(ctx, height, idx, v, r, PAD_SEED)
         rC, rH, _, _ = tree.root()
@@ -922,7 +965,7 @@ def mode_criterion(args):
                     tp.append(t1 - t0)
                     tv.append(t2 - t1)
             row = {"height": height, "policy": name, "prove_ms": 1e3 * sorted(tp)[len(tp) // 2], "verify_ms": 1e3 * sorted(tv)[len(tv) // 2],
-                   "proof_bytes": int(proofs.shape[1])}
+                   "proof_bytes": int(proofs.shape[1]), "parties": _np2(height), "window_bits": int(ctx.get_options().window_bits)}
             if ref is not None:
                 _, _, sv, sr = tree.paths(idx[picks[0]:picks[0] + 1])
                 t0 = time.perf_counter()
@@ -953,7 +996,7 @@ def mode_criterion(args):
         tree.close()
     print(json.dumps({"metric": "criterion groups of the reference (benches/dapol.rs:59-141): latency of ONE generate_proof / verify, ms",
                       "unit": "ms", "higher_is_better": False, "n_gpus": 1, "data": "synthetic", "dtype": "int32 limbs (255-bit modular integers)",
-                      "config": {"workload": "N = 1,024 strided leaves, heights 16 / 24 / 32, 64-bit proofs, aggregation_factor = height, BLAKE3"},
+                      "config": {"workload": "N = 1,024 strided leaves, heights 16 / 24 / 32 (the reference's) and 64 (its MAX_TREE_HEIGHT), 64-bit proofs, aggregation_factor = height, BLAKE3"},
                       "value": [r_["prove_ms"] for r_ in rows if r_["height"] == 32 and r_["policy"] == "padding"][0],
                       "prove_verify": rows, "build": "python bench.py --mode build"}), flush=True)
 
@@ -967,6 +1010,7 @@ def main():
     ap.add_argument("--budget-s", type=float, default=570.0,
                     help="wall budget of the whole process, counted from its start; the timed steps are clamped to fit (>= 3)")
     ap.add_argument("--cpu-budget-s", type=float, default=10.0, help="wall budget of the CPU-baseline leg")
+    ap.add_argument("--no-bad-proof-leg", action="store_true", help="--mode verify: skip the untimed pass with one bad proof (profiling: its per-proof re-check is not part of a pass)")
     ap.add_argument("--log2-entities", type=int, default=20,
                     help="entities IN TOTAL = 2^this (default 20: BASELINE configs[2], the metric's workload at every N); per GPU with --weak")
     ap.add_argument("--log2-entities-total", type=int, default=None, help="the same, spelled out (configs[3]: 22 with --gpus 8)")

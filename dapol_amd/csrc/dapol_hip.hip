@@ -108,6 +108,12 @@ struct dapol_ctx {
     // stream around its MSMs.
     hipStream_t msm_stream = nullptr;
     hipEvent_t ev_msm_pre[4] = {nullptr, nullptr, nullptr, nullptr}, ev_msm_post[4] = {nullptr, nullptr, nullptr, nullptr};
+    // Measurement knob DAPOL_STREAM_LAYOUT (round 4, profiles/r07*_stream_layout*.txt): streams with CU masks / priorities, made on
+    // first use.  layout_lane[] carry the chunks, layout_msm the VALU-bound launches of all of them when the layout separates those.
+    std::string layout_name;
+    hipStream_t layout_lane[2] = {nullptr, nullptr}, layout_msm = nullptr;
+    hipEvent_t layout_ev[2] = {nullptr, nullptr};
+    bool layout_split_msm = false;
     DevBuf<int32_t> table;       // window tables
     DevBuf<uint32_t> gens_comp;  // compressed base points of every row (for dapol_ctx_generator)
     TableView tv{};
@@ -146,6 +152,53 @@ static bool options_ok(const dapol_options* o) {
     if (o->gs_slices != 0 && o->gs_slices != 1 && o->gs_slices != 2 && o->gs_slices != 4 && o->gs_slices != 8 && o->gs_slices != 16) return false;
     return true;
 }
+// DAPOL_STREAM_LAYOUT=<name> (measurement knob): where the chunks in flight and their VALU-bound launches run.
+//   split_xcd     two chunks in flight, each on its own four XCDs (128 CUs, four L2s)
+//   split_cu      two chunks in flight, each on 16 CUs of every XCD
+//   msm:<K>       the VALU-bound launches of all chunks (sweeps, materialisation, tail MSM and tables) one after the other on 256 - K
+//                 CUs, everything else (streaming scalar kernels, Fiat-Shamir) on the other K CUs (K / 8 per XCD)
+//   prio          no masks: the VALU-bound launches on a LOW-priority stream, one after the other, the rest on HIGH-priority streams
+//   prio_lanes    no masks, no separation: two chunks in flight on two streams as by default, but created with HIGH priority for
+//                 the second (so that one chunk's launches overtake the other's instead of sharing)
+// A CU-mask bit i stands for CU i / 8 of XCD i % 8 (the driver deals the mask out round-robin over the XCCs).
+static int32_t ensure_stream_layout(dapol_ctx* c, const char* name) {
+    if (c->layout_name == name) return DAPOL_OK;
+    for (int i = 0; i < 2; i++) if (c->layout_lane[i]) { (void)hipStreamDestroy(c->layout_lane[i]); c->layout_lane[i] = nullptr; }
+    if (c->layout_msm) { (void)hipStreamDestroy(c->layout_msm); c->layout_msm = nullptr; }
+    c->layout_name.clear();
+    c->layout_split_msm = false;
+    for (int i = 0; i < 2; i++) if (!c->layout_ev[i]) HIPCHK(hipEventCreateWithFlags(&c->layout_ev[i], hipEventDisableTiming));
+    const int ncu = c->n_cu, words = (ncu + 31) / 32;
+    auto mask_of = [&](auto pred) { std::vector<uint32_t> m((size_t)words, 0u); for (int i = 0; i < ncu; i++) if (pred(i)) m[i >> 5] |= 1u << (i & 31); return m; };
+    const std::string n(name);
+    if (n == "split_xcd" || n == "split_cu") {
+        for (int h = 0; h < 2; h++) {
+            auto m = n == "split_xcd" ? mask_of([&](int i) { return ((i % 8) < 4) == (h == 0); }) : mask_of([&](int i) { return (i < ncu / 2) == (h == 0); });
+            HIPCHK(hipExtStreamCreateWithCUMask(&c->layout_lane[h], (uint32_t)words, m.data()));
+        }
+    } else if (n.rfind("msm:", 0) == 0) {
+        const int K = atoi(n.c_str() + 4);
+        if (K < 8 || K > ncu / 2 || K % 8) return fail(DAPOL_ERR_INVALID_ARGUMENT, "DAPOL_STREAM_LAYOUT=msm:<K>: K must be a multiple of 8 in [8, CUs / 2]");
+        auto small = mask_of([&](int i) { return i < K; }), big = mask_of([&](int i) { return i >= K; });
+        for (int h = 0; h < 2; h++) HIPCHK(hipExtStreamCreateWithCUMask(&c->layout_lane[h], (uint32_t)words, small.data()));
+        HIPCHK(hipExtStreamCreateWithCUMask(&c->layout_msm, (uint32_t)words, big.data()));
+        c->layout_split_msm = true;
+    } else if (n == "prio" || n == "prio_lanes") {
+        int lo = 0, hi = 0;                                   // (numerically lower = higher priority)
+        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        if (n == "prio") {
+            for (int h = 0; h < 2; h++) HIPCHK(hipStreamCreateWithPriority(&c->layout_lane[h], hipStreamDefault, hi));
+            HIPCHK(hipStreamCreateWithPriority(&c->layout_msm, hipStreamDefault, lo));
+            c->layout_split_msm = true;
+        } else {
+            HIPCHK(hipStreamCreateWithPriority(&c->layout_lane[0], hipStreamDefault, lo));
+            HIPCHK(hipStreamCreateWithPriority(&c->layout_lane[1], hipStreamDefault, hi));
+        }
+    } else return fail(DAPOL_ERR_INVALID_ARGUMENT, "unknown DAPOL_STREAM_LAYOUT");
+    c->layout_name = n;
+    return DAPOL_OK;
+}
+
 // A FORK hands kernels that read and write the context's scratch (or a call's own buffers) to a side stream; the matching JOIN makes
 // the context's stream wait for them.  An early return between the two -- any HIPCHK / LAUNCH_CHECK -- would leave those kernels
 // running while the caller's next call reuses the scratch, or after the call's buffers are freed.  This guard, one per forking
@@ -327,6 +380,11 @@ int32_t dapol_ctx_destroy(dapol_ctx* ctx) {
     }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->msm_stream) (void)hipStreamDestroy(ctx->msm_stream);
+    for (int i = 0; i < 2; i++) {
+        if (ctx->layout_lane[i]) (void)hipStreamDestroy(ctx->layout_lane[i]);
+        if (ctx->layout_ev[i]) (void)hipEventDestroy(ctx->layout_ev[i]);
+    }
+    if (ctx->layout_msm) (void)hipStreamDestroy(ctx->layout_msm);
     for (int i = 0; i < 4; i++) {
         if (ctx->ev_msm_pre[i]) (void)hipEventDestroy(ctx->ev_msm_pre[i]);
         if (ctx->ev_msm_post[i]) (void)hipEventDestroy(ctx->ev_msm_post[i]);

@@ -51,8 +51,12 @@ __device__ __forceinline__ void write_digits_gs(const RangeArgs& A, size_t p, in
 // of ONE 128-byte line of a proof's vector (the line is fetched once, by one pair of load instructions) and write the four
 // components of ONE 16-byte digit element; then the proofs, so that a wavefront's store is 256 contiguous bytes per window.
 // grid = ceil(cb * 2N / 64) blocks of 64.
-__device__ __forceinline__ bool gs_thread(const RangeArgs& A, size_t& p, int& sp) {
-    const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
+// The producers walk their blocks in a GRID-STRIDE loop (GS_BLOCKS): launched with as many blocks as there are, each does one;
+// launched with fewer (host_range.inc, DAPOL_PRODUCER_WAVES: an experiment that caps how many wavefront slots an HBM-bound
+// producer may hold beside another chunk's VALU-bound sweep), each walks several.
+#define GS_BLOCKS(A, vb) for (size_t vb = blockIdx.x, nb_ = ((size_t)(A).B * (size_t)(2 * (A).N) + 63) / 64; vb < nb_; vb += gridDim.x)
+__device__ __forceinline__ bool gs_thread(const RangeArgs& A, size_t vblock, size_t& p, int& sp) {
+    const size_t t = vblock * 64 + threadIdx.x;
     const size_t quad = t >> 2, sp4 = quad / A.B;
     p = quad - sp4 * A.B;
     sp = (int)(4 * sp4) + (int)(t & 3);
@@ -61,36 +65,40 @@ __device__ __forceinline__ bool gs_thread(const RangeArgs& A, size_t& p, int& sp
 
 // K0 (generator-stationary layout): nonces s_L, s_R + the S commitment's digits
 __global__ __launch_bounds__(64) void k_rp_nonces_gs(RangeArgs A) {
-    size_t p;
-    int sp;
-    if (!gs_thread(A, p, sp)) return;
-    const int side = sp >= A.N ? 1 : 0, q = sp - side * A.N;
-    const int j = q / A.n, ii = q - j * A.n;
-    const uint32_t slot = (uint32_t)(j * (2 * A.n + 2) + 2 + ii + (side ? A.n : 0));
-    sc s;
-    tape_scalar(s, A, p, slot);
-    st_sc((side ? A.s2 : A.s1) + p * A.N + q, s);
-    uint32_t c[8];
-    sc_from_mont(c, s);
-    write_digits_gs(A, p, sp, c);
+    GS_BLOCKS(A, vb) {
+        size_t p;
+        int sp;
+        if (!gs_thread(A, vb, p, sp)) continue;
+        const int side = sp >= A.N ? 1 : 0, q = sp - side * A.N;
+        const int j = q / A.n, ii = q - j * A.n;
+        const uint32_t slot = (uint32_t)(j * (2 * A.n + 2) + 2 + ii + (side ? A.n : 0));
+        sc s;
+        tape_scalar(s, A, p, slot);
+        st_sc((side ? A.s2 : A.s1) + p * A.N + q, s);
+        uint32_t c[8];
+        sc_from_mont(c, s);
+        write_digits_gs(A, p, sp, c);
+    }
 }
 
 // K5 (generator-stationary layout): round-k MSM scalars -> digits
 __global__ __launch_bounds__(64) void k_rp_round_prep_gs(RangeArgs A, int round) {
-    size_t p;
-    int sp;
-    if (!gs_thread(A, p, sp)) return;
-    const int side = sp >= A.N ? 1 : 0, q = sp - side * A.N;
-    const int lgh = A.lgN - 1 - round, half = 1 << lgh;
-    bool isH;
-    const int j = term_generator(round, A.N, A.lgN, side, q, isH);
-    const int off = j & (half - 1);
-    const bool upper = (j >> lgh) & 1;
-    const int vi = upper ? off : off + half;           // G_R pairs with a_L, G_L with a_R; H'_L with b_R, H'_R with b_L
-    sc v, pr;
-    ld_sc(v, (isH ? A.b : A.a) + p * A.N + vi);
-    coeff_times(pr, A, p, round, j, isH, v);           // the canonical product a_i * s_j (coefficient tables or vectors)
-    write_digits_gs(A, p, sp, pr.v);
+    GS_BLOCKS(A, vb) {
+        size_t p;
+        int sp;
+        if (!gs_thread(A, vb, p, sp)) continue;
+        const int side = sp >= A.N ? 1 : 0, q = sp - side * A.N;
+        const int lgh = A.lgN - 1 - round, half = 1 << lgh;
+        bool isH;
+        const int j = term_generator(round, A.N, A.lgN, side, q, isH);
+        const int off = j & (half - 1);
+        const bool upper = (j >> lgh) & 1;
+        const int vi = upper ? off : off + half;           // G_R pairs with a_L, G_L with a_R; H'_L with b_R, H'_R with b_L
+        sc v, pr;
+        ld_sc(v, (isH ? A.b : A.a) + p * A.N + vi);
+        coeff_times(pr, A, p, round, j, isH, v);           // the canonical product a_i * s_j (coefficient tables or vectors)
+        write_digits_gs(A, p, sp, pr.v);
+    }
 }
 
 // The sweep: rows q0 .. q0 + nq - 1 (terms of list `side`, nq a multiple of 4) added into every accumulator lane.
@@ -205,14 +213,16 @@ static_assert(GS_ACC_SLOTS >= MAT_GROUP && GS_ACC_SLOTS >= 2 * GS_MAX_SLICES, "a
 
 // grid = ceil(cb * 2N / 64) blocks of 64
 __global__ __launch_bounds__(64) void k_rp_mat_prep_gs(RangeArgs A) {
-    size_t p;
-    int sp;
-    if (!gs_thread(A, p, sp)) return;
-    const int side = sp >= A.N ? 1 : 0, rem = sp - side * A.N;
-    const int per = A.N / A.tail_n, cls = rem / per, k = rem - cls * per;
-    sc s;
-    coeff_plain(s, A, p, A.mat_round, cls + k * A.tail_n, side != 0);          // plain form
-    write_digits_gs(A, p, sp, s.v);
+    GS_BLOCKS(A, vb) {
+        size_t p;
+        int sp;
+        if (!gs_thread(A, vb, p, sp)) continue;
+        const int side = sp >= A.N ? 1 : 0, rem = sp - side * A.N;
+        const int per = A.N / A.tail_n, cls = rem / per, k = rem - cls * per;
+        sc s;
+        coeff_plain(s, A, p, A.mat_round, cls + k * A.tail_n, side != 0);          // plain form
+        write_digits_gs(A, p, sp, s.v);
+    }
 }
 
 // One class, one half (0: the generators' own rows, digits of window w; 1: their high-half rows, digits of window w + LW).
