@@ -61,17 +61,22 @@ def top_levels(ctx, records, rank, merge=None):
 
 
 def agreement_group(dist, comm_device):
-    """The process group the ranks AGREE on (ok flags of the library's collectives).  It must not ride the transport that may have
-    just failed: when the default group is RCCL (comm_device "cuda") this is a side group over gloo / TCP with CPU tensors; a
-    default group that already is gloo serves as it is (None).  Collective: every rank calls it at the same point."""
+    """The process group the ranks AGREE on (ok flags of the library's collectives) -> (group, device of its tensors).  It must not
+    ride the transport that may have just failed: when the default group is RCCL (comm_device "cuda") this is a side group over
+    gloo / TCP with CPU tensors; a default group that already is gloo serves as it is (None).  Collective: every rank calls it at
+    the same point.  If the side group cannot be made (a torch build without gloo), the agreement rides the default group with
+    device tensors -- weaker (torch's own RCCL communicator, not the library's, carries it) but never a rank deciding alone."""
     if comm_device != "cuda":
-        return None
-    return dist.new_group(backend="gloo")
+        return None, "cpu"
+    try:
+        return dist.new_group(backend="gloo"), "cpu"
+    except Exception:
+        return None, comm_device
 
 
-def all_agree(dist, torch, group, ok):
-    """all-reduce MIN of one flag over the agreement group (a CPU tensor): True iff every rank said ok."""
-    flag = torch.tensor([1 if ok else 0], dtype=torch.int64)
+def all_agree(dist, torch, group, ok, device="cpu"):
+    """all-reduce MIN of one flag over the agreement group: True iff every rank said ok."""
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=device)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
     return int(flag.item()) == 1
 
@@ -125,19 +130,21 @@ class ShardTransport:
     def __init__(self, ctx, rank, world, dist, torch, comm_device="cuda", merge=None):
         self.ctx, self.rank, self.world, self.dist, self.torch, self.comm_device, self.merge = ctx, rank, world, dist, torch, comm_device, merge
         self.comm, self.comm_ranks, self.comm_error = None, None, None
-        self.group = None                         # agreement group (None: the default group, which must then be a CPU-capable one)
+        self.group, self.group_device = None, "cpu"   # agreement group (None: the default group) and the device of its flag tensors
         self.agreements = 0                       # ok-flag all-reduces done so far (diagnostics / tests)
         self.path = "none (single GPU)" if world == 1 else self._torch_path()
 
     def _torch_path(self, after_failure=False):
         return "torch.distributed (%s)%s" % ("RCCL" if self.comm_device == "cuda" else "gloo", ", after the library's collective failed" if after_failure else "")
 
-    def create_comm(self, timeout_s=90.0):
-        """Collective: every rank calls it.  Creates the agreement group, then the library's communicator."""
+    def create_comm(self, timeout_s=90.0, even_alone=False):
+        """Collective: every rank calls it.  Creates the agreement group, then the library's communicator.
+        even_alone: also with ONE rank (a test hook: a 1-GPU box then exercises the gloo side group beside torch's RCCL group, the
+        id broadcast and the non-blocking creation exactly as N ranks would)."""
         import os
-        if self.world == 1 or self.comm_device != "cuda" or os.environ.get("DAPOL_EXCHANGE", "").lower() == "torch":
+        if (self.world == 1 and not even_alone) or self.comm_device != "cuda" or os.environ.get("DAPOL_EXCHANGE", "").lower() == "torch":
             return
-        self.group = agreement_group(self.dist, self.comm_device)
+        self.group, self.group_device = agreement_group(self.dist, self.comm_device)
         self.comm, self.comm_ranks, self.comm_error = create_library_comm(self.ctx, self.rank, self.world, self.dist, self.torch, self.comm_device,
                                                                           timeout_s, agree=self.agree)
         if self.comm is not None:
@@ -145,7 +152,7 @@ class ShardTransport:
 
     def agree(self, ok):
         self.agreements += 1
-        return all_agree(self.dist, self.torch, self.group, ok)
+        return all_agree(self.dist, self.torch, self.group, ok, self.group_device)
 
     def drop_comm(self, err):
         """Every rank has agreed that a collective of the library's communicator failed somewhere: abort it, carry on over torch."""

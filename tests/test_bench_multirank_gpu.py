@@ -73,3 +73,52 @@ def test_bench_verify_mode_two_ranks(hip_lib):
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["unit"] == "commitments/s"
     assert line["all_verified"] and line["one_bad_proof_turns_the_job_verdict"]
     assert "8 per GPU" in line["config"]["workload"] and "MIN" in line["config"]["verdict_reduce"]
+
+
+_ONE_RANK_RCCL = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+from dapol_amd import capi, sharded
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=%(port)r, NCCL_SOCKET_IFNAME="lo")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))      # torch's own RCCL communicator, as bench.py makes it
+ctx = capi.Context(0, 8)
+tr = sharded.ShardTransport(ctx, 0, 1, dist, torch, "cuda")
+tr.create_comm(timeout_s=60.0, even_alone=True)
+assert tr.comm is not None and tr.comm_ranks == 1, tr.comm_error
+assert tr.group is not None and tr.group_device == "cpu"                  # the side gloo group exists beside the RCCL default group
+assert tr.agreements == 1                                                 # the ranks agreed on the creation's outcome over it
+rng = np.random.default_rng(1)
+idx = np.sort(rng.choice(256, size=9, replace=False)).astype(np.uint64)
+v = rng.integers(0, 9, size=9, dtype=np.uint64)
+r = rng.integers(0, 256, size=(9, 32), dtype=np.uint8); r[:, 31] &= 0x0F
+root = capi.Tree(ctx, 8, idx, v, r, bytes(32)).root()
+ok, res = tr._library(lambda: tr.comm.exchange(root))                     # a library collective + the agreement after it
+assert ok and res[0] == root and tr.agreements == 2
+ok, res = tr._library(lambda: int(tr.comm.allreduce([41], capi.REDUCE_SUM)[0]))
+assert ok and res == 41 and tr.agreements == 3
+# a failing collective: every rank (here: the one) drops the communicator after the agreement, the torch transport takes over
+def boom():
+    raise capi.DapolError(19, "ncclAllReduce did not complete within 60000 ms")
+ok, res = tr._library(boom)
+assert not ok and tr.comm is None and "after the library's collective failed" in tr.path and tr.agreements == 4
+t = torch.tensor([7], dtype=torch.int64, device="cuda"); dist.all_reduce(t); assert int(t.item()) == 7    # torch's RCCL group still works
+dist.destroy_process_group()
+print("ONE-RANK-RCCL-OK")
+"""
+
+
+@pytest.mark.gpu
+def test_library_communicator_and_agreement_group_beside_torch_rccl(hip_lib):
+    """What `bench.py --gpus N` sets up on a multi-GPU node, with the one rank a 1-GPU box has: torch.distributed over RCCL as the
+    default group, the side gloo group the ranks agree over, the 128-byte id carried by a torch broadcast, the library's own
+    communicator created non-blocking, its collectives each followed by the agreement, and the agreed drop to torch's transport."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = subprocess.run([sys.executable, "-c", _ONE_RANK_RCCL % {"root": ROOT, "port": port}], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ONE-RANK-RCCL-OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
