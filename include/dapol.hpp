@@ -60,6 +60,8 @@ struct DapolNode {
 class Context {                                // PedersenGens::default() + BulletproofGens::new(64, m), once
   public:
     // digest = the node hash D of Dapol<D, R>: DAPOL_DIGEST_BLAKE3 or DAPOL_DIGEST_BLAKE2S
+    // max_parties = the largest aggregation a proof may need, rounded up to a power of two: 32 serves trees up to height 32
+    // (aggregation_factor <= tree_height), 64 the reference's whole range (MAX_TREE_HEIGHT = 64, src/dapol/mod.rs:26)
     explicit Context(int device = 0, int max_parties = 32, int digest = DAPOL_DIGEST_BLAKE3) { check(dapol_ctx_create(device, max_parties, digest, &h_)); }
     // ... with settings (dapol_options: zeros = the library's own choices; options.struct_size is filled in here)
     Context(int device, int max_parties, int digest, dapol_options options) {

@@ -4,7 +4,7 @@ export DAPOL_ENV_KNOBS=1     # the DAPOL_* knobs below are read only by a proces
 #   gpurun_out/<tag>_ubench_madd.txt      VALU-only cost of the point operations (the MSM's issue roof)
 #   gpurun_out/<tag>_bench.json           python bench.py (default workload, with the CPU baseline)
 #   gpurun_out/<tag>_stats/               rocprofv3 --kernel-trace --stats of the same command without the CPU leg
-#   gpurun_out/<tag>_pmc_*/               separate --pmc passes on 2^18 entities (full 73,728-proof launches)
+#   gpurun_out/<tag>_pmc_*/               separate --pmc passes on 2^18 entities (two full chunks of 131,072 proofs)
 set -o pipefail
 tag=${1:-r01}
 R=$(pwd)
@@ -18,9 +18,10 @@ cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${tag}_stats -o stats -- python3 $R/bench.py --no-cpu-baseline --no-secondary --steps 2 --warmup 1 > $OUT/${tag}_stats.log 2>&1 || { tail -5 $OUT/${tag}_stats.log; exit 1; }
 find $OUT/${tag}_stats -name "*kernel_trace.csv" -delete          # (tens of MB; the merged gpurun_out/ is capped at 64 MiB)
 echo "stats done"
-DAPOL_STREAMS=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${tag}_stats1 -o stats -- python3 $R/bench.py --no-cpu-baseline --no-secondary --log2-entities 18 --steps 1 --warmup 0 > $OUT/${tag}_stats1.log 2>&1 || { tail -5 $OUT/${tag}_stats1.log; exit 1; }
-find $OUT/${tag}_stats1 -name "*kernel_trace.csv" -delete
-echo "one-stream stats done"
+# (one chunk in flight is the default since round 4: the trace above IS the serial split of the step; two chunks in flight for comparison)
+DAPOL_STREAMS=2 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${tag}_stats2 -o stats -- python3 $R/bench.py --no-cpu-baseline --no-secondary --log2-entities 18 --steps 1 --warmup 0 > $OUT/${tag}_stats2.log 2>&1 || { tail -5 $OUT/${tag}_stats2.log; exit 1; }
+find $OUT/${tag}_stats2 -name "*kernel_trace.csv" -delete
+echo "two-stream stats done"
 # the dominant kernel: the generator-stationary sweep since round 3 (KERNEL="k_rp_msm<0" with DAPOL_GS=0 for the proof-stationary one)
 KERNEL=${KERNEL:-k_rp_msm_gs}
 PMC_LG=${PMC_LG:-18}

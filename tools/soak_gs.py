@@ -27,7 +27,8 @@ for case in range(cases):
     n_bits, m = [(64, 32), (64, 16), (32, 32), (32, 64), (16, 64), (64, 64)][int(rng.integers(0, 6))]
     b = int(rng.integers(1024, 40001)) if n_bits * m <= 2048 else int(rng.integers(1024, 14001))
     if rng.integers(0, 4) == 0:
-        os.environ["DAPOL_CHUNK"] = str(int(rng.integers(3000, 20000)))         # several (ragged) chunks on two streams
+        os.environ["DAPOL_CHUNK"] = str(int(rng.integers(3000, 20000)))         # several (ragged) chunks ...
+    os.environ["DAPOL_STREAMS"] = str(int(rng.integers(1, 3)))                  # ... one in flight (the default since round 4) or two
     vmax = (1 << n_bits) if n_bits < 64 else (1 << 63)
     v = rng.integers(0, vmax, size=(b, m), dtype=np.uint64)
     r = rng.integers(0, 256, size=(b, m, 32), dtype=np.uint8)
@@ -37,6 +38,7 @@ for case in range(cases):
         proofs = ctx.range_prove_batch(n_bits, m, v, r, nonce_seed=SEED, stream_id=sid)
     finally:
         os.environ.pop("DAPOL_CHUNK", None)
+        os.environ.pop("DAPOL_STREAMS", None)
     ps = ref.ref_range_proof_size(n_bits, m)
     assert proofs.shape == (b, ps)
     pick = rng.choice(b, size=6, replace=False)
