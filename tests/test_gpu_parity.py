@@ -1323,6 +1323,13 @@ def test_every_proving_strategy_gives_the_same_bytes(gpu_ctx, n_bits, m):
                 {"DAPOL_GS": "1", "DAPOL_NO_SPLIT": "1", "DAPOL_GS_TILE": "64", "DAPOL_CHUNK": "16", "DAPOL_STREAMS": "2"},
                 {"DAPOL_GS": "1", "DAPOL_NO_SPLIT": "1", "DAPOL_CHUNK": "16", "DAPOL_STREAMS": "2", "DAPOL_MSM_SERIAL": "1"},
                 {"DAPOL_GS": "1", "DAPOL_NO_SPLIT": "1", "DAPOL_NO_TAIL": "1"}, {"DAPOL_GS": "1", "DAPOL_NO_SPLIT": "1", "DAPOL_CHUNK": "5", "DAPOL_TAIL_N": "32"},
+                # round 4's stream layouts (two chunks in flight on CU-masked / prioritised streams) and grid-strided, capped digit producers
+                {"DAPOL_GS": "1", "DAPOL_NO_SPLIT": "1", "DAPOL_CHUNK": "16", "DAPOL_STREAMS": "2", "DAPOL_STREAM_LAYOUT": "split_xcd"},
+                {"DAPOL_GS": "1", "DAPOL_NO_SPLIT": "1", "DAPOL_CHUNK": "16", "DAPOL_STREAMS": "2", "DAPOL_STREAM_LAYOUT": "split_cu"},
+                {"DAPOL_GS": "1", "DAPOL_NO_SPLIT": "1", "DAPOL_CHUNK": "9", "DAPOL_STREAMS": "2", "DAPOL_STREAM_LAYOUT": "msm:32"},
+                {"DAPOL_GS": "1", "DAPOL_NO_SPLIT": "1", "DAPOL_CHUNK": "16", "DAPOL_STREAMS": "2", "DAPOL_STREAM_LAYOUT": "prio"},
+                {"DAPOL_GS": "1", "DAPOL_NO_SPLIT": "1", "DAPOL_CHUNK": "16", "DAPOL_STREAMS": "2", "DAPOL_STREAM_LAYOUT": "prio_lanes"},
+                {"DAPOL_GS": "1", "DAPOL_NO_SPLIT": "1", "DAPOL_PRODUCER_WAVES": "64"}, {"DAPOL_GS": "1", "DAPOL_NO_SPLIT": "1", "DAPOL_CHUNK": "16", "DAPOL_STREAMS": "2", "DAPOL_PRODUCER_WAVES": "100"},
                 {"DAPOL_QUAD_MAX_WAVES": "1000000"}, {"DAPOL_QUAD_MAX_WAVES": "1000000", "DAPOL_SMALL_TAIL": "1"}, {"DAPOL_QUAD_MAX_WAVES": "1000000", "DAPOL_SMALL_SPLIT": "8"}):
         os.environ.update(env)
         try:
