@@ -367,6 +367,12 @@ def mode_prove(args):
         if rank == 0:
             log("warm-up step %d: %.2f s" % (warm_done, t_step))
     extra_warm, steps = plan_steps(steps_req, warm_req - (warm_done - 1), t_step, deadline - time.time() - post_reserve)
+    if steps < steps_req and world == 1 and not args.no_secondary:
+        # short of time (a slow first `import torch`, a slow box): the requested steps come before the secondary legs, which are
+        # then run only as far as the budget still allows after the timed region
+        lean_reserve = 1.15 * ((args.cpu_budget_s + 4.0 if not args.no_cpu_baseline else 0.0) + 9.0)
+        _, steps = plan_steps(steps_req, 1, t_step, deadline - time.time() - lean_reserve)
+        extra_warm = 0
     extra_warm, steps = agree_min(extra_warm), agree_min(steps)
     for _ in range(extra_warm):
         prover.step(PAD_SEED, NONCE_SEED, n_bits)
@@ -497,7 +503,9 @@ def mode_prove(args):
         okv = ctx.verify_entities(height, vids, lC, lH, vC, vH, rC, rH, capi.POLICY_PADDING, height, n_bits, vproofs, verify_seed=os.urandom(32))
         parity = dict(parity or {}, inclusion_proofs_verified_on_gpu=int(okv.sum()), inclusion_proofs_checked=int(len(okv)))
     secondary = None
-    if world == 1 and not args.no_secondary and prover.w is not None:
+    if world == 1 and not args.no_secondary and prover.w is not None and (deadline + 15.0 - time.time()) < 20.0:
+        secondary = {"skipped": "wall budget: %.0f s left of %.0f" % (deadline + 15.0 - time.time(), args.budget_s)}
+    elif world == 1 and not args.no_secondary and prover.w is not None:
         log("secondary legs (splitting policy, API layout, host-buffer entry points)")
         try:
             secondary = secondary_legs(ctx, capi, prover, height, n_bits, idx, v, r, n_per_gpu, host_leg_deadline=deadline + 15.0, t_step_hint=ms_per_step / 1e3)
