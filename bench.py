@@ -559,18 +559,19 @@ def secondary_legs(ctx, capi, prover, height, n_bits, idx, v, r, n_per_gpu, host
     out["splitting"] = {"sample": "first 2^%d entities of the workload" % (ns.bit_length() - 1),
                         "agg32_entities_per_s": ns / dt, "agg32_bytes_equal_padding": same}
     n24 = min(n_per_gpu, 1 << 14)
+    a24 = min(24, max(1, height - 8))                           # (24 on the headline's height-32 tree)
     for pol, name in ((capi.POLICY_SPLITTING, "splitting"), (capi.POLICY_PADDING, "padding")):
-        w.prove(NONCE_SEED, n_bits, first=0, count=256, upper=prover.upper, policy=pol, aggregation_factor=24)      # warm the shapes
+        w.prove(NONCE_SEED, n_bits, first=0, count=min(256, n24), upper=prover.upper, policy=pol, aggregation_factor=a24)      # warm the shapes
         sync(); t0 = time.perf_counter()
-        st = w.prove(NONCE_SEED, n_bits, first=0, count=n24, upper=prover.upper, policy=pol, aggregation_factor=24)
+        st = w.prove(NONCE_SEED, n_bits, first=0, count=n24, upper=prover.upper, policy=pol, aggregation_factor=a24)
         sync(); dt = time.perf_counter() - t0
         out["splitting"]["agg24_%s_entities_per_s" % name] = n24 / dt
         out["splitting"]["agg24_%s_proof_bytes" % name] = int(st.proof_bytes // max(1, st.proofs))
-    out["splitting"]["agg24_sample"] = "first 2^%d entities, aggregation factor 24 on the height-32 tree" % (n24.bit_length() - 1)
+    out["splitting"]["agg24_sample"] = "first 2^%d entities, aggregation factor %d on the height-%d tree" % (n24.bit_length() - 1, a24, height)
     # leave the workload as the timed run left it (sampled proofs are read from it afterwards)
     w.prove(NONCE_SEED, n_bits, upper=prover.upper)
     # ---- API layout
-    n_ids = 1 << 20
+    n_ids = min(1 << 20, 1 << max(1, height - 1))               # (2^20 on the headline; never beyond Dapol::new's sparsity rule 2^height >= 2n)
     ids = np.char.add("id-", np.char.zfill(np.arange(n_ids).astype("U8"), 8)).astype("S11")
     packed = ids.tobytes()
     off = (np.arange(n_ids + 1, dtype=np.uint64) * 11).astype(np.uint32)
@@ -582,7 +583,7 @@ def secondary_legs(ctx, capi, prover, height, n_bits, idx, v, r, n_per_gpu, host
     sync(); t0 = time.perf_counter()
     root, sta = wa.build(PAD_SEED)
     sync(); t_build = time.perf_counter() - t0
-    na = 1 << 16
+    na = min(1 << 16, n_ids)
     sync(); t0 = time.perf_counter()
     sta = wa.prove(NONCE_SEED, n_bits, first=0, count=na, stats=sta)
     sync(); t_prove = time.perf_counter() - t0
@@ -592,11 +593,11 @@ def secondary_legs(ctx, capi, prover, height, n_bits, idx, v, r, n_per_gpu, host
     got = np.stack([wa.proofs(int(p), 1, ps)[0] for p in pos])
     lC, lH = ctx.commit_hash_batch(lf["v"][pos], lf["r"][pos])
     okv = ctx.verify_entities(height, sample, lC, lH, sC, sH, root[0], root[1], capi.POLICY_PADDING, height, n_bits, got)
-    out["api_layout"] = {"ids": "2^20 ids id-%08d, BLAKE3 index derivation, height 32", "build_leaf_nodes_s": t_leaf,
+    out["api_layout"] = {"ids": "2^%d ids id-%%08d, BLAKE3 index derivation, height %d" % (n_ids.bit_length() - 1, height), "build_leaf_nodes_s": t_leaf,
                          "build_leaf_nodes_entities_per_s": n_ids / t_leaf, "host_inclusive": True,
                          "indexes_distinct": bool(len(np.unique(lf["leaf_idx"])) == n_ids),
                          "root_value_equals_sum": bool(root[2] == int(vals.sum())), "tree_build_ms": t_build * 1e3,
-                         "prove_sample": "first 2^16 leaves in index order", "prove_entities_per_s": na / t_prove,
+                         "prove_sample": "first 2^%d leaves in index order" % (na.bit_length() - 1), "prove_entities_per_s": na / t_prove,
                          "sampled_proofs_verified": int(okv.sum()), "sampled_proofs_checked": int(len(okv))}
     wa.close()
     # ---- host buffers (PCIe-inclusive): the WHOLE workload once when the wall budget allows (~22 s at 2^20), else a 2^16 sample
