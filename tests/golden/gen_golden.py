@@ -109,6 +109,7 @@ def gen_range(full):
     specs = [(8, 1, 1), (8, 2, 2), (16, 4, 3), (32, 2, 4), (64, 1, 5), (64, 2, 6), (64, 4, 7), (8, 8, 8)]
     if full:
         specs.append((64, 32, 9))
+        specs.append((8, 64, 10))            # 64 parties (trees higher than 32): three groups of the statement-bound nonce key
     for n, m, sid in specs:
         values = [int.from_bytes(wide(12, sid, j)[:8], "little") & (2**n - 1) for j in range(m)]
         if m >= 2:

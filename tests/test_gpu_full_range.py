@@ -297,3 +297,24 @@ def test_liability_ids_of_any_length(gpu_ctx, hip_lib, pyref):
     with pytest.raises(hip_lib.DapolError) as e:
         gpu_ctx.build_leaf_nodes(liabs + [(liabs[9][0], b"x", 1)], seed, 40, hip_lib.DIGEST_BLAKE3)
     assert e.value.code == 4
+
+
+def test_golden_64_party_proof(ctx64):
+    """tests/golden/range.json's 64-party vector (made by the Python oracle: three groups of the statement-bound nonce key, a
+    (0, Scalar::one()) padding party, values 0 and 2^n - 1): the GPU's bytes, and its verifier's verdict on them."""
+    from conftest import load_golden
+    seen = 0
+    for c in load_golden("range.json"):
+        if c["m"] != 64:
+            continue
+        seen += 1
+        n, m = c["n"], c["m"]
+        bl = np.array([list(bytes.fromhex(h)) for h in c["blindings"]], np.uint8)
+        pr = ctx64.range_prove_batch(n, m, np.array(c["values"], np.uint64).reshape(1, m), bl.reshape(1, m, 32),
+                                     nonce_seed=bytes.fromhex(c["nonce_seed"]), stream_id=[c["stream_id"]])
+        assert pr[0].tobytes().hex() == c["proof"]
+        V = np.array([list(bytes.fromhex(h)) for h in c["commitments"]], np.uint8).reshape(1, m, 32)
+        assert ctx64.range_verify_batch(n, m, pr, V, verify_seed=SEED).all()
+        C, _ = ctx64.commit_hash_batch(np.array(c["values"], np.uint64), bl)
+        assert C.tobytes() == V.tobytes()
+    assert seen == 1

@@ -83,6 +83,8 @@ def test_trees_golden_every_node(gpu_ctx, hip_lib):
 def test_range_proofs_golden(gpu_ctx):
     for c in load_golden("range.json"):
         n, m = c["n"], c["m"]
+        if m > gpu_ctx.max_parties:
+            continue                                     # (the 64-party vector: tests/test_gpu_full_range.py, on a 64-party context)
         pr = gpu_ctx.range_prove_batch(n, m, np.array(c["values"], np.uint64).reshape(1, m), _arr(c["blindings"]).reshape(1, m, 32),
                                        nonce_seed=bytes.fromhex(c["nonce_seed"]), stream_id=[c["stream_id"]])
         assert pr[0].tobytes().hex() == c["proof"], (n, m)
@@ -685,6 +687,8 @@ def test_bench_layout_at_baseline_config_properties(gpu_ctx, hip_lib, ref):
 def test_verify_golden_and_tampered(gpu_ctx):
     for c in load_golden("range.json"):
         n, m = c["n"], c["m"]
+        if m > gpu_ctx.max_parties:
+            continue                                     # (the 64-party vector: tests/test_gpu_full_range.py)
         proof = np.frombuffer(bytes.fromhex(c["proof"]), np.uint8)
         Vs = _arr(c["commitments"]).reshape(1, m, 32)
         cases, expect = [proof], [1]
