@@ -418,18 +418,18 @@ def mode_prove(args):
     # generator-stationary -- k_rp_msm_gs, a few hundred tile launches per MSM -- smaller ones proof-stationary (k_rp_msm<0, .>).
     # The library brackets every MSM with HIP events on the stream it runs on (MsmTiming) and counts the kernel launches inside
     # the brackets; the materialisation of the folded generators (k_rp_mat_gs / k_rp_msm<1, .>) is bracketed separately.
-    # Two chunks are in flight on two streams: the library reports UNIONS of the bracket intervals (time during which a plain MSM /
-    # a materialisation / either was running), not sums of bracket lengths.
+    # The library reports UNIONS of the bracket intervals (time during which a plain MSM / a materialisation / either was running),
+    # which with several chunks in flight (DAPOL_STREAMS > 1) is less than the sum of the bracket lengths.
     plain_s, mat_s = acc["msm_ms"] / 1e3, acc["mat_ms"] / 1e3
     msm_s = acc["msm_all_ms"] / 1e3 if acc["msm_all_ms"] > 0 else plain_s + mat_s
     launches = int(acc["msm_kernels"]) or int(acc["msm_launches"])
     gs = int(acc["msm_kernels"]) > int(acc["msm_launches"])
     # Two clocks per launch.  `avg_launch_ms` is the SPAN of a launch -- bracket lengths summed / launches inside: what
-    # `rocprofv3 --kernel-trace --stats` of this command reports as the kernel's average, with the launches of the two chunks in
-    # flight overlapping in time (each then takes about twice as long as alone).  `avg_launch_ms_exclusive` divides the time during
-    # which such a launch was running at all (the union of the brackets) by the launches: an upper bound of the chip-wide cost of one
-    # launch (the other chunk's kernels also run inside those intervals; the serialised --pmc passes measure 0.47-0.49 ms).
-    # `achieved` uses the exclusive time.
+    # `rocprofv3 --kernel-trace --stats` of this command reports as the kernel's average.  `avg_launch_ms_exclusive` divides the time
+    # during which such a launch was running at all (the union of the brackets) by the launches.  With ONE chunk in flight (the
+    # default since round 4) brackets never overlap and the two are the same number; with DAPOL_STREAMS=2 the launches of the two
+    # chunks overlap pairwise, the span is about twice the exclusive time, and the exclusive time is an upper bound of the chip-wide
+    # cost of one launch (the other chunk's kernels also run inside those intervals).  `achieved` uses the exclusive time.
     avg_launch_span_ms = (acc["msm_span_ms"] if acc["msm_span_ms"] > 0 else acc["msm_ms"]) / max(1, launches)
     avg_launch_ms = acc["msm_ms"] / max(1, launches)
     # algorithmic bytes per launch (6,384 B of compulsory traffic per entity on the prove path, spread evenly over the
@@ -470,8 +470,8 @@ def mode_prove(args):
         "msm_share_of_step": msm_s / elapsed if elapsed > 0 else None,
         "note": "achieved = ALGORITHMIC bytes per launch of the dominant kernel (SURVEY 8d, prove path: 6,384 B per entity at H=32, spread over the "
                 "fixed-base MSM time; this kernel's share / its launches) / avg_launch_ms_exclusive (HIP events around every MSM on the stream "
-                "it runs on; union of those intervals / tile launches inside).  avg_launch_ms is the per-launch SPAN a kernel trace shows (two "
-                "chunks in flight: launches overlap pairwise).  By construction ~1e-5 of the HBM peak: the path does ~1e7 modular "
+                "it runs on; union of those intervals / tile launches inside).  avg_launch_ms is the per-launch SPAN a kernel trace shows: the "
+                "same number with one chunk in flight (the default), larger with DAPOL_STREAMS=2, whose launches overlap pairwise.  By construction ~1e-5 of the HBM peak: the path does ~1e7 modular "
                 "multiplications per 9 KB of compulsory traffic; what binds is integer-VALU issue (`valu`, from the PMC pass of this "
                 "build).  `traffic` = L2<->fabric bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE; Infinity-Cache hits are counted by "
                 "that counter: for the generator-stationary kernel most of them ARE Infinity-Cache hits, DESIGN.md section 5); it and "
