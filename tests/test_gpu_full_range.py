@@ -318,3 +318,63 @@ def test_golden_64_party_proof(ctx64):
         C, _ = ctx64.commit_hash_batch(np.array(c["values"], np.uint64), bl)
         assert C.tobytes() == V.tobytes()
     assert seen == 1
+
+
+@pytest.mark.parametrize("height,shard_bits", [(40, 3), (64, 2)])
+def test_sharded_trees_above_height_32(ctx64, hip_lib, height, shard_bits):
+    """The multi-GPU split (one top-level subtree per rank) on trees higher than 32: every shard's root record merges up
+    to the unsharded root, and a shard's entities proved with the upper siblings prepended give the unsharded tree's bytes -- 64-party
+    proofs, the shard with index prefix 1..1 holding the leaves above 2^63 at height 64."""
+    from dapol_amd import sharded
+    g = 1 << shard_bits
+    rng = np.random.default_rng(height + shard_bits)
+    low = height - shard_bits
+    parts = []
+    for s in range(g):
+        inner = rng.integers(0, 1 << min(low, 62), size=3, dtype=np.uint64)
+        parts.append(np.unique(inner) | (np.uint64(s) << np.uint64(low)))
+    idx = np.sort(np.concatenate(parts))
+    v = rng.integers(0, 2**36, size=len(idx), dtype=np.uint64)
+    r = rng.integers(0, 256, size=(len(idx), 32), dtype=np.uint8)
+    r[:, 31] &= 0x0F
+    full = hip_lib.Tree(ctx64, height, idx, v, r, SEED)
+    fC, fH, fout = full.prove_entities(idx, hip_lib.POLICY_PADDING, height, 64, SEED)
+    shards, recs = [], []
+    for s in range(g):
+        sel = (idx >> np.uint64(low)) == s
+        t = hip_lib.Tree(ctx64, height, idx[sel], v[sel], r[sel], SEED, shard_bits=shard_bits)
+        shards.append((sel, t))
+        recs.append(sharded.pack_record(t.root()))
+    records = sharded.unpack_records(np.stack(recs), g)
+    for s, (sel, t) in enumerate(shards):
+        root, upper = hip_lib.shard_top_levels(ctx64, np.stack(recs), s)
+        assert root == full.root() == sharded.top_levels(ctx64, records, s)[0]
+        pC, pH, out = t.prove_entities(idx[sel], hip_lib.POLICY_PADDING, height, 64, SEED, upper=upper)
+        assert out.tobytes() == fout[sel].tobytes() and pC.tobytes() == fC[sel].tobytes() and pH.tobytes() == fH[sel].tobytes()
+    lC, lH = ctx64.commit_hash_batch(v, r)
+    rC, rH, _, _ = full.root()
+    assert ctx64.verify_entities(height, idx, lC, lH, fC, fH, rC, rH, 0, height, 64, fout, verify_seed=SEED).all()
+
+
+def test_blake2s_context_at_height_64(hip_lib, ref, pyref):
+    """D = Blake2s (the reference's test digest, src/dapol/tests.rs:21) on a height-64 tree with 16-bit proofs of 64 parties:
+    every sibling hash of sampled paths and the root against the Python oracle with dg = blake2s; proofs verify, and do not under a
+    BLAKE3 context."""
+    ctx = hip_lib.Context(0, 64, digest=hip_lib.DIGEST_BLAKE2S)
+    rng = np.random.default_rng(2664)
+    idx, v, r = _leaves(rng, 64, 5, vmax=200, top_bit=True)
+    tr = hip_lib.Tree(ctx, 64, idx, v, r, SEED)
+    leaves = [(int(i), pyref.node_new(int(vv), int.from_bytes(rr.tobytes(), "little"), "blake2s")) for i, vv, rr in zip(idx, v, r)]
+    pt = pyref.Tree(64, leaves, SEED, "blake2s")
+    C, H, rv, rr_ = tr.root()
+    assert (C, H, rv) == (pt.root.C, pt.root.H, int(v.sum()))
+    pC, pH, proofs = tr.prove_entities(idx, 0, 64, 16, SEED)
+    for k in (0, len(idx) - 1):
+        sibs = pt.path_siblings(int(idx[k]))
+        assert [pH[k, s].tobytes() for s in range(64)] == [x.H for x in sibs] and [pC[k, s].tobytes() for s in range(64)] == [x.C for x in sibs]
+    lC, lH = ctx.commit_hash_batch(v, r)
+    assert ctx.verify_entities(64, idx, lC, lH, pC, pH, C, H, 0, 64, 16, proofs, verify_seed=SEED).all()
+    ctx3 = hip_lib.Context(0, 64)
+    assert not ctx3.verify_entities(64, idx, lC, lH, pC, pH, C, H, 0, 64, 16, proofs, verify_seed=SEED).any()
+    ctx3.close()
+    ctx.close()
