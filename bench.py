@@ -6,6 +6,8 @@ generation (one padding-policy inclusion proof per entity, aggregation_factor = 
       N > 1: one rank per GPU.  Under a launcher (torch.distributed.run sets WORLD_SIZE) this process IS a rank; without one
       the process -- which has not touched the GPU -- starts `python -m torch.distributed.run --nproc-per-node N ... bench.py`
       as a child, relays rank 0's JSON line and exits with the child's code.
+  python bench.py --gpus N --preflight   < 30 s, no proving: RCCL communicator inside the library up (ncclCommCount == N), the two
+                                    collectives of a step timed over 100 rounds, every rank's global root equal, link topology to stderr
   python bench.py --mode build      the reference's `build` criterion group (benches/dapol.rs:24-57) on the GPU, and the
                                     incremental dapol_tree_update on the headline tree
   python bench.py --mode verify [--gpus N]   BASELINE configs[4]: verification-only, aggregated proofs of 1,024 parties
@@ -292,6 +294,62 @@ def from_profiles(sha, full_size):
     return out
 
 
+def gather_phase_rows(dist, torch, phase_rows, world, device):
+    """Every rank's [step][key] matrix of phase times -> [rank][step][key] on every rank (one all-gather, outside the timed region)."""
+    if dist is None or world == 1:
+        return np.asarray(phase_rows, np.float64)[None]
+    mine = torch.tensor(phase_rows, dtype=torch.float64, device=device)
+    allp = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(allp, mine)
+    return torch.stack(allp).cpu().numpy()
+
+
+def rank_decomposition(per_rank, keys, world, exchange_path):
+    """per_rank[rank][step][key] (ShardedProver.PHASE_KEYS + the device times of the two phases) -> the `multi_gpu` object of the
+    line: per rank the mean over the timed steps of every phase; over the ranks min / max / imbalance of the build, the proving and
+    the whole step; and the two collectives -- host milliseconds of the calls (they include waiting for the slowest rank to arrive:
+    a rank that finishes its build early waits in the all-gather) and, when the library's communicator carried them, the device
+    microseconds from HIP events around ncclAllGather / the top-level merge / ncclAllReduce.  The all-gather's own latency is its
+    MINIMUM over the ranks (the last rank to arrive waits for nobody); max - min is the arrival skew."""
+    a = np.asarray(per_rank, np.float64)                     # [R][S][K]
+    mean = np.nanmean(a, axis=1) if a.shape[1] else np.zeros((a.shape[0], len(keys)))
+    col = {k: mean[:, i] for i, k in enumerate(keys)}
+
+    def spread(x):
+        x = np.asarray(x, np.float64)
+        if np.all(np.isnan(x)):
+            return None
+        lo, hi = float(np.nanmin(x)), float(np.nanmax(x))
+        return {"min": lo, "max": hi, "mean": float(np.nanmean(x)), "imbalance": (hi / lo - 1.0) if lo > 0 else None}
+
+    def per_step_stats(key):
+        i = keys.index(key)
+        x = a[:, :, i]
+        if np.all(np.isnan(x)):
+            return None
+        return {"min_over_ranks_mean_over_steps": float(np.nanmean(np.nanmin(x, axis=0))),
+                "max_over_ranks_mean_over_steps": float(np.nanmean(np.nanmax(x, axis=0))),
+                "max_over_ranks_and_steps": float(np.nanmax(x))}
+
+    out = {"ranks": int(a.shape[0]), "steps": int(a.shape[1]),
+           "per_rank_ms": {"build": [float(x) for x in col["build_ms"]], "exchange": [float(x) for x in col["exchange_ms"]],
+                           "prove": [float(x) for x in col["prove_ms"]], "reduce": [float(x) for x in col["reduce_ms"]],
+                           "step": [float(x) for x in col["step_ms"]],
+                           "tree_device": [float(x) for x in col["tree_device_ms"]], "prove_device": [float(x) for x in col["prove_device_ms"]]},
+           "build_ms": spread(col["build_ms"]), "prove_ms": spread(col["prove_ms"]), "step_ms": spread(col["step_ms"]),
+           "exchange": {"path": exchange_path, "host_ms": per_step_stats("exchange_ms"), "allgather_device_us": per_step_stats("allgather_us"),
+                        "top_levels_device_us": per_step_stats("top_levels_us"),
+                        "note": "host_ms = dapol_shard_exchange (or the torch all_gather + top-level merge) on the rank's host clock, incl. the wait "
+                                "for the slowest rank's build; *_device_us = HIP events inside the library around ncclAllGather (min over ranks = "
+                                "its own latency, max - min = arrival skew) and around the replicated merge of the top log2 N levels"},
+           "reduce": {"host_ms": per_step_stats("reduce_ms"), "allreduce_device_us": per_step_stats("allreduce_us"),
+                      "note": "the final all-reduce of the proof-transcript checksum (dapol_comm_allreduce_u64); host_ms includes the wait for the "
+                              "slowest rank's proving"}}
+    if world == 1:
+        out["note"] = "single GPU: no exchange, no reduce; the phases are this rank's"
+    return out
+
+
 def init_dist(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -384,12 +442,14 @@ def mode_prove(args):
     acc = {"tree_ms": 0.0, "prove_ms": 0.0, "msm_ms": 0.0, "msm_launches": 0, "proofs": 0, "mat_ms": 0.0, "mat_launches": 0, "msm_kernels": 0,
            "mat_kernels": 0, "msm_all_ms": 0.0, "msm_span_ms": 0.0}
     stats = None
+    phase_rows = []                                # per timed step, this rank: ShardedProver.PHASE_KEYS (host ms / device us)
     sync()
     t0 = time.perf_counter()
     for s in range(steps):
         stats = prover.step(PAD_SEED, NONCE_SEED, n_bits)
         for k in acc:
             acc[k] += getattr(stats, k)
+        phase_rows.append([prover.phases[k] for k in prover.PHASE_KEYS] + [stats.tree_ms, stats.prove_ms])
         if rank == 0:
             log("step %d/%d done (%.1f s since the timed region began; tree %.1f ms, proofs %.0f ms)" %
                 (s + 1, steps, time.perf_counter() - t0, stats.tree_ms, stats.prove_ms))
@@ -399,6 +459,8 @@ def mode_prove(args):
         tt = torch.tensor([elapsed], dtype=torch.float64, device=comm_device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    # every rank's per-step phase times -> rank 0 (after the timed region): what an N > 1 line needs to explain itself
+    per_rank = gather_phase_rows(dist, torch, phase_rows, world, comm_device)
     # The library's communicator has done its work: every rank finalises it HERE, together (they have just left the same
     # all-reduce), not one by one at interpreter exit while the others may already be gone.
     exchange_path, comm_ranks, comm_error = prover.exchange_path, prover.comm_ranks, prover.comm_error
@@ -477,6 +539,35 @@ def mode_prove(args):
                 "that counter: for the generator-stationary kernel most of them ARE Infinity-Cache hits, DESIGN.md section 5); it and "
                 "`valu` are only set from a PMC pass of the build that is running; older profiles are under from_profiles with their hash.",
         "kernel_src_sha": sha, "from_profiles": prof}
+    multi_gpu = rank_decomposition(per_rank, list(prover.PHASE_KEYS) + ["tree_device_ms", "prove_device_ms"], world, exchange_path)
+
+    def make_line(cpu, parity, secondary, complete):
+        return {
+            "metric": METRIC,
+            "value": value, "unit": "entities/s", "n_gpus": world, "steps": steps, "warmup": warm_done,
+            "steps_requested": steps_req, "warmup_requested": warm_req,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "dtype": "int32 limbs (255-bit modular integers)", "data": "synthetic",
+            "config": {"workload": "2^%d entities%s, height=%d, %d-bit range proofs, padding policy, aggregation_factor=height, BLAKE3 node hash"
+                                   % (lg_total if scaling == "strong" or world == 1 else args.log2_entities,
+                                      " in total (strong scaling: 2^%d per GPU)" % (lg_total - (world.bit_length() - 1)) if scaling == "strong" and world > 1
+                                      else (" per GPU (weak scaling)" if world > 1 else ""), height, n_bits),
+                       "entities_total": n_total, "entities_per_gpu": n_per_gpu, "proof_bytes": int(stats.proof_bytes // max(1, stats.proofs)),
+                       "sharding": "none" if world == 1 else "top-level subtrees, all-gather of %d subtree roots" % world,
+                       "exchange": exchange_path, "rccl_ranks_in_library_communicator": comm_ranks,
+                       "exchange_fallback_reason": comm_error},
+            "phases_ms": {"tree_build": acc["tree_ms"] / steps, "prove": acc["prove_ms"] / steps},
+            "multi_gpu": multi_gpu,
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "secondary": secondary,
+            "checksum": "%016x" % stats.checksum,
+            "complete": complete,
+            "wall_s_since_process_start": time.time() - T_PROC0,
+        }
+
+    # The headline goes out NOW, as soon as the timed region has ended: the legs below (CPU baseline, parity, secondary: ~60 s) come
+    # after it, and a run killed at the driver's limit must not lose the line.  The same line is printed again at the end with
+    # `cpu_baseline`, `parity` and `secondary` filled in ("complete": true); whoever reads the output takes the LAST line.
+    print(json.dumps(make_line(None, None, None, False)), flush=True)
     cpu = None
     parity = None
     if not args.no_cpu_baseline and os.path.exists(ORACLE_LIB) and prover.w is not None:
@@ -511,26 +602,7 @@ def mode_prove(args):
             secondary = secondary_legs(ctx, capi, prover, height, n_bits, idx, v, r, n_per_gpu, host_leg_deadline=deadline + 15.0, t_step_hint=ms_per_step / 1e3)
         except Exception as e:                                   # the headline line must not die with a secondary leg
             secondary = {"error": repr(e)}
-    line = {
-        "metric": METRIC,
-        "value": value, "unit": "entities/s", "n_gpus": world, "steps": steps, "warmup": warm_done,
-        "steps_requested": steps_req, "warmup_requested": warm_req,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-        "dtype": "int32 limbs (255-bit modular integers)", "data": "synthetic",
-        "config": {"workload": "2^%d entities%s, height=%d, %d-bit range proofs, padding policy, aggregation_factor=height, BLAKE3 node hash"
-                               % (lg_total if scaling == "strong" or world == 1 else args.log2_entities,
-                                  " in total (strong scaling: 2^%d per GPU)" % (lg_total - (world.bit_length() - 1)) if scaling == "strong" and world > 1
-                                  else (" per GPU (weak scaling)" if world > 1 else ""), height, n_bits),
-                   "entities_total": n_total, "entities_per_gpu": n_per_gpu, "proof_bytes": int(stats.proof_bytes // max(1, stats.proofs)),
-                   "sharding": "none" if world == 1 else "top-level subtrees, all-gather of %d subtree roots" % world,
-                   "exchange": exchange_path, "rccl_ranks_in_library_communicator": comm_ranks,
-                   "exchange_fallback_reason": comm_error},
-        "phases_ms": {"tree_build": acc["tree_ms"] / steps, "prove": acc["prove_ms"] / steps},
-        "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "secondary": secondary,
-        "checksum": "%016x" % stats.checksum,
-        "wall_s_since_process_start": time.time() - T_PROC0,
-    }
-    print(json.dumps(line), flush=True)
+    print(json.dumps(make_line(cpu, parity, secondary, True)), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -632,6 +704,148 @@ def secondary_legs(ctx, capi, prover, height, n_bits, idx, v, r, n_per_gpu, host
     return out
 
 
+def preflight_collectives(tr, root, rank, world, dist, torch, comm_device, iters, ctx, lib_comm, merge=None, local_ok=True):
+    """The collective half of --preflight over a ShardTransport `tr` that is already set up: `iters` rounds of the step's exchange
+    (all-gather of the subtree roots + replicated top levels) and of its final reduce, through the transport exactly as the timed
+    loop drives it (library communicator + agreement after every collective, or torch.distributed); the same exchange over
+    torch.distributed for comparison; every rank's global root equal; the reduce's sum right.  -> (checks, timings, global root,
+    ok on EVERY rank).  `merge` overrides the merge primitive of the torch path (CPU tests plug the oracle in)."""
+    from dapol_amd import capi
+    from dapol_amd.sharded import exchange_records, top_levels, pack_record, unpack_records
+    checks, res = {}, {}
+
+    def timed(fn, n):
+        ts = []
+        out = None
+        for _ in range(n):
+            t0 = time.perf_counter()
+            out = fn()
+            ts.append(1e6 * (time.perf_counter() - t0))
+        ts.sort()
+        return out, {"iters": n, "median_us": ts[len(ts) // 2], "min_us": ts[0], "p90_us": ts[int(0.9 * (len(ts) - 1))], "max_us": ts[-1]}
+
+    if world > 1:
+        do_exchange, do_reduce = (lambda: tr.exchange(root)), (lambda: tr.reduce_u64(rank + 1, "sum"))
+    else:      # ONE rank: the transport short-cuts (nothing to exchange); call the library's collectives + agreement as N ranks would
+        do_exchange = lambda: (tr._library(lambda: tr.comm.exchange(root))[1] if tr.comm is not None else (root, None))
+        do_reduce = lambda: (tr._library(lambda: int(tr.comm.allreduce([rank + 1], capi.REDUCE_SUM)[0]))[1] if tr.comm is not None else rank + 1)
+    dist.barrier()
+    (groot, upper), res["exchange_host"] = timed(do_exchange, iters)
+    red, res["reduce_host"] = timed(do_reduce, iters)
+    checks["reduce_sum_correct"] = red == world * (world + 1) // 2
+    checks["transport_still_on_the_library_communicator"] = (tr.comm is not None) == lib_comm
+    checks["upper_siblings_one_per_shard_bit"] = (upper is None and world == 1) or (upper is not None and len(upper[0]) == world.bit_length() - 1)
+    if tr.comm is not None:
+        tm = tr.comm.timing()
+        res["library_device_us"] = {"allgather_mean": tm.sum_allgather_us / max(1, tm.exchanges), "top_levels_mean": tm.sum_top_levels_us / max(1, tm.exchanges),
+                                    "allreduce_mean": tm.sum_allreduce_us / max(1, tm.reduces), "exchanges": int(tm.exchanges), "reduces": int(tm.reduces)}
+        res["library_host_us"] = {"exchange_mean": tm.sum_exchange_host_us / max(1, tm.exchanges), "reduce_mean": tm.sum_reduce_host_us / max(1, tm.reduces)}
+    if world > 1:          # the same exchange over torch.distributed (the fallback transport): comparison + cross-check of the root
+        def torch_exchange():
+            buf = exchange_records(dist, torch, pack_record(root), world, comm_device)
+            return top_levels(ctx, unpack_records(buf, world), rank, merge=merge)
+        (troot, _), res["exchange_host_torch"] = timed(torch_exchange, max(1, iters // 5))
+        checks["library_root_equals_torch_path_root"] = troot == groot
+    dig = np.frombuffer(hashlib.sha256(groot[0] + groot[1] + int(groot[2]).to_bytes(8, "little") + groot[3]).digest()[:8], np.int64).copy()
+    mine = torch.from_numpy(dig).to(comm_device)
+    allr = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    checks["global_root_equal_on_every_rank"] = all(int(a.item()) == int(mine.item()) for a in allr)
+    flag = torch.tensor([1 if (local_ok and all(bool(c) for c in checks.values())) else 0], dtype=torch.int64, device=comm_device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return checks, res, groot, int(flag.item()) == 1
+
+
+def mode_preflight(args):
+    """`bench.py --gpus N --preflight`: < 30 s, no proving.  What a multi-GPU run needs before it is worth 10 minutes of a node, and
+    what a FAILED one needs to leave behind: the link topology (`rocm-smi --showtopo`, to stderr, before this process touches the GPU),
+    torch.distributed up, the library's own RCCL communicator up (non-blocking creation with a deadline) with ncclCommCount == N, a
+    small shard tree per rank, then --preflight-iters rounds of the step's two collectives through the SAME transport object the
+    timed loop uses (dapol_shard_exchange = ncclAllGather + replicated top levels, dapol_comm_allreduce_u64 = ncclAllReduce, each
+    followed by the ranks' agreement), timed on the host and by the library's HIP events; the same over torch.distributed for
+    comparison; every rank's global root equal; the reduce giving N (N + 1) / 2.  One JSON line ("metric": "preflight ..."),
+    exit code 0 iff every check passed.  Works with ONE rank too (a 1-GPU box exercises every call site)."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    checks, notes = {}, {}
+    if rank == 0:
+        try:      # before anything here initialises the GPU; a child process, never an exec
+            topo = subprocess.run(["rocm-smi", "--showtopo"], capture_output=True, text=True, timeout=25)
+            print(topo.stdout[-6000:], file=sys.stderr, flush=True)
+            notes["rocm_smi_showtopo_rc"] = topo.returncode          # diagnostics, not a check: the links are what they are
+        except Exception as e:
+            notes["rocm_smi_showtopo"] = repr(e)
+    import torch
+    import torch.distributed as dist
+    backend = os.environ.get("DAPOL_BENCH_BACKEND", "nccl")
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    if "MASTER_PORT" not in os.environ:            # one rank without a launcher
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(so.getsockname()[1])
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    local_rank = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local_rank)
+    t0 = time.perf_counter()
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    comm_device = "cuda" if backend == "nccl" else "cpu"
+    x = torch.ones(1, dtype=torch.int64, device=comm_device)
+    dist.all_reduce(x)
+    checks["torch_distributed_up"] = int(x.item()) == world
+    t_torch = time.perf_counter() - t0
+    log("rank %d/%d: torch.distributed (%s) up in %.1f s" % (rank, world, backend, t_torch))
+    from __graft_entry__ import build
+    if rank == 0:
+        build()
+    dist.barrier()
+    from dapol_amd import capi
+    from dapol_amd.sharded import ShardTransport, exchange_records, top_levels, pack_record, unpack_records
+    t0 = time.perf_counter()
+    # tree nodes only need the rows of B and B_blinding: the narrowest windows, one party -- a context in a fraction of a second
+    ctx = capi.Context(local_rank, 1, options=capi.Options(window_bits=8, high_half_rows=-1))
+    t_ctx = time.perf_counter() - t0
+    tr = ShardTransport(ctx, rank, world, dist, torch, comm_device)
+    t0 = time.perf_counter()
+    tr.create_comm(timeout_s=args.preflight_timeout_s, even_alone=True)
+    t_comm = time.perf_counter() - t0
+    lib_comm = tr.comm is not None
+    if comm_device == "cuda":
+        checks["library_communicator_up"] = lib_comm
+        checks["nccl_comm_count_equals_n"] = bool(lib_comm and tr.comm_ranks == world)
+    else:
+        notes["library_communicator"] = "not created: the ranks share torch.distributed over %s (a test hook; RCCL needs one GPU per rank)" % backend
+    log("rank %d: library communicator %s in %.1f s (%s)" % (rank, "up" if lib_comm else "NOT up", t_comm, tr.comm_error or "ncclCommCount %s" % tr.comm_ranks))
+    height, n = 32, 1 << 10
+    bits = world.bit_length() - 1
+    idx, v, r = synth_inputs(n * world, height, rank * n, n)
+    tree = capi.Tree(ctx, height, idx, v, r, PAD_SEED, shard_bits=bits)
+    root = tree.root()
+
+    pc_checks, res, groot, ok = preflight_collectives(tr, root, rank, world, dist, torch, comm_device, max(1, args.preflight_iters), ctx, lib_comm, local_ok=all(bool(c) for c in checks.values()))
+    checks.update(pc_checks)
+    path, comm_ranks, comm_err = tr.path, tr.comm_ranks, tr.comm_error
+    tree.close()
+    tr.close()
+    if rank == 0:
+        print(json.dumps({"metric": "preflight of the multi-GPU path (no proving)", "ok": ok, "n_gpus": world, "backend": backend,
+                          "checks": checks, "notes": notes, "exchange_path": path, "rccl_ranks_in_library_communicator": comm_ranks,
+                          "comm_error": comm_err, "timings": res,
+                          "setup_s": {"torch_distributed": t_torch, "context": t_ctx, "library_communicator": t_comm},
+                          "shard_tree": "2^10 leaves per rank, height %d, %d shard bit(s)" % (height, bits),
+                          "global_root_C": groot[0].hex(), "wall_s_since_process_start": time.time() - T_PROC0}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    if not ok:
+        sys.exit(1)
+
+
 def spawn_ranks(args):
     """`--gpus N` without a launcher: this process has not touched the GPU (no torch import, no HIP call), so it may start the
     ranks itself -- N fresh children under torch.distributed.run, never an exec -- relay rank 0's JSON line, and leave with
@@ -647,17 +861,16 @@ def spawn_ranks(args):
     env["DAPOL_BENCH_T0"] = repr(T_PROC0)                     # the ranks count the wall budget from THIS process's start
     log("no launcher (WORLD_SIZE unset): starting %d ranks: %s" % (args.gpus, " ".join(cmd[1:8]) + " ..."))
     p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
-    last_json = None
+    got_json = False
     for ln in p.stdout:
         ln = ln.rstrip("\n")
         if ln.startswith("{") and '"metric"' in ln:
-            last_json = ln
-        else:
+            got_json = True
+            print(ln, flush=True)                   # at once: rank 0 prints the headline right after the timed region and the complete
+        else:                                       # line at the end; a run cut short in between must not lose the first
             print(ln, file=sys.stderr, flush=True)
     rc = p.wait()
-    if last_json is not None:
-        print(last_json, flush=True)
-    elif rc == 0:
+    if not got_json and rc == 0:
         rc = 1
     sys.exit(rc)
 
@@ -1030,6 +1243,10 @@ def main():
     ap.add_argument("--verify-proofs", type=int, default=1024)
     ap.add_argument("--verify-parties", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--preflight", action="store_true",
+                    help="< 30 s, no proving: the library's RCCL communicator up with ncclCommCount == N, the step's two collectives timed, every rank's root equal, rocm-smi --showtopo to stderr")
+    ap.add_argument("--preflight-iters", type=int, default=100)
+    ap.add_argument("--preflight-timeout-s", type=float, default=30.0, help="deadline of the communicator's creation and of each of its collectives")
     args = ap.parse_args()
     if args.steps < 1 or args.warmup < 0:
         raise SystemExit("--steps must be >= 1 and --warmup >= 0")
@@ -1037,6 +1254,8 @@ def main():
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and args.mode in ("prove", "verify"):
         return spawn_ranks(args)                  # (never returns)
+    if args.preflight:
+        return mode_preflight(args)
     if args.mode == "build":
         return mode_build(args)
     if args.mode == "verify":

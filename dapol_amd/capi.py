@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DAPOL_HIP_LIB", os.path.join(_HERE, "libdapol_hip.so"))   # override only for A/B builds
 
 POLICY_PADDING, POLICY_SPLITTING = 0, 1
-DIGEST_BLAKE3, DIGEST_BLAKE2S = 0, 1
+DIGEST_BLAKE3, DIGEST_BLAKE2S, DIGEST_BLAKE2B = 0, 1, 2      # Blake2b: 64-byte node hashes (every H array is then (.., 64))
 
 
 class DapolError(RuntimeError):
@@ -25,6 +25,13 @@ class WorkloadStats(ctypes.Structure):
                 ("checksum", ctypes.c_uint64), ("root_C", ctypes.c_uint8 * 32), ("root_H", ctypes.c_uint8 * 32),
                 ("mat_ms", ctypes.c_double), ("mat_launches", ctypes.c_uint64), ("msm_kernels", ctypes.c_uint64), ("mat_kernels", ctypes.c_uint64),
                 ("msm_all_ms", ctypes.c_double), ("msm_span_ms", ctypes.c_double)]
+
+
+class CommTiming(ctypes.Structure):
+    """dapol_comm_timing (include/dapol_hip.h): microseconds, measured inside dapol_shard_exchange / dapol_comm_allreduce_u64."""
+    _fields_ = [("exchanges", ctypes.c_uint64), ("reduces", ctypes.c_uint64)] + [(k, ctypes.c_double) for k in (
+        "last_allgather_us", "last_top_levels_us", "last_exchange_host_us", "last_allreduce_us", "last_reduce_host_us",
+        "sum_allgather_us", "sum_top_levels_us", "sum_exchange_host_us", "sum_allreduce_us", "sum_reduce_host_us")]
 
 
 class Options(ctypes.Structure):
@@ -53,6 +60,11 @@ _SIG = {
     "dapol_ctx_set_options": (ctypes.c_int32, [_P, ctypes.POINTER(Options)]),
     "dapol_env_knobs": (ctypes.c_int32, [ctypes.c_int32]),
     "dapol_ctx_destroy": (ctypes.c_int32, [_P]),
+    "dapol_ctx_digest_bytes": (ctypes.c_int32, [_P, _P]),
+    "dapol_proof_nodes_serialize_d": (ctypes.c_int32, [ctypes.c_int32, ctypes.c_size_t, _P, _P, _P]),
+    "dapol_proof_wire_size_d": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
+    "dapol_proof_serialize_d": (ctypes.c_int32, [ctypes.c_int32, ctypes.c_int32, ctypes.c_size_t, _P, ctypes.c_size_t, _P, _P, ctypes.c_int32, ctypes.c_int32,
+                                                 ctypes.c_int32, _P, _P]),
     "dapol_ctx_generator": (ctypes.c_int32, [_P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P]),
     "dapol_strerror": (ctypes.c_char_p, [ctypes.c_int32]),
     "dapol_last_error": (ctypes.c_char_p, []),
@@ -117,6 +129,7 @@ _SIG = {
     "dapol_shard_exchange": (ctypes.c_int32, [_P, _P, _P, ctypes.c_uint64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dapol_shard_top_levels": (ctypes.c_int32, [_P, ctypes.c_int32, ctypes.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dapol_comm_allreduce_u64": (ctypes.c_int32, [_P, ctypes.c_int32, _P, ctypes.c_size_t]),
+    "dapol_comm_timing_get": (ctypes.c_int32, [_P, _P, ctypes.c_int32]),
     "dapol_wire_config_get": (ctypes.c_int32, [_P]),
     "dapol_wire_config_set": (ctypes.c_int32, [_P]),
     "dapol_proof_nodes_serialize": (ctypes.c_int32, [ctypes.c_size_t, _P, _P, _P]),
@@ -217,18 +230,19 @@ def wire_config_restore(cfg):
     _chk(lib().dapol_wire_config_set(ctypes.byref(cfg)))
 
 
-def proof_serialize(height, leaf_idx, sib_C, sib_H, policy, aggregation_factor, n_bits, range_blob):
-    """DapolProof::serialize (range_proof || merkle_path) for a proof over the given leaves and siblings (host-only)."""
+def proof_serialize(height, leaf_idx, sib_C, sib_H, policy, aggregation_factor, n_bits, range_blob, hash_bytes=32):
+    """DapolProof::serialize (range_proof || merkle_path) for a proof over the given leaves and siblings (host-only).
+    hash_bytes = D::output_size() of the tree's digest (64 for a Blake2b context)."""
     leaf_idx = _u64(leaf_idx)
-    sC, sH = _u8(sib_C).reshape(-1, 32), _u8(sib_H).reshape(-1, 32)
+    sC, sH = _u8(sib_C).reshape(-1, 32), _u8(sib_H).reshape(-1, hash_bytes)
     S = sC.shape[0]
-    n = lib().dapol_proof_wire_size(height, leaf_idx.shape[0], S, policy, aggregation_factor, n_bits)
+    n = lib().dapol_proof_wire_size_d(hash_bytes, height, leaf_idx.shape[0], S, policy, aggregation_factor, n_bits)
     if n == 0:
         raise DapolError(8, "bad policy / aggregation_factor / n_bits")
     blob = _u8(np.frombuffer(bytes(range_blob), np.uint8))
     out = np.zeros(n, np.uint8)
-    _chk(lib().dapol_proof_serialize(height, leaf_idx.shape[0], _ptr(leaf_idx), S, _ptr(sC) if S else None, _ptr(sH) if S else None, policy,
-                                     aggregation_factor, n_bits, _ptr(blob), _ptr(out)))
+    _chk(lib().dapol_proof_serialize_d(hash_bytes, height, leaf_idx.shape[0], _ptr(leaf_idx), S, _ptr(sC) if S else None, _ptr(sH) if S else None, policy,
+                                       aggregation_factor, n_bits, _ptr(blob), _ptr(out)))
     return out.tobytes()
 
 
@@ -244,7 +258,7 @@ class Context:
         args = (self.h, policy, n_bits, _ptr(w), len(wire), ctypes.byref(h), ctypes.byref(k), ctypes.byref(S), ctypes.byref(agg), ctypes.byref(bl))
         _chk(lib().dapol_proof_deserialize(*args, None, None, None, None, ctypes.byref(cons)))
         leaf = np.zeros(max(k.value, 1), np.uint64)
-        sC, sH = np.zeros((max(S.value, 1), 32), np.uint8), np.zeros((max(S.value, 1), 32), np.uint8)
+        sC, sH = np.zeros((max(S.value, 1), 32), np.uint8), np.zeros((max(S.value, 1), self.hb), np.uint8)
         blob = np.zeros(max(bl.value, 1), np.uint8)
         _chk(lib().dapol_proof_deserialize(*args, _ptr(leaf), _ptr(sC), _ptr(sH), _ptr(blob), ctypes.byref(cons)))
         return dict(height=h.value, leaf_idx=leaf[:k.value], sib_C=sC[:S.value], sib_H=sH[:S.value], aggregation_factor=agg.value,
@@ -252,7 +266,7 @@ class Context:
 
     def proof_nodes_deserialize(self, wire, n):
         w = _u8(np.frombuffer(bytes(wire), np.uint8)) if len(wire) else np.zeros(1, np.uint8)
-        C, H = np.zeros((max(n, 1), 32), np.uint8), np.zeros((max(n, 1), 32), np.uint8)
+        C, H = np.zeros((max(n, 1), 32), np.uint8), np.zeros((max(n, 1), self.hb), np.uint8)
         _chk(lib().dapol_proof_nodes_deserialize(self.h, n, _ptr(w), len(wire), _ptr(C), _ptr(H)))
         return C[:n], H[:n]
 
@@ -264,6 +278,9 @@ class Context:
         else:
             _chk(lib().dapol_ctx_create_opts(device, max_parties, digest, ctypes.byref(options), ctypes.byref(self.h)))
         self.max_parties = max_parties
+        hb = ctypes.c_int32(0)
+        _chk(lib().dapol_ctx_digest_bytes(self.h, ctypes.byref(hb)))
+        self.hb = int(hb.value)                   # bytes of one node hash: the last dimension of every H array of this context
 
     def close(self):
         if self.h:
@@ -285,7 +302,7 @@ class Context:
         v = _u64(v)
         n = v.shape[0]
         r32 = _u8(r32, n, 32)
-        C, H = np.zeros((n, 32), np.uint8), np.zeros((n, 32), np.uint8)
+        C, H = np.zeros((n, 32), np.uint8), np.zeros((n, self.hb), np.uint8)
         _chk(lib().dapol_commit_hash_batch(self.h, n, _ptr(v), _ptr(r32), _ptr(C), _ptr(H)))
         return C, H
 
@@ -336,7 +353,7 @@ class Context:
         """Paddable::padding at the given (level above the leaves, index) positions: (C, H, r); the value is 0."""
         level, index = _u8(level), _u64(index)
         n = index.shape[0]
-        C, H, r = (np.zeros((n, 32), np.uint8) for _ in range(3))
+        C, H, r = np.zeros((n, 32), np.uint8), np.zeros((n, self.hb), np.uint8), np.zeros((n, 32), np.uint8)
         seed = _u8(np.frombuffer(pad_seed, np.uint8))
         _chk(lib().dapol_padding_nodes(self.h, _ptr(seed), n, _ptr(level), _ptr(index), _ptr(C), _ptr(H), _ptr(r)))
         return C, H, r
@@ -345,8 +362,8 @@ class Context:
         """Mergeable::merge on compressed records; returns (C, H) or (C, H, v, r) when the secrets are given."""
         CL = _u8(CL).reshape(-1, 32)
         n = CL.shape[0]
-        HL, CR, HR = _u8(HL, n, 32), _u8(CR, n, 32), _u8(HR, n, 32)
-        C, H = np.zeros((n, 32), np.uint8), np.zeros((n, 32), np.uint8)
+        HL, CR, HR = _u8(HL, n, self.hb), _u8(CR, n, 32), _u8(HR, n, self.hb)
+        C, H = np.zeros((n, 32), np.uint8), np.zeros((n, self.hb), np.uint8)
         if vL is None:
             _chk(lib().dapol_merge_batch(self.h, n, _ptr(CL), _ptr(HL), None, None, _ptr(CR), _ptr(HR), None, None, _ptr(C), _ptr(H), None, None))
             return C, H
@@ -373,10 +390,10 @@ class Context:
         """DapolProof::verify for single-leaf proofs (Merkle re-merge + policy range verification)."""
         leaf_idx = _u64(leaf_idx)
         b = leaf_idx.shape[0]
-        lC, lH = _u8(leaf_C, b, 32), _u8(leaf_H, b, 32)
+        lC, lH = _u8(leaf_C, b, 32), _u8(leaf_H, b, self.hb)
         # the length-checked entry point: arrays whose sizes do not fit (height, policy, aggregation factor) -- proofs decoded from
         # hostile bytes -- come back as invalid instead of being over-read
-        pC, pH = _u8(path_C).reshape(-1, 32), _u8(path_H).reshape(-1, 32)
+        pC, pH = _u8(path_C).reshape(-1, 32), _u8(path_H).reshape(-1, self.hb)
         rp = _u8(range_proofs).reshape(-1)
         rC, rH = _u8(np.frombuffer(root_C, np.uint8)), _u8(np.frombuffer(root_H, np.uint8))
         seed = _u8(np.frombuffer(verify_seed, np.uint8)) if verify_seed is not None else None   # None: the library draws one from the OS
@@ -392,8 +409,8 @@ class Context:
         """DapolProof::verify_batch: one proof covering k leaves."""
         leaf_idx = _u64(leaf_idx)
         k = leaf_idx.shape[0]
-        lC, lH = _u8(leaf_C, k, 32), _u8(leaf_H, k, 32)
-        sC, sH = _u8(sib_C).reshape(-1, 32), _u8(sib_H).reshape(-1, 32)
+        lC, lH = _u8(leaf_C, k, 32), _u8(leaf_H, k, self.hb)
+        sC, sH = _u8(sib_C).reshape(-1, 32), _u8(sib_H).reshape(-1, self.hb)
         rp = _u8(np.frombuffer(bytes(range_proofs), np.uint8))
         rC, rH = _u8(np.frombuffer(root_C, np.uint8)), _u8(np.frombuffer(root_H, np.uint8))
         seed = _u8(np.frombuffer(verify_seed, np.uint8)) if verify_seed is not None else None   # None: the library draws one from the OS
@@ -494,6 +511,12 @@ class Comm:
         _chk(lib().dapol_comm_allreduce_u64(self.h, op, _ptr(w), w.shape[0]))
         return w
 
+    def timing(self, reset=False):
+        """dapol_comm_timing_get: device / host microseconds of the collectives made through this communicator."""
+        t = CommTiming()
+        _chk(lib().dapol_comm_timing_get(self.h, ctypes.byref(t), 1 if reset else 0))
+        return t
+
 
 def tree_node_records(tree_handle, level, index):
     """Records (C, H, v, r, found) of the nodes a (shard) tree stores at the given (level above the leaves, index) positions."""
@@ -568,7 +591,7 @@ class Tree:
             pass
 
     def root(self):
-        C, H, r = np.zeros(32, np.uint8), np.zeros(32, np.uint8), np.zeros(32, np.uint8)
+        C, H, r = np.zeros(32, np.uint8), np.zeros(self.ctx.hb, np.uint8), np.zeros(32, np.uint8)
         v = np.zeros(1, np.uint64)
         _chk(lib().dapol_tree_root(self.h, _ptr(C), _ptr(H), _ptr(v), _ptr(r)))
         return C.tobytes(), H.tobytes(), int(v[0]), r.tobytes()
@@ -594,7 +617,7 @@ class Tree:
         _chk(lib().dapol_tree_level_size(self.h, level, _ptr(a), _ptr(b)))
         n = int(a[0] + b[0])
         idx, v = np.zeros(n, np.uint64), np.zeros(n, np.uint64)
-        r, C, H = (np.zeros((n, 32), np.uint8) for _ in range(3))
+        r, C, H = np.zeros((n, 32), np.uint8), np.zeros((n, 32), np.uint8), np.zeros((n, self.ctx.hb), np.uint8)
         pad = np.zeros(n, np.uint8)
         _chk(lib().dapol_tree_level_nodes(self.h, level, _ptr(idx), _ptr(v), _ptr(r), _ptr(C), _ptr(H), _ptr(pad)))
         return idx, v, r, C, H, pad
@@ -602,7 +625,7 @@ class Tree:
     def paths(self, leaf_idx):
         leaf_idx = _u64(leaf_idx)
         b, h = leaf_idx.shape[0], self.height
-        C, H, r = (np.zeros((b, h, 32), np.uint8) for _ in range(3))
+        C, H, r = np.zeros((b, h, 32), np.uint8), np.zeros((b, h, self.ctx.hb), np.uint8), np.zeros((b, h, 32), np.uint8)
         v = np.zeros((b, h), np.uint64)
         _chk(lib().dapol_tree_paths(self.h, b, _ptr(leaf_idx), _ptr(C), _ptr(H), _ptr(v), _ptr(r)))
         return C, H, v, r
@@ -616,7 +639,7 @@ class Tree:
         es = lib().dapol_entity_proof_size(S, policy, aggregation_factor, n_bits)
         if es == 0:
             raise DapolError(8, "bad policy / aggregation_factor / n_bits")
-        C, H = np.zeros((S, 32), np.uint8), np.zeros((S, 32), np.uint8)
+        C, H = np.zeros((S, 32), np.uint8), np.zeros((S, self.ctx.hb), np.uint8)
         out = np.zeros(es, np.uint8)
         seed = _u8(np.frombuffer(nonce_seed, np.uint8))
         _chk(lib().dapol_prove_batch(self.ctx.h, self.h, k, _ptr(leaf_idx), policy, aggregation_factor, n_bits, _ptr(seed), _ptr(C), _ptr(H),
@@ -629,7 +652,7 @@ class Tree:
         nu = 0 if upper is None else len(upper[2])
         b, h = leaf_idx.shape[0], self.height + nu
         es = lib().dapol_entity_proof_size(h, policy, aggregation_factor, n_bits)
-        C, H = np.zeros((b, h, 32), np.uint8), np.zeros((b, h, 32), np.uint8)
+        C, H = np.zeros((b, h, 32), np.uint8), np.zeros((b, h, self.ctx.hb), np.uint8)
         out = np.zeros((b, max(es, 1)), np.uint8)
         seed = _u8(np.frombuffer(nonce_seed, np.uint8))
         if nu:

@@ -120,6 +120,23 @@ struct dapol_ctx {
     RangeScratch scratch;        // grown on demand by the range prover
 };
 
+// Width of the context's node hash D: 8 words (BLAKE3, Blake2s) or 16 (Blake2b).  Every H buffer of the C ABI holds this many
+// bytes per node (dapol_ctx_digest_bytes).
+static inline int ctx_hw(const dapol_ctx* c) { return dg_hash_words(c->tv.digest); }
+static inline size_t ctx_hash_bytes(const dapol_ctx* c) { return (size_t)ctx_hw(c) * 4; }
+static inline bool ctx_wide(const dapol_ctx* c) { return ctx_hw(c) == 16; }
+// Paths that exist for the 32-byte digests only (the sharded / workload / record paths and Dapol::new's leaf derivation, which the
+// reference itself refuses for other sizes, src/dapol/mod.rs:101-103).
+#define NEEDS_32_BYTE_DIGEST(ctx, what)                                                                                                  \
+    do {                                                                                                                                 \
+        if (ctx_wide(ctx)) return fail(DAPOL_ERR_INVALID_DIGEST_SIZE, what " needs a 32-byte node digest (DapolError::InvalidDigestSize)"); \
+    } while (0)
+int32_t dapol_ctx_digest_bytes(dapol_ctx* ctx, int32_t* bytes) {
+    if (!ctx || !bytes) return fail(DAPOL_ERR_INVALID_ARGUMENT, "null argument");
+    *bytes = (int32_t)ctx_hash_bytes(ctx);
+    return DAPOL_OK;
+}
+
 const char* dapol_strerror(int32_t code) {
     switch (code) {
         case DAPOL_OK: return "ok";
@@ -254,8 +271,8 @@ int32_t dapol_ctx_create_opts(int32_t device, int32_t max_parties, int32_t diges
     if (!out) return fail(DAPOL_ERR_INVALID_ARGUMENT, "out is null");
     *out = nullptr;
     if (!options_ok(options)) return fail(DAPOL_ERR_INVALID_ARGUMENT, "bad dapol_options (struct_size, or a field out of range)");
-    if (digest_id != DAPOL_DIGEST_BLAKE3 && digest_id != DAPOL_DIGEST_BLAKE2S)
-        return fail(DAPOL_ERR_INVALID_DIGEST_SIZE, "node digest must be BLAKE3 or Blake2s-256 (32-byte output, DapolError::InvalidDigestSize)");
+    if (digest_id != DAPOL_DIGEST_BLAKE3 && digest_id != DAPOL_DIGEST_BLAKE2S && digest_id != DAPOL_DIGEST_BLAKE2B)
+        return fail(DAPOL_ERR_INVALID_DIGEST_SIZE, "node digest must be BLAKE3, Blake2s-256 or Blake2b-512");
     if (max_parties < 1 || max_parties > 1024 || (max_parties & (max_parties - 1)))
         return fail(DAPOL_ERR_INVALID_ARGUMENT, "max_parties must be a power of two in [1, 1024]");
     int count = 0;
@@ -412,14 +429,19 @@ int32_t dapol_commit_hash_batch(dapol_ctx* ctx, size_t n, const uint64_t* v, con
     if (n == 0) return DAPOL_OK;
     HIPCHK(hipSetDevice(ctx->device));
     DevBuf<uint64_t> dv;
-    DevBuf<uint32_t> dr, dC, dH;
+    DevBuf<uint32_t> dr, dC, dH, dHw;
     HIPCHK(dv.alloc(n)); HIPCHK(dr.alloc(n * 8)); HIPCHK(dC.alloc(n * 8)); HIPCHK(dH.alloc(n * 8));
     HIPCHK(hipMemcpyAsync(dv.p, v, n * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(dr.p, r32, n * 32, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_commit_hash, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, ctx->tv, n, dv.p, dr.p, dC.p, dH.p, (int32_t*)nullptr);
     LAUNCH_CHECK();
+    if (ctx_wide(ctx)) {                           // 64-byte digest: H = D(C) over the commitments just made
+        HIPCHK(dHw.alloc(n * 16));
+        hipLaunchKernelGGL(k_wide_hash_leaves, dim3(nblk(n, 256)), dim3(256), 0, ctx->stream, n, dC.p, dHw.p);
+        LAUNCH_CHECK();
+    }
     HIPCHK(hipMemcpyAsync(C_out32, dC.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(H_out32, dH.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(H_out32, ctx_wide(ctx) ? dHw.p : dH.p, n * ctx_hash_bytes(ctx), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return DAPOL_OK;
 }
@@ -448,6 +470,10 @@ struct dapol_tree {
     uint8_t pad_seed[32] = {0};
     bool invalid = false;              // an in-place update failed after its first write: root and leaves may disagree; every call refuses the tree
     DevBuf<LevelView> d_views;         // view(0..height, nullptr) on the device, for kernels that walk several levels
+    // 64-byte node hashes (a Blake2b context): the hash chain laid over the built tree (tree_hash_wide), per level H16[n] | padH16[n]
+    DevBuf<uint32_t> wide;
+    std::vector<WideView> wviews;      // host copy: pointers into `wide`
+    DevBuf<WideView> d_wviews;
     LevelView view(int k, int32_t* ext) {
         LevelBuf& L = levels[k];
         LevelView lv;
@@ -477,8 +503,8 @@ struct TreePoison {                    // armed before the first write of an in-
 
 // Builds the tree from device-resident leaf arrays (d_idx sorted; d_r is masked in place).  own==true: the tree
 // takes ownership of nothing; leaf arrays must outlive it (they are owned by the caller-side holder below).
-static int32_t tree_build_device(dapol_ctx* ctx, int index_bits, int shard_bits, size_t n, uint64_t* d_idx, uint64_t* d_v, uint32_t* d_r,
-                                 const uint8_t pad_seed32[32], dapol_tree* t) {
+static int32_t tree_build_device_core(dapol_ctx* ctx, int index_bits, int shard_bits, size_t n, uint64_t* d_idx, uint64_t* d_v, uint32_t* d_r,
+                                      const uint8_t pad_seed32[32], dapol_tree* t) {
     hipStream_t st = ctx->stream;
     const int height = index_bits - shard_bits;       // levels built on this GPU
     t->ctx = ctx;
@@ -623,6 +649,40 @@ static int32_t tree_build_device(dapol_ctx* ctx, int index_bits, int shard_bits,
     return DAPOL_OK;
 }
 
+// The hash chain of a 64-byte digest over a tree whose structure, commitments and padding nodes are in place (after a build or an
+// update): level 0 = D(C), then one launch per level (kernels_ctx_tree.h, "64-byte node hashes").  The whole chain is redone after
+// every update -- a pass over the tree's nodes, milliseconds at the reference test's sizes; only the 32-byte digests have the
+// incremental re-hash.
+static int32_t tree_hash_wide(dapol_tree* t) {
+    dapol_ctx* ctx = t->ctx;
+    if (!ctx_wide(ctx)) return DAPOL_OK;
+    hipStream_t st = ctx->stream;
+    const int H = t->height;
+    size_t words = 0;
+    std::vector<size_t> off((size_t)H + 1);
+    for (int k = 0; k <= H; k++) { off[k] = words; words += 2 * t->levels[k].n * 16; }
+    if (t->wide.n < words) HIPCHK(t->wide.alloc(words + words / 8));
+    t->wviews.resize((size_t)H + 1);
+    for (int k = 0; k <= H; k++) t->wviews[k] = WideView{t->wide.p + off[k], t->wide.p + off[k] + t->levels[k].n * 16};
+    if (t->d_wviews.n != t->wviews.size()) HIPCHK(t->d_wviews.alloc(t->wviews.size()));
+    HIPCHK(hipMemcpyAsync(t->d_wviews.p, t->wviews.data(), t->wviews.size() * sizeof(WideView), hipMemcpyHostToDevice, st));
+    const size_t n0 = t->levels[0].n;
+    hipLaunchKernelGGL(k_wide_hash_leaves, dim3(nblk(n0, 256)), dim3(256), 0, st, n0, t->levels[0].C.p, t->wviews[0].H);
+    LAUNCH_CHECK();
+    for (int k = 0; k < H; k++) {
+        LevelView cur = t->view(k, nullptr);
+        hipLaunchKernelGGL(k_wide_hash_level, dim3(nblk(cur.n, 256)), dim3(256), 0, st, cur, t->wviews[k], t->wviews[k + 1]);
+        LAUNCH_CHECK();
+    }
+    HIPCHK(hipStreamSynchronize(st));              // (wviews is copied from a host vector that may be resized by the next call)
+    return DAPOL_OK;
+}
+static int32_t tree_build_device(dapol_ctx* ctx, int index_bits, int shard_bits, size_t n, uint64_t* d_idx, uint64_t* d_v, uint32_t* d_r,
+                                 const uint8_t pad_seed32[32], dapol_tree* t) {
+    int32_t rc = tree_build_device_core(ctx, index_bits, shard_bits, n, d_idx, d_v, d_r, pad_seed32, t);
+    return rc ? rc : tree_hash_wide(t);
+}
+
 struct OwnedLeaves {
     DevBuf<uint64_t> idx, v;
     DevBuf<uint32_t> r;
@@ -643,6 +703,8 @@ int32_t dapol_tree_build(dapol_ctx* ctx, int32_t height, size_t n, const uint64_
     if (!ctx || !out || !pad_seed32 || (n && (!leaf_idx || !v || !r32))) return fail(DAPOL_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
     if (height < 0 || height > 64) return fail(DAPOL_ERR_TREE_HEIGHT_TOO_BIG, "tree height must not exceed 64");
+    if (enforce_sparsity && ctx_wide(ctx))           // Dapol::new (src/dapol/mod.rs:101-103); new_blank + build (enforce_sparsity = 0) has no such check
+        return fail(DAPOL_ERR_INVALID_DIGEST_SIZE, "digest size must be 32 bytes (DapolError::InvalidDigestSize)");
     if (enforce_sparsity && height < 64 && ((double)n * 2.0 > (double)(1ull << height) ))
         return fail(DAPOL_ERR_SPARSITY_TOO_SMALL, "2^height < 2 * number of liabilities");
     if (n == 0) return fail(DAPOL_ERR_INVALID_ARGUMENT, "empty leaf set");
@@ -667,6 +729,7 @@ int32_t dapol_tree_build_shard(dapol_ctx* ctx, int32_t total_height, int32_t sha
                                const uint64_t* v, const uint8_t* r32, const uint8_t pad_seed32[32], dapol_tree** out) {
     if (!ctx || !out || !pad_seed32 || !n || !leaf_idx || !v || !r32) return fail(DAPOL_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
+    if (shard_bits) NEEDS_32_BYTE_DIGEST(ctx, "the sharded (multi-GPU) path");
     if (total_height < 0 || total_height > 64) return fail(DAPOL_ERR_TREE_HEIGHT_TOO_BIG, "tree height must not exceed 64");
     if (shard_bits < 0 || shard_bits > total_height || shard_bits > 16) return fail(DAPOL_ERR_INVALID_ARGUMENT, "shard_bits out of range");
     if (n > ((size_t)1 << 31)) return fail(DAPOL_ERR_INVALID_ARGUMENT, "at most 2^31 leaves per GPU (32-bit node positions); memory is the practical bound");
@@ -883,7 +946,17 @@ static int32_t tree_insert_incremental(dapol_tree_owned* own, size_t k, const st
     return DAPOL_OK;
 }
 
+static int32_t tree_update_impl(dapol_tree* tree, size_t k, const uint64_t* leaf_idx, const uint64_t* v, const uint8_t* r32);
 int32_t dapol_tree_update(dapol_tree* tree, size_t k, const uint64_t* leaf_idx, const uint64_t* v, const uint8_t* r32) {
+    int32_t rc = tree_update_impl(tree, k, leaf_idx, v, r32);
+    if (rc || !tree || !k || !ctx_wide(tree->ctx)) return rc;
+    // a 64-byte digest: the in-place paths re-hash 32-byte chains only; lay the whole 64-byte chain again (the rebuild path has
+    // done so already -- once more costs a pass over the nodes and keeps this wrapper free of cases)
+    rc = tree_hash_wide(tree);
+    if (rc) tree->invalid = true;
+    return rc;
+}
+static int32_t tree_update_impl(dapol_tree* tree, size_t k, const uint64_t* leaf_idx, const uint64_t* v, const uint8_t* r32) {
     if (!tree || (k && (!leaf_idx || !v || !r32))) return fail(DAPOL_ERR_INVALID_ARGUMENT, "null argument");
     if (k == 0) return DAPOL_OK;
     TREE_USABLE(tree);
@@ -943,7 +1016,9 @@ int32_t dapol_tree_update(dapol_tree* tree, size_t k, const uint64_t* leaf_idx, 
                     own->last_update_path = 2;
                     if (ei.empty()) return DAPOL_OK;
                     rc = tree_update_incremental(own, ei.size(), ei, ev, er, &done);
-                    if (rc != DAPOL_OK) return rc;
+                    //  the inserts are in: whatever stops the replacements now -- also an error BEFORE their first write,
+                    // which would leave a consistent but half-updated tree -- is a failed in-place update; the tree is refused from here on
+                    if (rc != DAPOL_OK) { own->invalid = true; return rc; }
                     if (done) { own->last_update_path = 3; return DAPOL_OK; }
                     own->invalid = true;                     // the new leaves are in, the replacements are not
                     return fail(DAPOL_ERR_INVALID_ARGUMENT, "internal: a leaf found before the insert was not found after it");
@@ -1043,29 +1118,40 @@ int32_t dapol_padding_nodes(dapol_ctx* ctx, const uint8_t pad_seed32[32], size_t
     HIPCHK(hipMemcpyAsync(di.p, index, n * 8, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_padding_nodes, dim3(nblk(n, 64)), dim3(64), 0, st, ctx->tv, n, seed.p, dl.p, di.p, dC.p, dH.p, dr.p);
     LAUNCH_CHECK();
+    DevBuf<uint32_t> dHw;
+    if (ctx_wide(ctx)) {
+        HIPCHK(dHw.alloc(n * 16));
+        hipLaunchKernelGGL(k_wide_hash_leaves, dim3(nblk(n, 256)), dim3(256), 0, st, n, dC.p, dHw.p);
+        LAUNCH_CHECK();
+    }
     HIPCHK(hipMemcpyAsync(C32, dC.p, n * 32, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(H32, dH.p, n * 32, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(H32, ctx_wide(ctx) ? dHw.p : dH.p, n * ctx_hash_bytes(ctx), hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(r32, dr.p, n * 32, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     return DAPOL_OK;
 }
 
 // Mergeable::merge on compressed records
+template <int HW>
+__device__ __forceinline__ void ldh(uint32_t* w, const uint32_t* p) { ld8(w, p); if (HW == 16) ld8(w + 8, p + 8); }
+template <int HW>
+__device__ __forceinline__ void sth(uint32_t* p, const uint32_t* w) { st8(p, w); if (HW == 16) st8(p + 8, w + 8); }
+template <int HW>
 __global__ void k_merge_records(int dg, size_t n, const uint32_t* CL, const uint32_t* HL, const uint64_t* vL, const uint32_t* rL,
                                 const uint32_t* CR, const uint32_t* HR, const uint64_t* vR, const uint32_t* rR, uint32_t* C, uint32_t* H,
                                 uint64_t* v, uint32_t* r, uint32_t* bad) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint32_t cl[8], cr[8], hl[8], hr[8], cp[8], hp[8];
-    ld8(cl, CL + i * 8); ld8(cr, CR + i * 8); ld8(hl, HL + i * 8); ld8(hr, HR + i * 8);
+    uint32_t cl[8], cr[8], hl[HW], hr[HW], cp[8], hp[HW];
+    ld8(cl, CL + i * 8); ld8(cr, CR + i * 8); ldh<HW>(hl, HL + i * HW); ldh<HW>(hr, HR + i * HW);
     ge_p3 a, b, p;
     bool ok = ge_decompress(a, cl) & ge_decompress(b, cr);
     if (!ok) { atomicOr(bad, 1u); return; }
     ge_add(p, a, b);
     ge_compress(cp, p);
-    node_hash128(dg, hp, cl, cr, hl, hr);
+    node_hash_parent_w<HW>(dg, hp, cl, cr, hl, hr);
     st8(C + i * 8, cp);
-    st8(H + i * 8, hp);
+    sth<HW>(H + i * HW, hp);
     if (v) {
         uint32_t ra[8], rb[8], rp[8];
         ld8(ra, rL + i * 8); ld8(rb, rR + i * 8);
@@ -1087,13 +1173,14 @@ int32_t dapol_merge_batch(dapol_ctx* ctx, size_t n, const uint8_t* CL32, const u
     hipStream_t st = ctx->stream;
     DevBuf<uint32_t> d[8], bad;
     DevBuf<uint64_t> dv[3];
-    for (auto& x : d) HIPCHK(x.alloc(n * 8));
+    const size_t hw = (size_t)ctx_hw(ctx), hb = hw * 4;            // H arrays: ctx_hash_bytes per node
+    for (auto& x : d) HIPCHK(x.alloc(n * hw));
     HIPCHK(bad.alloc(1));
     HIPCHK(hipMemsetAsync(bad.p, 0, 4, st));
     HIPCHK(hipMemcpyAsync(d[0].p, CL32, n * 32, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(d[1].p, HL32, n * 32, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d[1].p, HL32, n * hb, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(d[2].p, CR32, n * 32, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(d[3].p, HR32, n * 32, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d[3].p, HR32, n * hb, hipMemcpyHostToDevice, st));
     if (with_secrets) {
         for (auto& x : dv) HIPCHK(x.alloc(n));
         HIPCHK(hipMemcpyAsync(d[4].p, rL32, n * 32, hipMemcpyHostToDevice, st));
@@ -1102,14 +1189,18 @@ int32_t dapol_merge_batch(dapol_ctx* ctx, size_t n, const uint8_t* CL32, const u
         HIPCHK(hipMemcpyAsync(dv[1].p, vR, n * 8, hipMemcpyHostToDevice, st));
     }
     DevBuf<uint32_t> oC, oH;
-    HIPCHK(oC.alloc(n * 8)); HIPCHK(oH.alloc(n * 8));
-    hipLaunchKernelGGL(k_merge_records, dim3(nblk(n, 64)), dim3(64), 0, st, ctx->tv.digest, n, d[0].p, d[1].p, with_secrets ? dv[0].p : nullptr, d[4].p,
-                       d[2].p, d[3].p, with_secrets ? dv[1].p : nullptr, d[5].p, oC.p, oH.p, with_secrets ? dv[2].p : nullptr, d[6].p, bad.p);
+    HIPCHK(oC.alloc(n * 8)); HIPCHK(oH.alloc(n * hw));
+    if (hw == 16)
+        hipLaunchKernelGGL(k_merge_records<16>, dim3(nblk(n, 64)), dim3(64), 0, st, ctx->tv.digest, n, d[0].p, d[1].p, with_secrets ? dv[0].p : nullptr, d[4].p,
+                           d[2].p, d[3].p, with_secrets ? dv[1].p : nullptr, d[5].p, oC.p, oH.p, with_secrets ? dv[2].p : nullptr, d[6].p, bad.p);
+    else
+        hipLaunchKernelGGL(k_merge_records<8>, dim3(nblk(n, 64)), dim3(64), 0, st, ctx->tv.digest, n, d[0].p, d[1].p, with_secrets ? dv[0].p : nullptr, d[4].p,
+                           d[2].p, d[3].p, with_secrets ? dv[1].p : nullptr, d[5].p, oC.p, oH.p, with_secrets ? dv[2].p : nullptr, d[6].p, bad.p);
     LAUNCH_CHECK();
     uint32_t h_bad = 0;
     HIPCHK(hipMemcpyAsync(&h_bad, bad.p, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(C32, oC.p, n * 32, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(H32, oH.p, n * 32, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(H32, oH.p, n * hb, hipMemcpyDeviceToHost, st));
     if (with_secrets) {
         HIPCHK(hipMemcpyAsync(v, dv[2].p, n * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(r32, d[6].p, n * 32, hipMemcpyDeviceToHost, st));
@@ -1135,7 +1226,7 @@ int32_t dapol_tree_root(dapol_tree* tree, uint8_t C32[32], uint8_t H32[32], uint
     HIPCHK(hipSetDevice(tree->ctx->device));
     LevelView lv = tree->view(tree->height, nullptr);
     if (C32) HIPCHK(hipMemcpy(C32, lv.C, 32, hipMemcpyDeviceToHost));
-    if (H32) HIPCHK(hipMemcpy(H32, lv.H, 32, hipMemcpyDeviceToHost));
+    if (H32) HIPCHK(hipMemcpy(H32, ctx_wide(tree->ctx) ? tree->wviews[tree->height].H : lv.H, ctx_hash_bytes(tree->ctx), hipMemcpyDeviceToHost));
     if (v) HIPCHK(hipMemcpy(v, lv.v, 8, hipMemcpyDeviceToHost));
     if (r32) HIPCHK(hipMemcpy(r32, lv.r, 32, hipMemcpyDeviceToHost));
     return DAPOL_OK;
@@ -1185,13 +1276,15 @@ int32_t dapol_tree_level_nodes(dapol_tree* tree, int32_t level, uint64_t* idx, u
     HIPCHK(hipMemcpy(idx, lv.idx, n * 8, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(v, lv.v, n * 8, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(r32, lv.r, n * 32, hipMemcpyDeviceToHost));
+    const bool wide = ctx_wide(tree->ctx);
+    const size_t hb = ctx_hash_bytes(tree->ctx);
     HIPCHK(hipMemcpy(C32, lv.C, n * 32, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(H32, lv.H, n * 32, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(H32, wide ? tree->wviews[level].H : lv.H, n * hb, hipMemcpyDeviceToHost));
     memset(is_pad, 0, n);
-    std::vector<uint8_t> pc(n * 32), ph(n * 32), pr(n * 32);
+    std::vector<uint8_t> pc(n * 32), ph(n * hb), pr(n * 32);
     if (level < tree->height) {
         HIPCHK(hipMemcpy(pc.data(), lv.padC, n * 32, hipMemcpyDeviceToHost));
-        HIPCHK(hipMemcpy(ph.data(), lv.padH, n * 32, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(ph.data(), wide ? tree->wviews[level].padH : lv.padH, n * hb, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(pr.data(), lv.padr, n * 32, hipMemcpyDeviceToHost));
     }
     size_t o = n;
@@ -1201,7 +1294,7 @@ int32_t dapol_tree_level_nodes(dapol_tree* tree, int32_t level, uint64_t* idx, u
         v[o] = 0;
         memcpy(r32 + o * 32, pr.data() + i * 32, 32);
         memcpy(C32 + o * 32, pc.data() + i * 32, 32);
-        memcpy(H32 + o * 32, ph.data() + i * 32, 32);
+        memcpy(H32 + o * hb, ph.data() + i * hb, hb);
         is_pad[o] = 1;
         o++;
     }
@@ -1222,6 +1315,14 @@ static int32_t tree_paths_device(dapol_tree* tree, size_t b, const uint64_t* d_l
     HIPCHK(hipMemcpyAsync(&h_missing, missing.p, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (h_missing) return fail(DAPOL_ERR_UNKNOWN_LEAF, "no liability at one of the requested leaves");
+    if (ctx_wide(tree->ctx) && out.H) {            // 64-byte hashes: out.H is [b][height + n_upper][16], filled from the wide chain
+        if (tree->height) {
+            hipLaunchKernelGGL(k_wide_path_walk, dim3(nblk(b, 64)), dim3(64), 0, st, b, d_pos, tree->d_views.p, tree->d_wviews.p, tree->height, n_upper,
+                               g_wire.siblings_leaf_first, out.H);
+            LAUNCH_CHECK();
+        }
+        out.H = nullptr;
+    }
     if (tree->height) {
         hipLaunchKernelGGL(k_tree_path_walk, dim3(nblk(b, 64)), dim3(64), 0, st, b, d_pos, tree->d_views.p, tree->height, n_upper, g_wire.siblings_leaf_first, out);
         LAUNCH_CHECK();
@@ -1240,13 +1341,13 @@ int32_t dapol_tree_paths(dapol_tree* tree, size_t b, const uint64_t* leaf_idx, u
     DevBuf<uint64_t> dl, dv;
     DevBuf<uint32_t> dC, dH, dr, dpos;
     HIPCHK(dl.alloc(b)); HIPCHK(dpos.alloc(b));
-    HIPCHK(dC.alloc(tot * 8)); HIPCHK(dH.alloc(tot * 8)); HIPCHK(dr.alloc(tot * 8)); HIPCHK(dv.alloc(tot));
+    HIPCHK(dC.alloc(tot * 8)); HIPCHK(dH.alloc(tot * (size_t)ctx_hw(tree->ctx))); HIPCHK(dr.alloc(tot * 8)); HIPCHK(dv.alloc(tot));
     HIPCHK(hipMemcpyAsync(dl.p, leaf_idx, b * 8, hipMemcpyHostToDevice, st));
     PathOut po{dC.p, dH.p, dv.p, dr.p};
     int32_t rc = tree_paths_device(tree, b, dl.p, po, dpos.p);
     if (rc) return rc;
     if (sib_C32) HIPCHK(hipMemcpyAsync(sib_C32, dC.p, tot * 32, hipMemcpyDeviceToHost, st));
-    if (sib_H32) HIPCHK(hipMemcpyAsync(sib_H32, dH.p, tot * 32, hipMemcpyDeviceToHost, st));
+    if (sib_H32) HIPCHK(hipMemcpyAsync(sib_H32, dH.p, tot * ctx_hash_bytes(tree->ctx), hipMemcpyDeviceToHost, st));
     if (sib_v) HIPCHK(hipMemcpyAsync(sib_v, dv.p, tot * 8, hipMemcpyDeviceToHost, st));
     if (sib_r32) HIPCHK(hipMemcpyAsync(sib_r32, dr.p, tot * 32, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));

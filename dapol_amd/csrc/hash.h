@@ -91,7 +91,7 @@ DAPOL_HD void seed_wide(uint32_t* out16, const uint32_t* seed8, uint32_t domain,
 // D = BLAKE3 (any length: the chunk chaining values of inputs beyond 1024 bytes go through the caller's stack, see
 // dg_init_long) or Blake2s-256 (the reference's KAT digest, src/dapol/tests.rs:13,21).
 // Usage: dg_init / dg_init_long, dg_update* (bytes), dg_final -> eight little-endian words.
-enum : int { DG_BLAKE3 = 0, DG_BLAKE2S = 1 };
+enum : int { DG_BLAKE3 = 0, DG_BLAKE2S = 1, DG_BLAKE2B = 2 };   // (Blake2b: node hashes only, 64 bytes -- see "wide node hashes" below)
 enum : int { B3_STACK_DEPTH = 24 };   // subtree chaining values of up to 2^24 chunks = 16 GiB (inputs here are < 2^32 + 600 bytes)
 struct Digest {
     uint32_t h[8];
@@ -162,6 +162,82 @@ DAPOL_HD void node_hash32(int kind, uint32_t* out8, const uint32_t* c8) {
 DAPOL_HD void node_hash128(int kind, uint32_t* out8, const uint32_t* cl, const uint32_t* cr, const uint32_t* hl, const uint32_t* hr) {
     if (kind == DG_BLAKE2S) blake2s_hash128(out8, cl, cr, hl, hr);
     else blake3_hash128(out8, cl, cr, hl, hr);
+}
+
+// ---------------------------------------------------------------------------------------- wide node hashes (Blake2b-512)
+// The reference's own integration test also runs Dapol<blake2::Blake2b, _> through new_blank + build + prove + verify
+// (src/tests.rs:100-106; only Dapol::new checks D::output_size() == 32, src/dapol/mod.rs:101-103): node hashes of 64 bytes,
+// leaf = Blake2b(C) (32 bytes: one block), parent = Blake2b(C_L || C_R || H_L || H_R) (192 bytes: a full block + 64 bytes).
+// A hash is 16 little-endian 32-bit words here, like every other byte string of the library.
+DAPOL_HD uint64_t rotr64(uint64_t x, int n) {
+    return (x >> n) | (x << (64 - n));
+}
+DAPOL_HD void blake2b_compress(uint64_t* h, const uint64_t* m, uint64_t t, bool last) {
+    const uint64_t IV[8] = {0x6A09E667F3BCC908ull, 0xBB67AE8584CAA73Bull, 0x3C6EF372FE94F82Bull, 0xA54FF53A5F1D36F1ull,
+                            0x510E527FADE682D1ull, 0x9B05688C2B3E6C1Full, 0x1F83D9ABFB41BD6Bull, 0x5BE0CD19137E2179ull};
+    const uint8_t SIG[10][16] = {{0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+                                 {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+                                 {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+                                 {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+                                 {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0}};
+    uint64_t v[16];
+    for (int i = 0; i < 8; i++) { v[i] = h[i]; v[8 + i] = IV[i]; }
+    v[12] ^= t;                                    // (inputs here are < 2^64 bytes: the high counter word stays 0)
+    if (last) v[14] = ~v[14];
+#define B2BG(a, b, c, d, x, y)               \
+    v[a] = v[a] + v[b] + (x);                \
+    v[d] = rotr64(v[d] ^ v[a], 32);          \
+    v[c] = v[c] + v[d];                      \
+    v[b] = rotr64(v[b] ^ v[c], 24);          \
+    v[a] = v[a] + v[b] + (y);                \
+    v[d] = rotr64(v[d] ^ v[a], 16);          \
+    v[c] = v[c] + v[d];                      \
+    v[b] = rotr64(v[b] ^ v[c], 63);
+    for (int r = 0; r < 12; r++) {
+        const uint8_t* s = SIG[r % 10];
+        B2BG(0, 4, 8, 12, m[s[0]], m[s[1]]) B2BG(1, 5, 9, 13, m[s[2]], m[s[3]]) B2BG(2, 6, 10, 14, m[s[4]], m[s[5]]) B2BG(3, 7, 11, 15, m[s[6]], m[s[7]])
+        B2BG(0, 5, 10, 15, m[s[8]], m[s[9]]) B2BG(1, 6, 11, 12, m[s[10]], m[s[11]]) B2BG(2, 7, 8, 13, m[s[12]], m[s[13]]) B2BG(3, 4, 9, 14, m[s[14]], m[s[15]])
+    }
+#undef B2BG
+    for (int i = 0; i < 8; i++) h[i] ^= v[i] ^ v[8 + i];
+}
+DAPOL_HD void blake2b_init512(uint64_t* h) {
+    const uint64_t IV[8] = {0x6A09E667F3BCC908ull, 0xBB67AE8584CAA73Bull, 0x3C6EF372FE94F82Bull, 0xA54FF53A5F1D36F1ull,
+                            0x510E527FADE682D1ull, 0x9B05688C2B3E6C1Full, 0x1F83D9ABFB41BD6Bull, 0x5BE0CD19137E2179ull};
+    for (int i = 0; i < 8; i++) h[i] = IV[i];
+    h[0] ^= 0x01010040ull;                         // parameter block: digest 64 bytes, no key, fanout 1, depth 1
+}
+DAPOL_HD uint64_t w64(const uint32_t* w, int i) { return (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32); }
+DAPOL_HD void blake2b_hash32(uint32_t* out16, const uint32_t* c8) {
+    uint64_t h[8], m[16];
+    blake2b_init512(h);
+    for (int i = 0; i < 4; i++) m[i] = w64(c8, i);
+    for (int i = 4; i < 16; i++) m[i] = 0;
+    blake2b_compress(h, m, 32, true);
+    for (int i = 0; i < 8; i++) { out16[2 * i] = (uint32_t)h[i]; out16[2 * i + 1] = (uint32_t)(h[i] >> 32); }
+}
+DAPOL_HD void blake2b_hash192(uint32_t* out16, const uint32_t* cl, const uint32_t* cr, const uint32_t* hl16, const uint32_t* hr16) {
+    uint64_t h[8], m[16];
+    blake2b_init512(h);
+    for (int i = 0; i < 4; i++) { m[i] = w64(cl, i); m[4 + i] = w64(cr, i); }
+    for (int i = 0; i < 8; i++) m[8 + i] = w64(hl16, i);
+    blake2b_compress(h, m, 128, false);
+    for (int i = 0; i < 8; i++) { m[i] = w64(hr16, i); m[8 + i] = 0; }
+    blake2b_compress(h, m, 192, true);
+    for (int i = 0; i < 8; i++) { out16[2 * i] = (uint32_t)h[i]; out16[2 * i + 1] = (uint32_t)(h[i] >> 32); }
+}
+// Words of one node hash of digest `kind`, and the node hash over HW-word hashes: HW = 8 -> the 32-byte digests above (by kind),
+// HW = 16 -> Blake2b-512.  Kernels that carry hashes are templates over HW; the host picks the instantiation from the context.
+DAPOL_HD int dg_hash_words(int kind) { return kind == DG_BLAKE2B ? 16 : 8; }
+template <int HW>
+DAPOL_HD void node_hash_leaf_w(int kind, uint32_t* out, const uint32_t* c8) {
+    if (HW == 16) blake2b_hash32(out, c8);
+    else node_hash32(kind, out, c8);
+}
+template <int HW>
+DAPOL_HD void node_hash_parent_w(int kind, uint32_t* out, const uint32_t* cl, const uint32_t* cr, const uint32_t* hl, const uint32_t* hr) {
+    if (HW == 16) blake2b_hash192(out, cl, cr, hl, hr);
+    else node_hash128(kind, out, cl, cr, hl, hr);
 }
 
 DAPOL_HD void dg_init(Digest& d, int kind) {

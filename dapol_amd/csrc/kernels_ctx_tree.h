@@ -863,4 +863,66 @@ __global__ void k_tree_path_upper(size_t b, int height, int n_upper, int leaf_fi
     if (out.r) { ld8(w, ur + u * 8); st8(out.r + slot * 8, w); }
 }
 
+// ------------------------------------------------------------------------------------- 64-byte node hashes (Blake2b)
+// Dapol<blake2::Blake2b, R> on the new_blank + build path (src/tests.rs:100-106; mod.rs:196-208 has no digest check).  Everything
+// of a node but its hash -- structure, values, blindings, commitments, padding nodes -- is independent of the digest, so a
+// context with a 64-byte digest builds (and updates) its trees with the kernels above and then lays the hash chain over them:
+// per level an array of 16-word hashes for the real nodes and one for their padding siblings (WideView), filled bottom-up, one
+// launch per level.  The 8-word H arrays of such a tree are not used.
+struct WideView {
+    uint32_t* H;       // [n][16]  hash of real node i
+    uint32_t* padH;    // [n][16]  hash of the padding sibling of real node i (where has_pad[i])
+};
+__device__ __forceinline__ void ld16(uint32_t* w, const uint32_t* p) { ld8(w, p); ld8(w + 8, p + 8); }
+__device__ __forceinline__ void st16(uint32_t* p, const uint32_t* w) { st8(p, w); st8(p + 8, w + 8); }
+// leaves: H = D(C)  (DapolNode::new, src/dapol/node.rs:34-36)
+__global__ __launch_bounds__(256) void k_wide_hash_leaves(size_t n, const uint32_t* C, uint32_t* H16) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t c[8], h[16];
+    ld8(c, C + i * 8);
+    blake2b_hash32(h, c);
+    st16(H16 + i * 16, h);
+}
+// level k -> k + 1: one lane per child that owns its parent (the left child of a real pair, or the real child of a padded pair):
+// the padding sibling's hash D(C_pad), then Mergeable::merge's D(C_L || C_R || H_L || H_R) (node.rs:66-77).
+__global__ __launch_bounds__(256) void k_wide_hash_level(LevelView cur, WideView wcur, WideView wnxt) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cur.n) return;
+    const bool left = (cur.idx[i] & 1ull) == 0, padded = cur.has_pad[i] != 0;
+    if (!padded && !left) return;                          // the right child of a real pair: its left neighbour does the parent
+    uint32_t cA[8], cB[8], hA[16], hB[16], hp[16];
+    ld8(cA, cur.C + i * 8);
+    ld16(hA, wcur.H + i * 16);
+    if (padded) {
+        ld8(cB, cur.padC + i * 8);
+        blake2b_hash32(hB, cB);
+        st16(wcur.padH + i * 16, hB);
+    } else {
+        ld8(cB, cur.C + (i + 1) * 8);
+        ld16(hB, wcur.H + (i + 1) * 16);
+    }
+    if (left) blake2b_hash192(hp, cA, cB, hA, hB);
+    else blake2b_hash192(hp, cB, cA, hB, hA);
+    st16(wnxt.H + (size_t)cur.parent[i] * 16, hp);
+}
+// the 64-byte hashes of the siblings along b paths (k_tree_path_walk's walk; pos = the leaves' positions, left untouched)
+__global__ __launch_bounds__(64) void k_wide_path_walk(size_t b, const uint32_t* pos, const LevelView* views, const WideView* wviews, int height, int n_upper,
+                                                      int leaf_first, uint32_t* outH16) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= b) return;
+    uint32_t p = pos[t];
+    if (p == 0xffffffffu) return;
+    for (int level = 0; level < height; level++) {
+        const LevelView lv = views[level];
+        const WideView wv = wviews[level];
+        const size_t slot = t * (size_t)(height + n_upper) + (size_t)(leaf_first ? level : n_upper + height - 1 - level);
+        uint32_t h[16];
+        if (lv.has_pad[p]) ld16(h, wv.padH + (size_t)p * 16);
+        else ld16(h, wv.H + ((lv.idx[p] & 1ull) ? (size_t)p - 1 : (size_t)p + 1) * 16);
+        st16(outH16 + slot * 16, h);
+        p = lv.parent[p];
+    }
+}
+
 }  // namespace dapol

@@ -105,7 +105,10 @@ __global__ __launch_bounds__(64) void k_rp_round_prep_gs(RangeArgs A, int round)
 // first: the accumulators start at the identity; else they are loaded from acc (SoA: word k of lane l at acc[k * Ltot + l]).
 // SLICES (calls of a few thousand proofs, whose B * nwin lanes cannot fill the chip): gridDim.y slices of a list, slice s sweeping
 // rows s * slice_rows + q0 ... into its own accumulators (lane s * L + l of Ltot = L * gridDim.y); k_rp_gs_sum_slices adds them up.
-__global__ __launch_bounds__(64, 4) void k_rp_msm_gs(RangeArgs A, TableView tbl, int round, int side, int q0, int nq, int first, int32_t* __restrict__ accs, int slice_rows) {
+#ifndef DAPOL_GS_OCC
+#define DAPOL_GS_OCC 4
+#endif
+__global__ __launch_bounds__(64, DAPOL_GS_OCC) void k_rp_msm_gs(RangeArgs A, TableView tbl, int round, int side, int q0, int nq, int first, int32_t* __restrict__ accs, int slice_rows) {
     const size_t L = A.B * (size_t)A.nwin, Ltot = L * gridDim.y;
     const size_t lane = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (lane >= L) return;
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(64) void k_rp_mat_prep_gs(RangeArgs A) {
 // One class, one half (0: the generators' own rows, digits of window w; 1: their high-half rows, digits of window w + LW).
 // accs: this class's slot, SoA over LM = cb * LW lanes (lane = w * cb + p).
 // gridDim.y classes per launch (cls + blockIdx.y, each in its own slot) when the lanes of one class cannot fill the chip.
-__global__ __launch_bounds__(64, 4) void k_rp_mat_gs(RangeArgs A, TableView tbl, int side, int cls, int hi, int LW, int32_t* __restrict__ accs) {
+__global__ __launch_bounds__(64, DAPOL_GS_OCC) void k_rp_mat_gs(RangeArgs A, TableView tbl, int side, int cls, int hi, int LW, int32_t* __restrict__ accs) {
     const size_t LM = A.B * (size_t)LW, L = A.B * (size_t)A.nwin;
     const size_t lane = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (lane >= LM) return;

@@ -1101,31 +1101,36 @@ __global__ void k_rvb_verdicts(VerifyArgs V) {
 
 // MerkleProof::verify for single leaves with DapolProofNode::merge (src/proof/node.rs:56-69, src/proof/mod.rs:41-47):
 // re-merge the leaf with its siblings (root side first in `pC/pH`) and compare with the root.  One lane per entity.
+// HW = words of a node hash (8: the 32-byte digests; 16: Blake2b-512 -- hash arrays then hold 16 words per node).
+template <int HW>
+__device__ __forceinline__ void ldhw(uint32_t* w, const uint32_t* p) { ld8(w, p); if (HW == 16) ld8(w + 8, p + 8); }
+template <int HW>
 __global__ __launch_bounds__(64) void k_verify_paths(int dg, size_t b, int height, const uint64_t* leaf_idx, const uint32_t* leafC, const uint32_t* leafH,
                                                     const uint32_t* pC, const uint32_t* pH, const uint32_t* rootC, const uint32_t* rootH,
                                                     int leaf_first, uint8_t* ok) {
     size_t e = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (e >= b) return;
-    uint32_t c[8], h[8], sc_[8], sh[8], hn[8];
+    uint32_t c[8], h[HW], sc_[8], sh[HW], hn[HW];
     ld8(c, leafC + e * 8);
-    ld8(h, leafH + e * 8);
+    ldhw<HW>(h, leafH + e * HW);
     ge_p3 acc, sp;
     bool good = ge_decompress(acc, c);
     uint64_t idx = leaf_idx[e];
     for (int k = 0; k < height; k++) {
         size_t slot = e * (size_t)height + (size_t)(leaf_first ? k : height - 1 - k);
         ld8(sc_, pC + slot * 8);
-        ld8(sh, pH + slot * 8);
+        ldhw<HW>(sh, pH + slot * HW);
         good &= ge_decompress(sp, sc_);                      // deserialisation rejects non-canonical points (proof/node.rs:88-94)
-        if ((idx >> k) & 1) node_hash128(dg, hn, sc_, c, sh, h);
-        else node_hash128(dg, hn, c, sc_, h, sh);
+        if ((idx >> k) & 1) node_hash_parent_w<HW>(dg, hn, sc_, c, sh, h);
+        else node_hash_parent_w<HW>(dg, hn, c, sc_, h, sh);
         ge_p3 t;
         ge_add(t, acc, sp);
         acc = t;
         ge_compress(c, acc);
-        for (int i = 0; i < 8; i++) h[i] = hn[i];
+        for (int i = 0; i < HW; i++) h[i] = hn[i];
     }
-    for (int i = 0; i < 8; i++) good &= (c[i] == rootC[i]) & (h[i] == rootH[i]);
+    for (int i = 0; i < 8; i++) good &= (c[i] == rootC[i]);
+    for (int i = 0; i < HW; i++) good &= (h[i] == rootH[i]);
     ok[e] = good ? 1 : 0;
 }
 // commitments of one sub-proof from the path (pad parties: commit(0, 1) = B_blinding, src/range/padding.rs:176-180)
@@ -1133,15 +1138,16 @@ __global__ __launch_bounds__(64) void k_verify_paths(int dg, size_t b, int heigh
 // version above is a chain of `height` decompressions, additions and encodings -- 4.9 ms for one height-32 path.  Here lane k
 // decompresses sibling k, an inclusive prefix sum over the lanes (shuffles) gives every ancestor's commitment at once, each lane
 // encodes its own, and only the hash chain stays serial (every lane walks it in step; its inputs come by shuffle).
+template <int HW>
 __global__ __launch_bounds__(64) void k_verify_paths_wave(int dg, size_t b, int height, const uint64_t* leaf_idx, const uint32_t* leafC,
                                                          const uint32_t* leafH, const uint32_t* pC, const uint32_t* pH, const uint32_t* rootC,
                                                          const uint32_t* rootH, int leaf_first, uint8_t* ok) {
     const size_t e = blockIdx.x;
     const int l = threadIdx.x;
     if (e >= b) return;
-    uint32_t c[8], h[8], sc_[8] = {0}, sh[8] = {0}, cn[8];
+    uint32_t c[8], h[HW], sc_[8] = {0}, sh[HW] = {0}, cn[8];
     ld8(c, leafC + e * 8);
-    ld8(h, leafH + e * 8);
+    ldhw<HW>(h, leafH + e * HW);
     const bool live = l < height;
     ge_p3 acc, lf;
     bool good = ge_decompress(lf, c);
@@ -1149,7 +1155,7 @@ __global__ __launch_bounds__(64) void k_verify_paths_wave(int dg, size_t b, int 
     if (live) {
         size_t slot = e * (size_t)height + (size_t)(leaf_first ? l : height - 1 - l);
         ld8(sc_, pC + slot * 8);
-        ld8(sh, pH + slot * 8);
+        ldhw<HW>(sh, pH + slot * HW);
         good &= ge_decompress(acc, sc_);                     // deserialisation rejects non-canonical points (proof/node.rs:88-94)
     }
     {
@@ -1171,17 +1177,19 @@ __global__ __launch_bounds__(64) void k_verify_paths_wave(int dg, size_t b, int 
     ge_compress(cn, acc);
     const uint64_t idx = leaf_idx[e];
     for (int k = 0; k < height; k++) {
-        uint32_t sk[8], shk[8], nx[8], hn[8];
+        uint32_t sk[8], shk[HW], nx[8], hn[HW];
         for (int i = 0; i < 8; i++) {
             sk[i] = (uint32_t)__shfl((int)sc_[i], k, 64);
-            shk[i] = (uint32_t)__shfl((int)sh[i], k, 64);
             nx[i] = (uint32_t)__shfl((int)cn[i], k, 64);
         }
-        if ((idx >> k) & 1) node_hash128(dg, hn, sk, c, shk, h);
-        else node_hash128(dg, hn, c, sk, h, shk);
-        for (int i = 0; i < 8; i++) { c[i] = nx[i]; h[i] = hn[i]; }
+        for (int i = 0; i < HW; i++) shk[i] = (uint32_t)__shfl((int)sh[i], k, 64);
+        if ((idx >> k) & 1) node_hash_parent_w<HW>(dg, hn, sk, c, shk, h);
+        else node_hash_parent_w<HW>(dg, hn, c, sk, h, shk);
+        for (int i = 0; i < 8; i++) c[i] = nx[i];
+        for (int i = 0; i < HW; i++) h[i] = hn[i];
     }
-    for (int i = 0; i < 8; i++) good &= (c[i] == rootC[i]) & (h[i] == rootH[i]);
+    for (int i = 0; i < 8; i++) good &= (c[i] == rootC[i]);
+    for (int i = 0; i < HW; i++) good &= (h[i] == rootH[i]);
     const bool all_good = __all(good ? 1 : 0) != 0;
     if (l == 0) ok[e] = all_good ? 1 : 0;
 }

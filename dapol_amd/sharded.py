@@ -10,6 +10,8 @@ broadcast) and calls them.  The torch.distributed all-gather below remains for h
 
 Indices stay global everywhere, so padding-node seeds and nonce stream ids -- and therefore every byte -- equal
 the single-GPU result (tests/test_sharded.py emulates G shards on one device and checks exactly that)."""
+import time
+
 import numpy as np
 
 from . import capi
@@ -60,7 +62,7 @@ def top_levels(ctx, records, rank, merge=None):
     return (C[0].tobytes(), H[0].tobytes(), int(v[0]), r[0].tobytes()), upper
 
 
-def agreement_group(dist, comm_device):
+def agreement_group(dist, comm_device, torch=None):
     """The process group the ranks AGREE on (ok flags of the library's collectives) -> (group, device of its tensors).  It must not
     ride the transport that may have just failed: when the default group is RCCL (comm_device "cuda") this is a side group over
     gloo / TCP with CPU tensors; a default group that already is gloo serves as it is (None).  Collective: every rank calls it at
@@ -68,10 +70,20 @@ def agreement_group(dist, comm_device):
     device tensors -- weaker (torch's own RCCL communicator, not the library's, carries it) but never a rank deciding alone."""
     if comm_device != "cuda":
         return None, "cpu"
+    group = None
     try:
-        return dist.new_group(backend="gloo"), "cpu"
+        group = dist.new_group(backend="gloo")
     except Exception:
-        return None, comm_device
+        group = None
+    # new_group can fail on ONE rank only; ranks that then agreed over different groups would not be agreeing at all.  The outcome is
+    # itself agreed over the default group: the side group is used only if every rank has it.
+    if torch is None:
+        import torch
+    flag = torch.tensor([1 if group is not None else 0], dtype=torch.int64, device=comm_device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 1:
+        return group, "cpu"
+    return None, comm_device
 
 
 def all_agree(dist, torch, group, ok, device="cpu"):
@@ -144,7 +156,7 @@ class ShardTransport:
         import os
         if (self.world == 1 and not even_alone) or self.comm_device != "cuda" or os.environ.get("DAPOL_EXCHANGE", "").lower() == "torch":
             return
-        self.group, self.group_device = agreement_group(self.dist, self.comm_device)
+        self.group, self.group_device = agreement_group(self.dist, self.comm_device, self.torch)
         self.comm, self.comm_ranks, self.comm_error = create_library_comm(self.ctx, self.rank, self.world, self.dist, self.torch, self.comm_device,
                                                                           timeout_s, agree=self.agree)
         if self.comm is not None:
@@ -170,9 +182,13 @@ class ShardTransport:
         res, err = None, None
         try:
             res = call()
-        except capi.DapolError as e:
-            err = e
-        if self.agree(err is None):
+        except BaseException as e:      # ANY failure on this rank (a ctypes / numpy error, an interrupt) must reach the agreement: the
+            err = e                     # peers are about to wait in it, and would sit there until gloo's own timeout
+        agreed = self.agree(err is None)
+        if err is not None and not isinstance(err, capi.DapolError):
+            self.drop_comm(err)         # the peers have just learnt that this rank failed and drop theirs; this rank does not go on
+            raise err
+        if agreed:
             return True, res
         self.drop_comm(err)
         return False, None
@@ -225,6 +241,7 @@ class ShardedProver:
         self.w = capi.Workload(ctx, height, leaf_idx, v, r32, shard_bits=self.shard_bits) if len(self.idx) else None
         self.upper = None
         self.root = None
+        self.phases = None                        # host-clock milliseconds of the last step's phases + the library's collective timings
         self.transport = ShardTransport(ctx, rank, world, dist, torch, comm_device)
         self.transport.create_comm()
 
@@ -242,17 +259,36 @@ class ShardedProver:
             return "dapol_shard_exchange (ncclAllGather inside libdapol_hip.so)"
         return t.path.replace("torch.distributed (", "torch.distributed all_gather (")
 
+    PHASE_KEYS = ("build_ms", "exchange_ms", "prove_ms", "reduce_ms", "step_ms", "allgather_us", "top_levels_us", "allreduce_us")
+
     def step(self, pad_seed, nonce_seed, n_bits=64):
+        """One step.  Leaves in self.phases what each part took on THIS rank's host clock (every part ends with the host waiting
+        for the device, so these are device-inclusive) and, when the library's communicator carried the collectives, their device
+        times from HIP events inside the library (dapol_comm_timing_get: the all-gather's time includes the wait for the slowest
+        rank; the smallest value over the ranks is the collective's own latency)."""
+        t0 = time.perf_counter()
         if self.w is None:
             C, H, r = self.ctx.padding_nodes(pad_seed, [self.height - self.shard_bits], [self.rank])
             root, st = (C[0].tobytes(), H[0].tobytes(), 0, r[0].tobytes()), capi.WorkloadStats()
+            t1 = time.perf_counter()
             self.root, self.upper = self.transport.exchange(root)
+            t2 = t3 = time.perf_counter()
         else:
             root, st = self.w.build(pad_seed)
+            t1 = time.perf_counter()
             self.root, self.upper = self.transport.exchange(root)
+            t2 = time.perf_counter()
             st = self.w.prove(nonce_seed, n_bits, upper=self.upper, stats=st)
+            t3 = time.perf_counter()
         # final reduce of the aggregated proof transcript checksum (wrapping 64-bit sum)
         st.checksum = self.transport.reduce_u64(st.checksum, "sum")
+        t4 = time.perf_counter()
+        ph = {"build_ms": 1e3 * (t1 - t0), "exchange_ms": 1e3 * (t2 - t1), "prove_ms": 1e3 * (t3 - t2), "reduce_ms": 1e3 * (t4 - t3),
+              "step_ms": 1e3 * (t4 - t0), "allgather_us": float("nan"), "top_levels_us": float("nan"), "allreduce_us": float("nan")}
+        if self.transport.comm is not None:
+            tm = self.transport.comm.timing()
+            ph.update(allgather_us=tm.last_allgather_us, top_levels_us=tm.last_top_levels_us, allreduce_us=tm.last_allreduce_us)
+        self.phases = ph
         return st
 
     def sample_paths(self, leaf_ids, pad_seed, with_nodes=False):

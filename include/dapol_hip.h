@@ -62,14 +62,25 @@ typedef struct dapol_ctx dapol_ctx;
 typedef struct dapol_tree dapol_tree;
 
 enum { DAPOL_POLICY_PADDING = 0, DAPOL_POLICY_SPLITTING = 1 };  /* RangeProofPadding / RangeProofSplitting */
-enum { DAPOL_DIGEST_BLAKE3 = 0, DAPOL_DIGEST_BLAKE2S = 1 };     /* D = blake3::Hasher (benches/dapol.rs:38) or blake2::Blake2s (src/dapol/tests.rs:21) */
+/* D = blake3::Hasher (benches/dapol.rs:38), blake2::Blake2s (src/dapol/tests.rs:21), or blake2::Blake2b (src/tests.rs:100-101: the
+ * reference's integration test also runs Dapol<Blake2b, R> through new_blank + build + prove + serialize + verify; only Dapol::new
+ * rejects a digest that is not 32 bytes, src/dapol/mod.rs:101-103).  With DAPOL_DIGEST_BLAKE2B every node hash is 64 bytes: every
+ * `H` buffer of this header -- whatever its parameter is called (H32, H_out32, path_H32 ...) -- then holds dapol_ctx_digest_bytes()
+ * = 64 bytes per node instead of 32.  The Blake2b context serves the new_blank + build path: dapol_tree_build (enforce_sparsity = 0),
+ * dapol_tree_update, roots / levels / paths, dapol_prove_entities, dapol_prove_batch, the wire format (*_d forms below),
+ * dapol_verify_entities / dapol_verify_batch, dapol_merge_batch, dapol_padding_nodes, dapol_commit_hash_batch.  What the reference
+ * refuses for such a digest is refused here with DAPOL_ERR_INVALID_DIGEST_SIZE: Dapol::new (dapol_tree_build with enforce_sparsity,
+ * dapol_build_leaf_nodes); so are the paths that exist only for the benchmark and for multi-GPU sharding (workloads, shard trees,
+ * the communicator, node records), whose records carry 32-byte hashes. */
+enum { DAPOL_DIGEST_BLAKE3 = 0, DAPOL_DIGEST_BLAKE2S = 1, DAPOL_DIGEST_BLAKE2B = 2 };
 
 /* Replaces the per-call PedersenGens::default() (src/dapol/node.rs:31, src/range/mod.rs:49,65,84,103) and
  * BulletproofGens::new(64, m) (src/range/mod.rs:50,66,85,104): generators and their window tables are derived
  * ONCE, on the GPU, for up to max_parties parties of 64 bits.  max_parties must be a power of two <= 1024.
  * digest_id: the node hash D of Dapol<D, R> used by every tree / merge / verify call of this context; anything but the
- * two 32-byte digests above -> DAPOL_ERR_INVALID_DIGEST_SIZE (DapolError::InvalidDigestSize, src/dapol/mod.rs:101-103). */
+ * three digests above -> DAPOL_ERR_INVALID_DIGEST_SIZE. */
 int32_t dapol_ctx_create(int32_t device, int32_t max_parties, int32_t digest_id, dapol_ctx** out);
+int32_t dapol_ctx_digest_bytes(dapol_ctx* ctx, int32_t* bytes);          /* D::output_size(): 32 or 64 -- the size of every node hash of this context */
 /* Settings of a context.  Every field: 0 = the library's own choice (what a plain dapol_ctx_create gives).  The first three are
  * fixed at creation (dapol_ctx_create_opts), the others may be changed at any time between calls (dapol_ctx_set_options).
  * None of them changes a byte of any output (tests/test_gpu_parity.py::test_every_proving_strategy_gives_the_same_bytes); they
@@ -253,6 +264,9 @@ int32_t dapol_wire_config_set(const dapol_wire_config* cfg);
  * canonical encoding of a point."). */
 int32_t dapol_proof_nodes_serialize(size_t n, const uint8_t* C32, const uint8_t* H32, uint8_t* wire_out);
 int32_t dapol_proof_nodes_deserialize(dapol_ctx* ctx, size_t n, const uint8_t* wire, size_t wire_len, uint8_t* C32_out, uint8_t* H32_out);
+/* ... for a digest of hash_bytes = D::output_size() bytes (32 or 64): wire = (C32 || hash) per node, H holds hash_bytes per node.
+ * (The context-taking deserialisers read the width from their context.) */
+int32_t dapol_proof_nodes_serialize_d(int32_t hash_bytes, size_t n, const uint8_t* C32, const uint8_t* H, uint8_t* wire_out);
 
 /* DapolProof::serialize / deserialize (src/proof/mod.rs:68-85): R::serialize() || MerkleProof::serialize(), the latter
  * restated as batch_num || sibling_num || tree_height || path_1..k || (C || hash)_1..S (smtree 0.1.2, from memory: see
@@ -266,6 +280,10 @@ size_t dapol_proof_wire_size(int32_t height, size_t k, size_t n_siblings, int32_
 int32_t dapol_proof_serialize(int32_t height, size_t k, const uint64_t* leaf_idx, size_t n_siblings, const uint8_t* sib_C32,
                               const uint8_t* sib_H32, int32_t policy, int32_t aggregation_factor, int32_t n_bits,
                               const uint8_t* range_blob, uint8_t* wire_out);
+size_t dapol_proof_wire_size_d(int32_t hash_bytes, int32_t height, size_t k, size_t n_siblings, int32_t policy, int32_t aggregation_factor, int32_t n_bits);
+int32_t dapol_proof_serialize_d(int32_t hash_bytes, int32_t height, size_t k, const uint64_t* leaf_idx, size_t n_siblings, const uint8_t* sib_C32,
+                                const uint8_t* sib_H, int32_t policy, int32_t aggregation_factor, int32_t n_bits, const uint8_t* range_blob,
+                                uint8_t* wire_out);
 int32_t dapol_proof_deserialize(dapol_ctx* ctx, int32_t policy, int32_t n_bits, const uint8_t* wire, size_t wire_len, int32_t* height,
                                 size_t* k, size_t* n_siblings, int32_t* aggregation_factor, size_t* range_blob_len,
                                 uint64_t* leaf_idx_out, uint8_t* sib_C32_out, uint8_t* sib_H32_out, uint8_t* range_blob_out,
@@ -356,6 +374,17 @@ int32_t dapol_shard_exchange(dapol_comm* comm, const uint8_t sub_C[32], const ui
 int32_t dapol_shard_top_levels(dapol_ctx* ctx, int32_t world, int32_t rank, const uint8_t* records, uint8_t root_C[32], uint8_t root_H[32],
                                uint64_t* root_v, uint8_t root_r[32], uint8_t* up_C32, uint8_t* up_H32, uint64_t* up_v, uint8_t* up_r32);
 int32_t dapol_comm_allreduce_u64(dapol_comm* comm, int32_t op, uint64_t* inout, size_t n);
+/* What the two collectives cost, measured inside the calls above (a multi-GPU bench line carries them per step, so that a scaling
+ * curve can be read from its own records): DEVICE time between HIP events on the context's stream around ncclAllGather -- which
+ * includes waiting for the slowest rank to arrive -- around the replicated merge of the top levels with its copies back, and
+ * around ncclAllReduce; HOST wall time of each whole call.  Microseconds; last_* = the most recent call, sum_* since creation or
+ * the last reset (reset != 0 clears the counters after copying them out). */
+typedef struct {
+    uint64_t exchanges, reduces;
+    double last_allgather_us, last_top_levels_us, last_exchange_host_us, last_allreduce_us, last_reduce_host_us;
+    double sum_allgather_us, sum_top_levels_us, sum_exchange_host_us, sum_allreduce_us, sum_reduce_host_us;
+} dapol_comm_timing;
+int32_t dapol_comm_timing_get(dapol_comm* comm, dapol_comm_timing* out, int32_t reset);
 
 /* generate_proof_batch (src/dapol/mod.rs:172-190) on a SHARDED tree.  The siblings of a batch lie in several shards and in
  * the replicated top levels, so the proof is assembled from node RECORDS (C, H, v, r):

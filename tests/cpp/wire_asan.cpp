@@ -19,6 +19,7 @@ using namespace dapol;
 static thread_local std::string g_last_error;
 static int32_t fail(int32_t code, const char* msg) { g_last_error = msg; return code; }
 struct dapol_ctx { int unused; };
+static size_t ctx_hash_bytes(const dapol_ctx* c) { return c->unused == 64 ? 64 : 32; }     // (64: a Blake2b context's 64-byte node hashes)
 
 #define DAPOL_WIRE_HOST_ONLY 1
 #include "wire_scope.inc"

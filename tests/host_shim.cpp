@@ -124,6 +124,19 @@ void t_blake3_128(const uint8_t* in, uint8_t* out) {
     blake3_hash128(o, w, w + 8, w + 16, w + 24);
     st(out, o, 8);
 }
+// wide node hashes (Blake2b-512): leaf = D(C32), parent = D(C_L || C_R || H_L64 || H_R64)
+void t_blake2b_32(const uint8_t* in, uint8_t* out64) {
+    uint32_t w[8], o[16];
+    ld(w, in, 8);
+    node_hash_leaf_w<16>(DG_BLAKE2B, o, w);
+    st(out64, o, 16);
+}
+void t_blake2b_192(const uint8_t* in, uint8_t* out64) {
+    uint32_t w[48], o[16];
+    ld(w, in, 48);
+    node_hash_parent_w<16>(DG_BLAKE2B, o, w, w + 8, w + 16, w + 32);
+    st(out64, o, 16);
+}
 void t_seed_wide(const uint8_t* seed, uint32_t dom, uint64_t a, uint64_t b, uint8_t* out64) {
     uint32_t s[8], o[16];
     ld(s, seed, 8);

@@ -47,8 +47,8 @@ def test_error_strings_and_no_device_behaviour(hip_lib):
     h = ctypes.c_void_p()
     rc = lib.dapol_ctx_create(0, 3, 0, ctypes.byref(h))
     assert rc == 8                                   # max_parties must be a power of two
-    rc = lib.dapol_ctx_create(0, 32, 2, ctypes.byref(h))
-    assert rc == 3                                   # only the 32-byte digests BLAKE3 / Blake2s (DapolError::InvalidDigestSize)
+    rc = lib.dapol_ctx_create(0, 32, 3, ctypes.byref(h))
+    assert rc == 3                                   # BLAKE3 / Blake2s / Blake2b (0, 1, 2) and nothing else (DapolError::InvalidDigestSize)
     import torch
     if not torch.cuda.is_available():
         rc = lib.dapol_ctx_create(0, 32, 0, ctypes.byref(h))

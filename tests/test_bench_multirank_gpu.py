@@ -49,8 +49,16 @@ def test_bench_gpus_2_without_a_launcher_spawns_its_ranks(hip_lib):
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1                                           # ONE JSON line on stdout, everything else went to stderr
-    line = json.loads(lines[0])
+    # the headline right after the timed region, then the complete line (the driver takes the last); everything else went to stderr
+    assert len(lines) == 2 and json.loads(lines[0])["complete"] is False and json.loads(lines[0])["cpu_baseline"] is None
+    assert json.loads(lines[0])["value"] == json.loads(lines[1])["value"]
+    line = json.loads(lines[1])
+    assert line["complete"] is True
+    mg = line["multi_gpu"]                                           # an N > 1 line explains itself: per-rank phases, the two collectives
+    assert mg["ranks"] == 2 and mg["steps"] == 2 and len(mg["per_rank_ms"]["step"]) == 2
+    assert mg["step_ms"]["max"] >= mg["step_ms"]["min"] > 0 and mg["prove_ms"]["imbalance"] >= 0
+    assert mg["exchange"]["host_ms"]["max_over_ranks_mean_over_steps"] > 0 and mg["reduce"]["host_ms"]["max_over_ranks_mean_over_steps"] > 0
+    assert mg["exchange"]["allgather_device_us"] is None             # (gloo here: the library's communicator, whose HIP events these are, needs RCCL)
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["steps"] == 2
     assert line["config"]["entities_total"] == 1024 and line["config"]["entities_per_gpu"] == 512
     assert "strong scaling" in line["config"]["workload"] and "gloo" in line["config"]["exchange"]

@@ -128,7 +128,12 @@ def test_hashes_and_transcript(host_shim, pyref):
         assert o.raw == R.blake3(m[:32])
         host_shim.t_blake3_128(m, o)
         assert o.raw == R.blake3(m)
-        o = buf(64)
+        o = buf(64)                                                  # the 64-byte node hashes of Dapol<blake2::Blake2b, _> (src/tests.rs:100-101)
+        w = m + m[:64]
+        host_shim.t_blake2b_32(w[:32], o)
+        assert o.raw == hashlib.blake2b(w[:32]).digest()
+        host_shim.t_blake2b_192(w, o)
+        assert o.raw == hashlib.blake2b(w).digest()
         a, b = rnd.randrange(2**64), rnd.randrange(2**64)
         host_shim.t_seed_wide(m[:32], it, ctypes.c_uint64(a), ctypes.c_uint64(b), o)
         assert o.raw == R.seed_wide(m[:32], it, a, b)

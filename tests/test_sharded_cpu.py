@@ -170,3 +170,134 @@ def test_one_rank_failing_makes_every_rank_fall_back_together():
     assert [r for r, _ in res] == [0, 1]
     for _, out in res:
         assert out and all(out.values()), out
+
+
+# ------------------------------------------------------------------- bench.py's N > 1 records: --preflight and the `multi_gpu` object
+class _TimedFakeComm(_FakeLibraryComm):
+    """... with the timing accessor of dapol_comm (dapol_comm_timing_get): host-clock stand-ins for the library's HIP events."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        from dapol_amd import capi
+        self.tm = capi.CommTiming()
+
+    def exchange(self, root):
+        import time
+        t0 = time.perf_counter()
+        out = super().exchange(root)
+        us = 1e6 * (time.perf_counter() - t0)
+        self.tm.exchanges += 1
+        self.tm.last_allgather_us, self.tm.last_top_levels_us = 0.6 * us, 0.4 * us
+        self.tm.sum_allgather_us += 0.6 * us
+        self.tm.sum_top_levels_us += 0.4 * us
+        self.tm.sum_exchange_host_us += us
+        return out
+
+    def allreduce(self, words, op=None):
+        import time
+        t0 = time.perf_counter()
+        out = super().allreduce(words, op)
+        us = 1e6 * (time.perf_counter() - t0)
+        self.tm.reduces += 1
+        self.tm.last_allreduce_us = us
+        self.tm.sum_allreduce_us += us
+        self.tm.sum_reduce_host_us += us
+        return out
+
+    def timing(self, reset=False):
+        return self.tm
+
+
+def _bench_records_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch
+    import torch.distributed as dist
+    import pyref as R
+    import bench
+    from dapol_amd import capi, sharded
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    H, seed, bits = 5, bytes(range(32)), world.bit_length() - 1
+    leaves_all = [(i, R.node_new(3 + i, 1000 + i)) for i in (1, 6, 9, 13, 18, 29)]        # every quarter of the index space holds a leaf
+    full = R.Tree(H, leaves_all, seed)
+    node = full.levels[H - bits][rank]                       # the subtree root dapol_tree_build_shard would return on this rank
+    sub_root = (node.C, node.H, node.v, R.scalar_bytes(node.r))
+    want_root = (full.root.C, full.root.H, full.root.v, R.scalar_bytes(full.root.r))
+    merge = _oracle_merge(R)
+    out = {}
+    # ---- --preflight's collective half, through the library-communicator path (stand-in) and through torch.distributed alone
+    for name, with_lib in (("library", True), ("torch", False)):
+        tr = sharded.ShardTransport(None, rank, world, dist, torch, comm_device="cpu", merge=merge)
+        if with_lib:
+            tr.comm, tr.comm_ranks = _TimedFakeComm(dist, torch, capi, sharded, rank, world, merge), world
+        checks, res, groot, ok = bench.preflight_collectives(tr, sub_root, rank, world, dist, torch, "cpu", 10, None, with_lib, merge=merge)
+        good = ok and all(checks.values()) and groot == want_root
+        good &= res["exchange_host"]["iters"] == 10 and res["reduce_host"]["median_us"] > 0 and res["exchange_host_torch"]["iters"] == 2
+        good &= ("library_device_us" in res) == with_lib
+        if with_lib:
+            good &= res["library_device_us"]["exchanges"] == 10 and res["library_device_us"]["reduces"] == 10 and tr.agreements == 20
+        out["preflight " + name] = bool(good)
+    # ---- a preflight in which ONE rank's check fails is not ok on ANY rank
+    tr = sharded.ShardTransport(None, rank, world, dist, torch, comm_device="cpu", merge=merge)
+    _, _, _, ok = bench.preflight_collectives(tr, sub_root, rank, world, dist, torch, "cpu", 2, None, False, merge=merge, local_ok=(rank != world - 1))
+    out["one rank failing fails the preflight everywhere"] = not ok
+    # ---- the timed loop's records: per-step phases of every rank gathered to everybody, then the `multi_gpu` object of the line
+    tr = sharded.ShardTransport(None, rank, world, dist, torch, comm_device="cpu", merge=merge)
+    tr.comm, tr.comm_ranks = _TimedFakeComm(dist, torch, capi, sharded, rank, world, merge), world
+    keys = list(sharded.ShardedProver.PHASE_KEYS) + ["tree_device_ms", "prove_device_ms"]
+    rows = []
+    for step in range(3):
+        import time
+        t0 = time.perf_counter()
+        time.sleep(0.002 * (rank + 1))                        # "build": the higher ranks are slower, so the lower ones wait in the exchange
+        t1 = time.perf_counter()
+        root, upper = tr.exchange(sub_root)
+        t2 = time.perf_counter()
+        time.sleep(0.004)                                     # "prove"
+        t3 = time.perf_counter()
+        tr.reduce_u64(rank, "sum")
+        t4 = time.perf_counter()
+        tm = tr.comm.timing()
+        rows.append([1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (t3 - t2), 1e3 * (t4 - t3), 1e3 * (t4 - t0), tm.last_allgather_us, tm.last_top_levels_us,
+                     tm.last_allreduce_us, 1e3 * (t1 - t0), 1e3 * (t3 - t2)])
+        assert root == want_root
+    per_rank = bench.gather_phase_rows(dist, torch, rows, world, "cpu")
+    mg = bench.rank_decomposition(per_rank, keys, world, "stand-in")
+    good = per_rank.shape == (world, 3, len(keys)) and mg["ranks"] == world and mg["steps"] == 3
+    good &= len(mg["per_rank_ms"]["build"]) == world and mg["per_rank_ms"]["build"][world - 1] > mg["per_rank_ms"]["build"][0]
+    good &= mg["build_ms"]["imbalance"] > 0.3                 # rank N-1 sleeps N times as long as rank 0
+    # the wait for the slowest rank shows up where it is spent: in the EXCHANGE of the fast ranks
+    good &= mg["per_rank_ms"]["exchange"][0] > mg["per_rank_ms"]["exchange"][world - 1]
+    good &= mg["exchange"]["allgather_device_us"]["max_over_ranks_mean_over_steps"] >= mg["exchange"]["allgather_device_us"]["min_over_ranks_mean_over_steps"] > 0
+    good &= mg["reduce"]["allreduce_device_us"]["max_over_ranks_and_steps"] > 0
+    out["multi_gpu object"] = bool(good)
+    # without the library's communicator the device columns are NaN and the object says None, not zero
+    nan_rows = [[1.0, 2.0, 3.0, 4.0, 10.0, float("nan"), float("nan"), float("nan"), 1.0, 3.0]]
+    mg2 = bench.rank_decomposition(bench.gather_phase_rows(dist, torch, nan_rows, world, "cpu"), keys, world, "torch.distributed all_gather (gloo)")
+    out["no library communicator -> None"] = mg2["exchange"]["allgather_device_us"] is None and mg2["exchange"]["host_ms"]["max_over_ranks_and_steps"] == 2.0
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def _run_ranks(worker, world, port):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+    return res
+
+
+def test_bench_multi_gpu_records_two_and_four_gloo_ranks():
+    """an N > 1 bench line explains itself (per-rank build / prove / step times and their imbalance, the two
+    collectives' host and device times) and `bench.py --preflight` proves the transport before a long run -- the collective half of
+    both, on 2 and on 4 gloo ranks (the GPU half: tests/test_bench_multirank_gpu.py)."""
+    for world, port in ((2, 33500), (4, 35500)):
+        res = _run_ranks(_bench_records_worker, world, port + (os.getpid() % 1500))
+        assert [r for r, _ in res] == list(range(world))
+        for _, out in res:
+            assert out and all(out.values()), (world, out)

@@ -62,6 +62,25 @@ __device__ __forceinline__ void load_entry(ge_niels& q, const int32_t* e) {
     q.xy2d.v[2] = a5.x; q.xy2d.v[3] = a5.y; q.xy2d.v[4] = a5.z; q.xy2d.v[5] = a5.w;
     q.xy2d.v[6] = a6.x; q.xy2d.v[7] = a6.y; q.xy2d.v[8] = a6.z;
 }
+// 96-byte packed entries (round 5, lever b): 3 x 255 bits in 24 words, six 16-byte loads; unpacking = per field element eight
+// funnel shifts + nine masks (one v_alignbit + one v_and per limb).  The stride is 96 B, so two entries of four straddle a 128-byte line.
+__device__ __forceinline__ void unpack255(fe& r, const uint32_t* w) {     // w[0..7]: 255 bits little-endian -> nine 29-bit limbs
+#pragma unroll
+    for (int i = 0; i < FE_NL; i++) {
+        const int bit = 29 * i, k = bit >> 5, sh = bit & 31;
+        uint32_t lo = w[k] >> sh;
+        if (sh > 3 && k + 1 < 8) lo |= w[k + 1] << (32 - sh);
+        r.v[i] = (int32_t)(lo & (i == 8 ? 0x7fffffu : 0x1fffffffu));
+    }
+}
+__device__ __forceinline__ void load_entry_packed(ge_niels& q, const int32_t* e) {
+    const v4i* p = reinterpret_cast<const v4i*>(e);
+    v4i a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3], a4 = p[4], a5 = p[5];
+    uint32_t w[24] = {(uint32_t)a0.x, (uint32_t)a0.y, (uint32_t)a0.z, (uint32_t)a0.w, (uint32_t)a1.x, (uint32_t)a1.y, (uint32_t)a1.z, (uint32_t)a1.w,
+                      (uint32_t)a2.x, (uint32_t)a2.y, (uint32_t)a2.z, (uint32_t)a2.w, (uint32_t)a3.x, (uint32_t)a3.y, (uint32_t)a3.z, (uint32_t)a3.w,
+                      (uint32_t)a4.x, (uint32_t)a4.y, (uint32_t)a4.z, (uint32_t)a4.w, (uint32_t)a5.x, (uint32_t)a5.y, (uint32_t)a5.z, (uint32_t)a5.w};
+    unpack255(q.ypx, w); unpack255(q.ymx, w + 8); unpack255(q.xy2d, w + 16);
+}
 __device__ __forceinline__ void acc_init(ge_p3& acc, int seed) {
     for (int i = 0; i < FE_NL; i++) {
         acc.X.v[i] = (seed * 7 + i) & 0xffff; acc.Y.v[i] = (seed * 11 + i) & 0xffff; acc.Z.v[i] = (seed * 13 + i) & 0xffff; acc.T.v[i] = (seed * 17 + i) & 0xffff;
@@ -110,7 +129,7 @@ __global__ __launch_bounds__(64, 4) void k_ps(int32_t* out, const int32_t* tbl, 
 // ------------------------------------------------------------------------------------------ generator-stationary
 // NACC accumulators per lane (1: occupancy 4; 2: occupancy 3).  Lane id -> accumulator(s) a * lanes + lane; digits dig[row][NACC * lanes].
 // carry != 0: accumulators are loaded from / stored to `accs` (SoA) -- the tile form.
-template <int NACC, int OCC, int DV = 0>
+template <int NACC, int OCC, int DV = 0, int PK = 0>
 __global__ __launch_bounds__(64, OCC) void k_gs(int32_t* out, int32_t* accs, const int32_t* tbl, const int32_t* dig, size_t lanes, int row0, int rows, size_t row_words,
                                                 int carry, unsigned long long* clk) {
     unsigned long long c0 = clock64(), w0 = wall_clock64();
@@ -141,7 +160,8 @@ __global__ __launch_bounds__(64, OCC) void k_gs(int32_t* out, int32_t* accs, con
             else d = dg[((size_t)g * NACC + a) * lanes];
             const int ad = d < 0 ? -d : d;
             ge_niels e;
-            load_entry(e, trow + (uint32_t)(ad * 32));
+            if constexpr (PK) load_entry_packed(e, trow + (uint32_t)(ad * 24));
+            else load_entry(e, trow + (uint32_t)(ad * 32));
             ge_madd(acc[a], acc[a], e, d < 0);
         }
     }
@@ -288,7 +308,10 @@ int main(int argc, char** argv) {
                     else hipLaunchKernelGGL((k_gs<2, 3>), dim3(blocks), dim3(64), 0, 0, out, accs, tbl, dig, lanes, row_base, list_rows, row_words, 0, d_clk);
                 } else {
                     for (int t = 0; t < list_rows; t += tile_rows) {
-                        if (dv == 2) hipLaunchKernelGGL(k_gs_mid, dim3(blocks), dim3(64), 0, 0, accs, tbl, dig + (size_t)t * lanes, lanes, row_base + t, tile_rows, row_words, d_clk);
+                        const size_t rw = dv == 4 ? row_words / 32 * 24 : row_words;       // packed: rows of 96-byte entries
+                        if (dv == 3) hipLaunchKernelGGL((k_gs<1, 5, 1>), dim3(blocks), dim3(64), 0, 0, out, accs, tbl, dig + (size_t)t * lanes, lanes, row_base + t, tile_rows, row_words, 1, d_clk);
+                        else if (dv == 4) hipLaunchKernelGGL((k_gs<1, 4, 1, 1>), dim3(blocks), dim3(64), 0, 0, out, accs, tbl, dig + (size_t)t * lanes, lanes, row_base + t, tile_rows, rw, 1, d_clk);
+                        else if (dv == 2) hipLaunchKernelGGL(k_gs_mid, dim3(blocks), dim3(64), 0, 0, accs, tbl, dig + (size_t)t * lanes, lanes, row_base + t, tile_rows, row_words, d_clk);
                         else if (dv) hipLaunchKernelGGL((k_gs<1, 4, 1>), dim3(blocks), dim3(64), 0, 0, out, accs, tbl, dig + (size_t)t * lanes, lanes, row_base + t, tile_rows, row_words, 1, d_clk);
                         else hipLaunchKernelGGL((k_gs<1, 4>), dim3(blocks), dim3(64), 0, 0, out, accs, tbl, dig + (size_t)t * lanes, lanes, row_base + t, tile_rows, row_words, 1, d_clk);
                     }
@@ -323,7 +346,9 @@ int main(int argc, char** argv) {
             if (tok.rfind("gst:", 0) == 0) {
                 size_t lanes = 0; int tile = 16; char v = 0;
                 sscanf(tok.c_str(), "gst:%zu:%d:%c", &lanes, &tile, &v);
-                run_gs(v == 'v' ? "gstv" : v == 'm' ? "gstm" : "gst", 1, lanes, tile, v == 'v' ? 1 : v == 'm' ? 2 : 0);
+                // w = as v with five wavefronts per SIMD (96 VGPRs); p = as v over 96-byte packed entries
+                run_gs(v == 'v' ? "gstv" : v == 'm' ? "gstm" : v == 'w' ? "gstw" : v == 'p' ? "gstp" : "gst", 1, lanes, tile,
+                       v == 'v' ? 1 : v == 'm' ? 2 : v == 'w' ? 3 : v == 'p' ? 4 : 0);
             }
         }
     }
