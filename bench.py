@@ -388,8 +388,9 @@ def mode_prove(args):
     n_total, n_per_gpu, lg_total, scaling = plan_workload(args, world)
     height, n_bits = args.height, args.n_bits
     idx, v, r = synth_inputs(n_total, height, rank * n_per_gpu, n_per_gpu, n_bits)
-    ctx = capi.Context(local_rank, _np2(height))
-    log("context ready (generators + window tables)")
+    opts = capi.Options(profile=capi.PROFILE_HOST) if args.profile == "host" else None
+    ctx = capi.Context(local_rank, _np2(height), options=opts)
+    log("context ready (generators + window tables; profile %s, %d-bit windows)" % (args.profile, ctx.get_options().window_bits))
     comm_device = "cuda" if backend == "nccl" else "cpu"
     prover = ShardedProver(ctx, height, idx, v, r, rank, world, dist, torch, comm_device=comm_device)
 
@@ -455,6 +456,7 @@ def mode_prove(args):
                 (s + 1, steps, time.perf_counter() - t0, stats.tree_ms, stats.prove_ms))
     sync()
     elapsed = time.perf_counter() - t0
+    free_b, total_b = torch.cuda.mem_get_info()            # what the context, the tree and the prover's scratch hold after the timed steps
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=comm_device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -555,7 +557,9 @@ def mode_prove(args):
                        "entities_total": n_total, "entities_per_gpu": n_per_gpu, "proof_bytes": int(stats.proof_bytes // max(1, stats.proofs)),
                        "sharding": "none" if world == 1 else "top-level subtrees, all-gather of %d subtree roots" % world,
                        "exchange": exchange_path, "rccl_ranks_in_library_communicator": comm_ranks,
-                       "exchange_fallback_reason": comm_error},
+                       "exchange_fallback_reason": comm_error,
+                       "profile": args.profile, "window_bits": int(ctx.get_options().window_bits), "high_half_rows": bool(ctx.get_options().high_half_rows > 0),
+                       "device_memory_in_use_gb": (total_b - free_b) / 1e9},
             "phases_ms": {"tree_build": acc["tree_ms"] / steps, "prove": acc["prove_ms"] / steps},
             "multi_gpu": multi_gpu,
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "secondary": secondary,
@@ -1243,6 +1247,9 @@ def main():
     ap.add_argument("--verify-proofs", type=int, default=1024)
     ap.add_argument("--verify-parties", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile", choices=("bench", "host"), default="bench",
+                    help="dapol_options.profile: bench = the library's throughput defaults (17-bit windows + high-half rows, two-round chunks: ~175 GB "
+                         "in use); host = sized for an embedder that shares the GPU (16-bit windows, no high-half rows, one-round chunks)")
     ap.add_argument("--preflight", action="store_true",
                     help="< 30 s, no proving: the library's RCCL communicator up with ncclCommCount == N, the step's two collectives timed, every rank's root equal, rocm-smi --showtopo to stderr")
     ap.add_argument("--preflight-iters", type=int, default=100)

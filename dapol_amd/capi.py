@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DAPOL_HIP_LIB", os.path.join(_HERE, "libdapol_hip.so"))   # override only for A/B builds
 
 POLICY_PADDING, POLICY_SPLITTING = 0, 1
+PROFILE_BENCH, PROFILE_HOST = 0, 1          # dapol_options.profile: memory defaults tuned for the bench / for an embedder that shares the GPU
 DIGEST_BLAKE3, DIGEST_BLAKE2S, DIGEST_BLAKE2B = 0, 1, 2      # Blake2b: 64-byte node hashes (every H array is then (.., 64))
 
 
@@ -39,7 +40,7 @@ class Options(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_int32), ("window_bits", ctypes.c_int32), ("table_gb", ctypes.c_double), ("high_half_rows", ctypes.c_int32),
                 ("generator_stationary", ctypes.c_int32), ("gs_tile_rows", ctypes.c_int32), ("streams", ctypes.c_int32), ("chunk_proofs", ctypes.c_int64),
                 ("scratch_gb", ctypes.c_double), ("tail_length", ctypes.c_int32), ("small_call_max", ctypes.c_int32), ("verify_batch_min", ctypes.c_int32),
-                ("update_incremental_max", ctypes.c_int64), ("gs_slices", ctypes.c_int32), ("reserved0", ctypes.c_int32)]
+                ("update_incremental_max", ctypes.c_int64), ("gs_slices", ctypes.c_int32), ("profile", ctypes.c_int32)]
 
     def __init__(self, **kw):
         super().__init__()
@@ -72,6 +73,10 @@ _SIG = {
     "dapol_build_leaf_nodes": (ctypes.c_int32, [_P, ctypes.c_int32, _P, ctypes.c_size_t, ctypes.c_int32, ctypes.c_size_t, _P, _P, _P, _P, _P, _P, _P, _P,
                                                 _P, _P]),
     "dapol_tree_build": (ctypes.c_int32, [_P, ctypes.c_int32, ctypes.c_size_t, _P, _P, _P, _P, ctypes.c_int32, ctypes.POINTER(_P)]),
+    "dapol_tree_padding_positions": (ctypes.c_int32, [ctypes.c_int32, ctypes.c_size_t, _P, _P, _P, _P]),
+    "dapol_tree_build_tape": (ctypes.c_int32, [_P, ctypes.c_int32, ctypes.c_size_t, _P, _P, _P, _P, ctypes.c_size_t, ctypes.POINTER(_P)]),
+    "dapol_entity_tape_slots": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
+    "dapol_prove_entities_tape": (ctypes.c_int32, [_P, _P, ctypes.c_size_t, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _P, _P, _P, _P]),
     "dapol_tree_build_shard": (ctypes.c_int32, [_P, ctypes.c_int32, ctypes.c_int32, ctypes.c_size_t, _P, _P, _P, _P, ctypes.POINTER(_P)]),
     "dapol_merge_batch": (ctypes.c_int32, [_P, ctypes.c_size_t] + [_P] * 12),
     "dapol_padding_nodes": (ctypes.c_int32, [_P, _P, ctypes.c_size_t, _P, _P, _P, _P, _P]),
@@ -431,6 +436,16 @@ class Context:
         return ok
 
 
+def tree_padding_positions(height, leaf_idx):
+    """(level, index) of the padding nodes of the tree over the given leaves, in tape order (level bottom-up, index ascending)."""
+    leaf_idx = _u64(leaf_idx)
+    n = ctypes.c_size_t(0)
+    _chk(lib().dapol_tree_padding_positions(height, leaf_idx.shape[0], _ptr(leaf_idx), ctypes.byref(n), None, None))
+    level, index = np.zeros(max(n.value, 1), np.uint8), np.zeros(max(n.value, 1), np.uint64)
+    _chk(lib().dapol_tree_padding_positions(height, leaf_idx.shape[0], _ptr(leaf_idx), ctypes.byref(n), _ptr(level), _ptr(index)))
+    return level[:n.value], index[:n.value]
+
+
 def batch_siblings(height, leaf_idx):
     """Positions (level, index) of the siblings of a batched Merkle proof, in proof order (host-only)."""
     leaf_idx = _u64(leaf_idx)
@@ -566,14 +581,19 @@ def shard_top_levels(ctx, records, rank):
 class Tree:
     """dapol_tree: the sparse Merkle sum tree resident in HBM."""
 
-    def __init__(self, ctx, height, leaf_idx, v, r32, pad_seed, enforce_sparsity=False, shard_bits=0):
-        """height = total tree height; shard_bits > 0 builds only the subtree holding the (global-index) leaves."""
+    def __init__(self, ctx, height, leaf_idx, v, r32, pad_seed, enforce_sparsity=False, shard_bits=0, pad_tape=None):
+        """height = total tree height; shard_bits > 0 builds only the subtree holding the (global-index) leaves.
+        pad_tape (bytes / uint8 array of 64-byte draws; pad_seed is then ignored): dapol_tree_build_tape."""
         self.ctx, self.height, self.shard_bits = ctx, height - shard_bits, shard_bits
         leaf_idx, v = _u64(leaf_idx), _u64(v)
         n = leaf_idx.shape[0]
         r32 = _u8(r32, n, 32)
-        seed = _u8(np.frombuffer(pad_seed, np.uint8))
         self.h = _P()
+        if pad_tape is not None:
+            tp = _u8(np.frombuffer(bytes(pad_tape), np.uint8)) if len(pad_tape) else np.zeros(64, np.uint8)
+            _chk(lib().dapol_tree_build_tape(ctx.h, height, n, _ptr(leaf_idx), _ptr(v), _ptr(r32), _ptr(tp), len(pad_tape) // 64, ctypes.byref(self.h)))
+            return
+        seed = _u8(np.frombuffer(pad_seed, np.uint8))
         if shard_bits:
             _chk(lib().dapol_tree_build_shard(ctx.h, height, shard_bits, n, _ptr(leaf_idx), _ptr(v), _ptr(r32), _ptr(seed), ctypes.byref(self.h)))
         else:
@@ -646,14 +666,21 @@ class Tree:
                                      _ptr(out)))
         return level, index, C, H, out.tobytes()
 
-    def prove_entities(self, leaf_idx, policy, aggregation_factor, n_bits, nonce_seed, upper=None):
-        """upper = (C[u,32], H[u,32], v[u], r[u,32]) siblings above a shard root, root side first."""
+    def prove_entities(self, leaf_idx, policy, aggregation_factor, n_bits, nonce_seed, upper=None, tape=None):
+        """upper = (C[u,32], H[u,32], v[u], r[u,32]) siblings above a shard root, root side first.
+        tape (nonce_seed is then ignored): dapol_prove_entities_tape, [b][dapol_entity_tape_slots][64] bytes."""
         leaf_idx = _u64(leaf_idx)
         nu = 0 if upper is None else len(upper[2])
         b, h = leaf_idx.shape[0], self.height + nu
         es = lib().dapol_entity_proof_size(h, policy, aggregation_factor, n_bits)
         C, H = np.zeros((b, h, 32), np.uint8), np.zeros((b, h, self.ctx.hb), np.uint8)
         out = np.zeros((b, max(es, 1)), np.uint8)
+        if tape is not None:
+            tp = _u8(np.frombuffer(bytes(tape), np.uint8))
+            if tp.shape[0] != b * 64 * lib().dapol_entity_tape_slots(h, policy, aggregation_factor, n_bits):
+                raise DapolError(8, "the tape must hold dapol_entity_tape_slots draws of 64 bytes per entity")
+            _chk(lib().dapol_prove_entities_tape(self.ctx.h, self.h, b, _ptr(leaf_idx), policy, aggregation_factor, n_bits, _ptr(tp), _ptr(C), _ptr(H), _ptr(out)))
+            return C, H, out
         seed = _u8(np.frombuffer(nonce_seed, np.uint8))
         if nu:
             uC, uH, uv, ur = _u8(upper[0], nu, 32), _u8(upper[1], nu, 32), _u64(upper[2]), _u8(upper[3], nu, 32)

@@ -57,6 +57,14 @@ static const char* knob(const char* name) {
     }
     return on ? getenv(name) : nullptr;
 }
+// Fault injection and limit overrides that exist for tests/ only (DAPOL_TEST_FAIL_AFTER_FORK, DAPOL_TEST_FAIL_UPDATE_MIDWAY,
+// DAPOL_LEAF_MAX_TRIES: they make healthy calls fail, or change when DapolError::FailedToMapIndex fires) need a SECOND opt-in,
+// DAPOL_TEST_HOOKS=1, read once per process: the measurement scripts of tools/ export DAPOL_ENV_KNOBS alone and can never trip them,
+// and a call site costs a flag test instead of a getenv + strcmp (round-4 advisor).
+static const char* test_knob(const char* name) {
+    static const bool hooks = [] { const char* e = getenv("DAPOL_TEST_HOOKS"); return e && !strcmp(e, "1"); }();
+    return hooks ? knob(name) : nullptr;
+}
 int32_t dapol_env_knobs(int32_t enable) {
     int old = g_env_knobs.exchange(enable ? 1 : 0);
     if (old < 0) { const char* e = getenv("DAPOL_ENV_KNOBS"); old = (e && *e && strcmp(e, "0") != 0) ? 1 : 0; }
@@ -167,6 +175,7 @@ static bool options_ok(const dapol_options* o) {
     if (o->tail_length && o->tail_length != -1 && o->tail_length != 32 && o->tail_length != 64 && o->tail_length != 128 && o->tail_length != 256) return false;
     if (o->small_call_max < 0 || o->verify_batch_min < 0 || o->update_incremental_max < -1) return false;
     if (o->gs_slices != 0 && o->gs_slices != 1 && o->gs_slices != 2 && o->gs_slices != 4 && o->gs_slices != 8 && o->gs_slices != 16) return false;
+    if (o->profile != DAPOL_PROFILE_BENCH && o->profile != DAPOL_PROFILE_HOST) return false;
     return true;
 }
 // DAPOL_STREAM_LAYOUT=<name> (measurement knob): where the chunks in flight and their VALU-bound launches run.
@@ -224,21 +233,26 @@ static int32_t ensure_stream_layout(dapol_ctx* c, const char* name) {
 struct ForkGuard {
     dapol_ctx* c;
     bool open[3] = {false, false, false};
+    hipStream_t extra = nullptr;     // one more stream that carries this call's kernels while the guard is armed (the measurement knobs'
+    bool extra_open = false;         // MSM stream: DAPOL_MSM_SERIAL / stream layouts); closed by done() on the normal path
     explicit ForkGuard(dapol_ctx* c_) : c(c_) {}
     ForkGuard(const ForkGuard&) = delete;
     ForkGuard& operator=(const ForkGuard&) = delete;
     void forked(int i) { open[i] = true; }
     void joined(int i) { open[i] = false; }
+    void also(hipStream_t s) { extra = s; extra_open = s != nullptr; }
+    void done() { extra_open = false; }
     ~ForkGuard() {
         for (int i = 0; i < 3; i++)
             if (open[i]) { (void)hipStreamSynchronize(c->side[i]); g_fork_guard_waits.fetch_add(1, std::memory_order_relaxed); }
+        if (extra_open) { (void)hipStreamSynchronize(extra); g_fork_guard_waits.fetch_add(1, std::memory_order_relaxed); }
     }
 };
-// Test knob (opt-in only, like every DAPOL_* variable): DAPOL_TEST_FAIL_AFTER_FORK=<site> makes the named site return an error right
+// Test knob (behind BOTH opt-ins, test_knob above): DAPOL_TEST_FAIL_AFTER_FORK=<site> makes the named site return an error right
 // after its fork, as a failed launch would -- tests/test_gpu_fault_paths.py then checks that the next call on the context is clean.
 #define FAULT_AFTER_FORK(site)                                                                                          \
     do {                                                                                                                \
-        const char* e_ = knob("DAPOL_TEST_FAIL_AFTER_FORK");                                                            \
+        const char* e_ = test_knob("DAPOL_TEST_FAIL_AFTER_FORK");                                                         \
         if (e_ && !strcmp(e_, site)) return fail(DAPOL_ERR_HIP, "injected failure after the fork at " site " (test knob)"); \
     } while (0)
 
@@ -265,6 +279,7 @@ int32_t dapol_ctx_set_options(dapol_ctx* ctx, const dapol_options* o) {
     const dapol_options keep = ctx->opt;
     ctx->opt = *o;
     ctx->opt.window_bits = keep.window_bits; ctx->opt.table_gb = keep.table_gb; ctx->opt.high_half_rows = keep.high_half_rows;    // fixed at creation
+    ctx->opt.profile = keep.profile;
     return DAPOL_OK;
 }
 int32_t dapol_ctx_create_opts(int32_t device, int32_t max_parties, int32_t digest_id, const dapol_options* options, dapol_ctx** out) {
@@ -324,6 +339,7 @@ int32_t dapol_ctx_create_opts(int32_t device, int32_t max_parties, int32_t diges
         const char* eb = knob("DAPOL_TABLE_GB");
         double budget = 40.0e9;
         size_t free_b = 0, total_b = 0;
+        if (c->opt.profile == DAPOL_PROFILE_HOST) budget = 18.0e9;       // 16-bit windows for 32 parties (17.3 GB), 15-bit for 64
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)free_b * 0.30 < budget) budget = (double)free_b * 0.30;
         if (c->opt.table_gb > 0) budget = c->opt.table_gb * 1e9;
         if (eb) budget = atof(eb) * 1e9;
@@ -348,6 +364,7 @@ int32_t dapol_ctx_create_opts(int32_t device, int32_t max_parties, int32_t diges
         size_t free_b = 0, total_b = 0;
         const double bytes2 = (double)(rows + 128 * P) * (double)tv.row_words() * 4.0;
         bool hi = P <= 64 && hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes2 <= 0.30 * (double)free_b;
+        if (c->opt.profile == DAPOL_PROFILE_HOST) hi = false;             // as much memory again for +1.5-2 %: not for a shared GPU
         if (c->opt.high_half_rows) hi = c->opt.high_half_rows > 0 && P <= 64;
         if (const char* e = knob("DAPOL_TABLE_HI")) hi = atoi(e) != 0;
         if (hi) tv.hi_split = (tv.nwin_c() + 1) / 2;
@@ -469,6 +486,7 @@ struct dapol_tree {
     int index_bits = 0, shard_bits = 0;          // what the tree was built with (dapol_tree_update rebuilds with the same)
     uint8_t pad_seed[32] = {0};
     bool invalid = false;              // an in-place update failed after its first write: root and leaves may disagree; every call refuses the tree
+    bool tape_built = false;           // dapol_tree_build_tape: the padding draws came from a caller's tape (no seed to make further ones from)
     DevBuf<LevelView> d_views;         // view(0..height, nullptr) on the device, for kernels that walk several levels
     // 64-byte node hashes (a Blake2b context): the hash chain laid over the built tree (tree_hash_wide), per level H16[n] | padH16[n]
     DevBuf<uint32_t> wide;
@@ -504,8 +522,9 @@ struct TreePoison {                    // armed before the first write of an in-
 // Builds the tree from device-resident leaf arrays (d_idx sorted; d_r is masked in place).  own==true: the tree
 // takes ownership of nothing; leaf arrays must outlive it (they are owned by the caller-side holder below).
 static int32_t tree_build_device_core(dapol_ctx* ctx, int index_bits, int shard_bits, size_t n, uint64_t* d_idx, uint64_t* d_v, uint32_t* d_r,
-                                      const uint8_t pad_seed32[32], dapol_tree* t) {
+                                      const uint8_t pad_seed32[32], dapol_tree* t, const uint32_t* d_tape = nullptr, size_t tape_draws = 0) {
     hipStream_t st = ctx->stream;
+    t->tape_built = d_tape != nullptr;
     const int height = index_bits - shard_bits;       // levels built on this GPU
     t->ctx = ctx;
     t->height = height;
@@ -566,7 +585,11 @@ static int32_t tree_build_device_core(dapol_ctx* ctx, int index_bits, int shard_
     const uint32_t n32 = (uint32_t)n;
     HIPCHK(hipMemcpyAsync(cnt.p, &n32, 4, hipMemcpyHostToDevice, st));
     DevBuf<int32_t> ext_a, ext_b;
-    const bool phased = n <= (size_t)TREE_SMALL_MAX && height >= 1 && !knob("DAPOL_TREE_LEVELWISE");
+    const bool phased = n <= (size_t)TREE_SMALL_MAX && height >= 1 && !knob("DAPOL_TREE_LEVELWISE") && !d_tape;     // (tape mode: the level-wise kernel reads the tape)
+    DevBuf<uint32_t> tape_short;
+    HIPCHK(tape_short.alloc(1));
+    HIPCHK(hipMemsetAsync(tape_short.p, 0, 4, st));
+    const PadTape ptape{d_tape, (uint32_t)std::min<size_t>(tape_draws, 0xffffffffu), tape_short.p};
     if (phased) {
         // Small trees, by phases (kernels_ctx_tree.h, "small trees"): structure, all padding nodes, point sums level by level, all
         // encodings, hashes level by level.  The extended points of every level are kept until the encodings are done.
@@ -629,14 +652,17 @@ static int32_t tree_build_device_core(dapol_ctx* ctx, int index_bits, int shard_
         hipLaunchKernelGGL(k_scan_finish, dim3(nblk(bound[k], 256)), dim3(256), 0, st, cnt.p + k, flag.p, pos.p, bsums.p, head.p);
         LAUNCH_CHECK();
         LevelView nxt = t->view(k + 1, k + 1 < height ? ext_nxt : nullptr);
-        hipLaunchKernelGGL(k_tree_merge, dim3(nblk(bound[k + 1], 256)), dim3(256), 0, st, ctx->tv, cur, nxt, head.p, k, seed.p, cnt.p);
+        hipLaunchKernelGGL(k_tree_merge, dim3(nblk(bound[k + 1], 256)), dim3(256), 0, st, ctx->tv, cur, nxt, head.p, k, seed.p, cnt.p, ptape);
         LAUNCH_CHECK();
         std::swap(ext_cur, ext_nxt);
     }
     }
     std::vector<uint32_t> h_cnt((size_t)height + 1);
+    uint32_t h_short = 0;
     HIPCHK(hipMemcpyAsync(h_cnt.data(), cnt.p, ((size_t)height + 1) * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&h_short, tape_short.p, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    if (h_short) return fail(DAPOL_ERR_INVALID_ARGUMENT, "the padding tape is shorter than the tree's padding nodes (dapol_tree_padding_positions gives the count)");
     for (int k = 0; k <= height; k++) {
         t->levels[k].n = h_cnt[k];
         t->n_real += h_cnt[k];
@@ -678,8 +704,8 @@ static int32_t tree_hash_wide(dapol_tree* t) {
     return DAPOL_OK;
 }
 static int32_t tree_build_device(dapol_ctx* ctx, int index_bits, int shard_bits, size_t n, uint64_t* d_idx, uint64_t* d_v, uint32_t* d_r,
-                                 const uint8_t pad_seed32[32], dapol_tree* t) {
-    int32_t rc = tree_build_device_core(ctx, index_bits, shard_bits, n, d_idx, d_v, d_r, pad_seed32, t);
+                                 const uint8_t pad_seed32[32], dapol_tree* t, const uint32_t* d_tape = nullptr, size_t tape_draws = 0) {
+    int32_t rc = tree_build_device_core(ctx, index_bits, shard_bits, n, d_idx, d_v, d_r, pad_seed32, t, d_tape, tape_draws);
     return rc ? rc : tree_hash_wide(t);
 }
 
@@ -717,6 +743,65 @@ int32_t dapol_tree_build(dapol_ctx* ctx, int32_t height, size_t n, const uint64_
     HIPCHK(hipMemcpyAsync(t->leaves.v.p, v, n * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(t->leaves.r.p, r32, n * 32, hipMemcpyHostToDevice, ctx->stream));
     int32_t rc = tree_build_device(ctx, height, 0, n, t->leaves.idx.p, t->leaves.v.p, t->leaves.r.p, pad_seed32, t);
+    if (rc != DAPOL_OK) return rc;
+    guard.t = nullptr;
+    t->holds_ctx = true;
+    ctx_retain(ctx);
+    *out = t;
+    return DAPOL_OK;
+}
+
+// Padding nodes of the tree over the given (sorted, distinct) leaves, in TAPE order: level bottom-up, index ascending.  Pure index
+// arithmetic (smtree's build restated: every real node's missing sibling is a padding node; a parent exists iff a child does).
+int32_t dapol_tree_padding_positions(int32_t height, size_t n, const uint64_t* leaf_idx, size_t* count, uint8_t* level, uint64_t* index) {
+    if (!count || (n && !leaf_idx)) return fail(DAPOL_ERR_INVALID_ARGUMENT, "null argument");
+    if (height < 0 || height > 64) return fail(DAPOL_ERR_TREE_HEIGHT_TOO_BIG, "tree height must not exceed 64");
+    for (size_t i = 0; i < n; i++)
+        if ((height < 64 && (leaf_idx[i] >> height)) || (i && leaf_idx[i] <= leaf_idx[i - 1]))
+            return fail(DAPOL_ERR_INVALID_ARGUMENT, "leaf indexes must be strictly increasing and below 2^height");
+    std::vector<uint64_t> cur(leaf_idx, leaf_idx + n), nxt;
+    size_t k = 0;
+    for (int L = 0; L < height; L++) {
+        nxt.clear();
+        for (size_t i = 0; i < cur.size();) {
+            const uint64_t x = cur[i];
+            if (!(x & 1) && i + 1 < cur.size() && cur[i + 1] == x + 1) i += 2;
+            else {
+                if (level) level[k] = (uint8_t)L;
+                if (index) index[k] = x ^ 1ull;
+                k++;
+                i += 1;
+            }
+            nxt.push_back(x >> 1);
+        }
+        cur.swap(nxt);
+    }
+    *count = k;
+    return DAPOL_OK;
+}
+// dapol_tree_build in TAPE mode: the padding nodes' blindings (Paddable::padding -> Scalar::random, src/dapol/node.rs:86-88) are read
+// from `tape` -- tape_draws draws of 64 bytes, each reduced mod l, one per padding node in dapol_tree_padding_positions' order --
+// instead of being derived from a seed.  With the draws a seed would give, the tree equals the seed-mode tree bit for bit.  A tree
+// built from a tape has no seed to draw further padding nodes from: dapol_tree_update refuses it (build it again with a longer tape).
+int32_t dapol_tree_build_tape(dapol_ctx* ctx, int32_t height, size_t n, const uint64_t* leaf_idx, const uint64_t* v, const uint8_t* r32,
+                              const uint8_t* tape, size_t tape_draws, dapol_tree** out) {
+    if (!ctx || !out || (n && (!leaf_idx || !v || !r32)) || (tape_draws && !tape)) return fail(DAPOL_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (height < 0 || height > 64) return fail(DAPOL_ERR_TREE_HEIGHT_TOO_BIG, "tree height must not exceed 64");
+    if (n == 0) return fail(DAPOL_ERR_INVALID_ARGUMENT, "empty leaf set");
+    if (n > ((size_t)1 << 31)) return fail(DAPOL_ERR_INVALID_ARGUMENT, "at most 2^31 leaves per GPU (32-bit node positions); memory is the practical bound");
+    HIPCHK(hipSetDevice(ctx->device));
+    dapol_tree_owned* t = new dapol_tree_owned();
+    struct Guard { dapol_tree* t; ~Guard() { if (t) dapol_tree_destroy(t); } } guard{t};
+    DevBuf<uint32_t> dtape;
+    HIPCHK(dtape.alloc(tape_draws * 16 + 16));
+    HIPCHK(t->leaves.idx.alloc(n)); HIPCHK(t->leaves.v.alloc(n)); HIPCHK(t->leaves.r.alloc(n * 8));
+    HIPCHK(hipMemcpyAsync(t->leaves.idx.p, leaf_idx, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(t->leaves.v.p, v, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(t->leaves.r.p, r32, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    if (tape_draws) HIPCHK(hipMemcpyAsync(dtape.p, tape, tape_draws * 64, hipMemcpyHostToDevice, ctx->stream));
+    const uint8_t no_seed[32] = {0};
+    int32_t rc = tree_build_device(ctx, height, 0, n, t->leaves.idx.p, t->leaves.v.p, t->leaves.r.p, no_seed, t, dtape.p, tape_draws);
     if (rc != DAPOL_OK) return rc;
     guard.t = nullptr;
     t->holds_ctx = true;
@@ -783,7 +868,7 @@ static int32_t tree_update_incremental(dapol_tree_owned* own, size_t k, const st
     HIPCHK(hipStreamSynchronize(st));
     if (missing) return DAPOL_OK;                            // a new index: nothing has been written; the caller inserts or rebuilds
     TreePoison poison{own, true};                            // from here on the leaves and the levels above are rewritten in place
-    if (knob("DAPOL_TEST_FAIL_UPDATE_MIDWAY")) return fail(DAPOL_ERR_HIP, "injected failure between the leaf update and the re-merge (test knob)");
+    if (test_knob("DAPOL_TEST_FAIL_UPDATE_MIDWAY")) return fail(DAPOL_ERR_HIP, "injected failure between the leaf update and the re-merge (test knob)");
     hipLaunchKernelGGL(k_tree_upd_leaves, dim3(nblk(k, 64)), dim3(64), 0, st, ctx->tv, own->d_views.p, U);
     LAUNCH_CHECK();
     if (H >= 1) {
@@ -960,6 +1045,7 @@ static int32_t tree_update_impl(dapol_tree* tree, size_t k, const uint64_t* leaf
     if (!tree || (k && (!leaf_idx || !v || !r32))) return fail(DAPOL_ERR_INVALID_ARGUMENT, "null argument");
     if (k == 0) return DAPOL_OK;
     TREE_USABLE(tree);
+    if (tree->tape_built) return fail(DAPOL_ERR_INVALID_ARGUMENT, "the tree was built from a padding tape: an update may need draws the tape does not hold; build it again");
     dapol_tree_owned* own = static_cast<dapol_tree_owned*>(tree);
     if (!own->leaves.idx.p) return fail(DAPOL_ERR_INVALID_ARGUMENT, "tree does not own its leaves (workload tree): rebuild the workload instead");
     dapol_ctx* ctx = tree->ctx;

@@ -246,8 +246,17 @@ struct LevelView {
 // One lane per PARENT q (smtree build restated level-synchronously): children = the real node head[q] and either
 // the adjacent real node or a padding node made on the spot (Paddable::padding, src/dapol/node.rs:86-88, with the
 // positional seed-mode blinding); parent = Mergeable::merge (node.rs:64-80).
+// TAPE mode (pad_tape != null; dapol_tree_build_tape): the padding node's 64-byte draw is read from the caller's tape instead of being
+// derived from the seed.  Tape order = (level bottom-up, index ascending) over the padding nodes.  Parent q of this level has the
+// real children head[q] (and head[q] + 1 when they are a pair), so 2 q - head[q] parents before it own a padding child -- the rank
+// inside the level -- and the levels below hold sum (2 cnt[j + 1] - cnt[j]) padding nodes: no scan, no second pass.
+struct PadTape {
+    const uint32_t* draws;     // [n_draws][16] or null (seed mode)
+    uint32_t n_draws;
+    uint32_t* short_flag;      // set when the tree needs more draws than the tape holds
+};
 __global__ __launch_bounds__(256) void k_tree_merge(TableView tbl, LevelView cur, LevelView nxt, const uint32_t* head, int level,
-                                                    const uint32_t* pad_seed /*8 words*/, const uint32_t* cnt /*[levels + 1], device*/) {
+                                                    const uint32_t* pad_seed /*8 words*/, const uint32_t* cnt /*[levels + 1], device*/, PadTape tape) {
     size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t cur_n = cnt[level], nxt_n = cnt[level + 1];           // (cur.n / nxt.n are only host-side bounds during the build)
     if (q >= nxt_n) return;
@@ -272,8 +281,15 @@ __global__ __launch_bounds__(256) void k_tree_merge(TableView tbl, LevelView cur
         cur.parent[i + 1] = (uint32_t)q;
     } else {
         uint32_t seed[8], wide[16];
-        for (int k = 0; k < 8; k++) seed[k] = pad_seed[k];
-        seed_wide(wide, seed, 1u, (uint64_t)level, my_idx ^ 1ull);
+        if (tape.draws) {
+            uint64_t rank = 2 * (uint64_t)q - (uint64_t)i;
+            for (int j = 0; j < level; j++) rank += 2 * (uint64_t)cnt[j + 1] - (uint64_t)cnt[j];
+            if (rank < tape.n_draws) { for (int k = 0; k < 16; k++) wide[k] = tape.draws[rank * 16 + k]; }
+            else { atomicOr(tape.short_flag, 1u); for (int k = 0; k < 16; k++) wide[k] = 0; }
+        } else {
+            for (int k = 0; k < 8; k++) seed[k] = pad_seed[k];
+            seed_wide(wide, seed, 1u, (uint64_t)level, my_idx ^ 1ull);
+        }
         sc rm;
         sc_from_wide(rm, wide);
         sc_from_mont(rB, rm);

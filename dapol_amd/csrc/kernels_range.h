@@ -37,7 +37,8 @@ struct RangeArgs {
     const uint32_t* seed;       // [8] device
     const uint64_t* stream_id;  // [B]
     uint64_t slot_base;
-    const uint32_t* tape;       // [B][m(2n+4)][16] or null
+    const uint32_t* tape;       // [B][tape_stride][16] or null: the proof's slots start at its row's head
+    uint32_t tape_stride;       // draws per proof in `tape`: m(2n+4) for a lone proof, the whole entity's slots when the sub-proofs of a policy share one stream
     // scratch
     sc* a; sc* b; sc* s1; sc* s2;       // [B][N] each
     // Coefficient TABLES (null: the s-vectors themselves are folded every round, as before round 3).  The coefficient of
@@ -74,7 +75,7 @@ enum { STAB_ROUNDS = 6, STAB_N = 1 << STAB_ROUNDS };      // coefficient tables 
 
 __device__ __forceinline__ void tape_wide(uint32_t* w16, const RangeArgs& A, size_t b, uint32_t slot) {
     if (A.tape) {
-        const uint4* p = reinterpret_cast<const uint4*>(A.tape + ((size_t)b * (size_t)(A.m * (2 * A.n + 4)) + slot) * 16);
+        const uint4* p = reinterpret_cast<const uint4*>(A.tape + ((size_t)b * (size_t)A.tape_stride + slot) * 16);
         for (int i = 0; i < 4; i++) { uint4 q = p[i]; w16[4 * i] = q.x; w16[4 * i + 1] = q.y; w16[4 * i + 2] = q.z; w16[4 * i + 3] = q.w; }
     } else {
         uint32_t key[8];

@@ -957,29 +957,47 @@ __global__ __launch_bounds__(64) void k_rvp_decode(RlcArgs R) {
     niels_store_entry(o, qn);
     o[30] = good ? 0 : 1;
 }
-// Scalars -> digits + histogram (lane per point), after the replay.  A point that did not decode sends the chunk to the
-// proof-by-proof check if its proof is still in the running.
-__global__ __launch_bounds__(64) void k_rvp_digits(RlcArgs R) {
-    size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
-    if (t >= R.npts) return;
-    size_t p = t / R.K;
-    sc sm;
-    sc_zero(sm);
-    if (R.V.vs[p].ok) {
-        if (R.pN[t * 32 + 30]) atomicOr(&R.flag[1], 1u);
-        else {
-            uint32_t w8[8];
-            rv_own_point(w8, sm, R.V, p, (int)(t - p * R.K));
-            sc_montmul(sm, sm, R.V.vs[p].rho);
+// Scalars -> digits + histogram, after the replay.  A point that did not decode sends the chunk to the proof-by-proof check if its
+// proof is still in the running.
+// Round 5: the 25 M increments of a 1,024 x 1,024-party batch used to be 25 M device-scope atomics -- which on this chip go past
+// the (per-XCD, mutually incoherent) L2s to the memory side, 28 bytes of fabric traffic each, to 23,575 counters that are hit a
+// thousand times each (706 MB written for 50 MB of digits, profiles/r07k_verify_pmc.txt).  A block now owns a contiguous run of
+// RVP_RUN points and counts them in LDS (23 x 1,025 counters of 16 bits, two to a word: a run holds 4,096 points, 46 KB); what
+// reaches memory is one add per non-empty counter and block.
+enum { RVP_BLOCK = 256, RVP_RUN = 4096, RVP_HW = (RVP_NW * (RVP_NB + 1) + 1) / 2 };   // threads / points per block (digits and scatter kernels), LDS words
+static_assert(RVP_RUN < 65536, "16-bit run counters");
+__global__ __launch_bounds__(RVP_BLOCK) void k_rvp_digits(RlcArgs R) {
+    __shared__ uint32_t hist[RVP_HW];
+    for (int i = threadIdx.x; i < RVP_HW; i += RVP_BLOCK) hist[i] = 0;
+    __syncthreads();
+    const size_t np = R.npts, t0 = (size_t)blockIdx.x * RVP_RUN, t1 = t0 + RVP_RUN < np ? t0 + RVP_RUN : np;
+    for (size_t t = t0 + threadIdx.x; t < t1; t += RVP_BLOCK) {
+        size_t p = t / R.K;
+        sc sm;
+        sc_zero(sm);
+        if (R.V.vs[p].ok) {
+            if (R.pN[t * 32 + 30]) atomicOr(&R.flag[1], 1u);
+            else {
+                uint32_t w8[8];
+                rv_own_point(w8, sm, R.V, p, (int)(t - p * R.K));
+                sc_montmul(sm, sm, R.V.vs[p].rho);
+            }
         }
+        uint32_t c[8];
+        sc_from_mont(c, sm);
+        sc_recode_w(RVP_C, RVP_NW, c, [&](int i, int digit) {
+            R.pdig[(size_t)i * np + t] = (int16_t)digit;
+            if (digit) {
+                const int k = i * (RVP_NB + 1) + (digit < 0 ? -digit : digit);
+                atomicAdd(&hist[k >> 1], 1u << (16 * (k & 1)));
+            }
+        });
     }
-    uint32_t c[8];
-    sc_from_mont(c, sm);
-    const size_t np = R.npts;
-    sc_recode_w(RVP_C, RVP_NW, c, [&](int i, int digit) {
-        R.pdig[(size_t)i * np + t] = (int16_t)digit;
-        if (digit) atomicAdd(&R.phist[(size_t)i * (RVP_NB + 1) + (digit < 0 ? -digit : digit)], 1u);
-    });
+    __syncthreads();
+    for (int i = threadIdx.x; i < RVP_NW * (RVP_NB + 1); i += RVP_BLOCK) {
+        const uint32_t c = (hist[i >> 1] >> (16 * (i & 1))) & 0xffffu;
+        if (c) atomicAdd(&R.phist[i], c);
+    }
 }
 // offs[w][d] = number of points of window w with 0 < |digit| < d; cursor = offs.  One wavefront per window.
 __global__ __launch_bounds__(64) void k_rvp_scan(RlcArgs R) {
@@ -999,15 +1017,39 @@ __global__ __launch_bounds__(64) void k_rvp_scan(RlcArgs R) {
         base += i ? h[i] : 0u;
     }
 }
-__global__ __launch_bounds__(64) void k_rvp_scatter(RlcArgs R) {
-    size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
-    if (t >= R.npts) return;
-    const size_t np = R.npts;
-    for (int w = 0; w < RVP_NW; w++) {
-        int d = R.pdig[(size_t)w * np + t];
-        if (!d) continue;
-        uint32_t pos = atomicAdd(&R.pcursor[(size_t)w * (RVP_NB + 1) + (d < 0 ? -d : d)], 1u);
-        R.psorted[(size_t)w * np + pos] = (uint32_t)t | (d < 0 ? 0x80000000u : 0u);
+// Counting-sort scatter.  Round 5, two changes against 25 M returning device-scope atomics + 25 M stray 4-byte stores (1.25 GB
+// written for a 100 MB array: a line of psorted was touched from all eight XCDs, whose L2s cannot merge each other's bytes):
+//  * a block owns (a run of RVP_RUN points) x (the windows of ONE XCD: w = xcd, xcd + 8, ...; blockIdx.x % 8 is the XCD a block lands
+//    on) -- every line of a window's slice of psorted is then written from one L2 only, which merges the 4-byte stores into lines;
+//  * per window the block counts its run in LDS first, reserves its share of every bucket with ONE returning add per non-empty
+//    bucket, and ranks its points inside that share with LDS atomics.
+// The order inside a bucket is whatever the atomics give; the bucket's sum does not depend on it.
+__global__ __launch_bounds__(RVP_BLOCK) void k_rvp_scatter(RlcArgs R) {
+    __shared__ uint32_t cnt[RVP_NB + 1];
+    const int xcd = blockIdx.x & 7;
+    const size_t np = R.npts, t0 = (size_t)(blockIdx.x >> 3) * RVP_RUN, t1 = t0 + RVP_RUN < np ? t0 + RVP_RUN : np;
+    for (int w = xcd; w < RVP_NW; w += 8) {
+        for (int i = threadIdx.x; i <= RVP_NB; i += RVP_BLOCK) cnt[i] = 0;
+        __syncthreads();
+        const int16_t* dg = R.pdig + (size_t)w * np;
+        for (size_t t = t0 + threadIdx.x; t < t1; t += RVP_BLOCK) {
+            const int d = dg[t];
+            if (d) atomicAdd(&cnt[d < 0 ? -d : d], 1u);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i <= RVP_NB; i += RVP_BLOCK) {   // cnt[d] := where this block's share of bucket d begins
+            const uint32_t c = cnt[i];
+            cnt[i] = c ? atomicAdd(&R.pcursor[(size_t)w * (RVP_NB + 1) + i], c) : 0u;
+        }
+        __syncthreads();
+        uint32_t* out = R.psorted + (size_t)w * np;
+        for (size_t t = t0 + threadIdx.x; t < t1; t += RVP_BLOCK) {
+            const int d = dg[t];
+            if (!d) continue;
+            const uint32_t pos = atomicAdd(&cnt[d < 0 ? -d : d], 1u);
+            out[pos] = (uint32_t)t | (d < 0 ? 0x80000000u : 0u);
+        }
+        __syncthreads();
     }
 }
 // Bucket sums: RVP_S adjacent lanes share a bucket (every RVP_S-th point each), then a tree reduction.  grid = NW * NB * S / 64.

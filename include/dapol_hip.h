@@ -105,8 +105,14 @@ typedef struct {
     int32_t verify_batch_min;         /* fewest proofs the verifier checks as ONE random linear combination (0: 112) */
     int64_t update_incremental_max;   /* dapol_tree_update: most replaced leaves re-merged in place (0: 65,536; -1: always rebuild) */
     int32_t gs_slices;                /* slices of a list swept side by side by the generator-stationary MSM: 1, 2, 4, 8, 16 (0: as many as fill the chip) */
-    int32_t reserved0;                /* 0 */
+    int32_t profile;                  /* creation: DAPOL_PROFILE_BENCH (0, the default) or DAPOL_PROFILE_HOST: the defaults of the memory fields above.
+                                         BENCH spends HBM for the last percent of throughput: 17-bit windows + high-half rows (69 GB of tables for 32
+                                         parties), chunks of two rounds of resident wavefronts (102 GB of scratch during a large call).  HOST is sized for
+                                         an embedder that shares the GPU: 18 GB table budget (16-bit windows for 32 parties, no high-half rows), chunks of
+                                         one round (<= 56 GB of scratch) -- INTEGRATION.md section 4 gives both footprints and throughputs.  Explicit
+                                         table_gb / window_bits / high_half_rows / scratch_gb / chunk_proofs win over the profile. */
 } dapol_options;
+enum { DAPOL_PROFILE_BENCH = 0, DAPOL_PROFILE_HOST = 1 };
 int32_t dapol_ctx_create_opts(int32_t device, int32_t max_parties, int32_t digest_id, const dapol_options* options, dapol_ctx** out);
 int32_t dapol_ctx_get_options(dapol_ctx* ctx, dapol_options* out);      /* the stored settings (zeros = defaults) + window_bits / high_half_rows as built */
 int32_t dapol_ctx_set_options(dapol_ctx* ctx, const dapol_options* options);   /* creation-time fields are ignored here */
@@ -149,6 +155,15 @@ int32_t dapol_build_leaf_nodes(dapol_ctx* ctx, int32_t digest_id, const uint8_t*
  * their blinding from pad_seed32 (seed mode, positional). */
 int32_t dapol_tree_build(dapol_ctx* ctx, int32_t height, size_t n, const uint64_t* leaf_idx, const uint64_t* v,
                          const uint8_t* r32, const uint8_t pad_seed32[32], int32_t enforce_sparsity, dapol_tree** out);
+/* TAPE mode of the build (the randomness contract in this header's head comment): the padding nodes' blindings are read from
+ * `tape` -- tape_draws x 64 bytes, each reduced mod l like Scalar::random, ONE PER PADDING NODE in the order (level bottom-up, index
+ * ascending) -- instead of being derived from a seed.  dapol_tree_padding_positions (host only, pure index arithmetic) gives that
+ * order and the count for a leaf set: *count, and, when non-NULL, level[] (0 = leaf level) and index[] of every padding node.  With
+ * the draws a seed would have given, the tree equals dapol_tree_build's bit for bit.  A tape shorter than the tree's padding nodes ->
+ * DAPOL_ERR_INVALID_ARGUMENT.  A tree built from a tape cannot be updated (no seed to draw new padding nodes from). */
+int32_t dapol_tree_padding_positions(int32_t height, size_t n, const uint64_t* leaf_idx, size_t* count, uint8_t* level, uint64_t* index);
+int32_t dapol_tree_build_tape(dapol_ctx* ctx, int32_t height, size_t n, const uint64_t* leaf_idx, const uint64_t* v, const uint8_t* r32,
+                              const uint8_t* tape, size_t tape_draws, dapol_tree** out);
 /* Multi-GPU sharding: builds only the subtree that holds all the given leaves, i.e. the
  * lowest (total_height - shard_bits) levels; every leaf index (GLOBAL, < 2^total_height) must share its top
  * shard_bits bits.  Padding seeds and nonce stream ids use the global indexes, so the nodes equal the ones a
@@ -225,6 +240,13 @@ int32_t dapol_prove_entities(dapol_ctx* ctx, dapol_tree* tree, size_t b, const u
                              int32_t aggregation_factor, int32_t n_bits, const uint8_t nonce_seed32[32], uint8_t* path_C32,
                              uint8_t* path_H32, uint8_t* range_out);
 size_t dapol_entity_proof_size(int32_t height, int32_t policy, int32_t aggregation_factor, int32_t n_bits);
+/* TAPE mode of dapol_prove_entities: the nonces of entity e are the draws tape[e][slot][64], slot < dapol_entity_tape_slots(...), in
+ * the crate's draw order -- the sub-proofs of the policy one after the other (ONE RNG runs through R::generate_proof,
+ * src/range/padding.rs:104-112, splitting.rs:110-123), inside each the slot order given at the top of this header.  What a Rust
+ * harness replays through a custom RngCore into prove_multiple_with_rng (tools/replay_tape.rs). */
+size_t dapol_entity_tape_slots(int32_t height, int32_t policy, int32_t aggregation_factor, int32_t n_bits);
+int32_t dapol_prove_entities_tape(dapol_ctx* ctx, dapol_tree* tree, size_t b, const uint64_t* leaf_idx, int32_t policy, int32_t aggregation_factor,
+                                  int32_t n_bits, const uint8_t* tape, uint8_t* path_C32, uint8_t* path_H32, uint8_t* range_out);
 /* Same, for a shard tree: the n_upper siblings above the shard root (root side first; identical for every leaf
  * of the shard) are prepended to each leaf's own siblings before the policy is applied.  Path outputs are
  * [b][n_upper + tree height][32]. */

@@ -13,6 +13,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 # The library reads its DAPOL_* measurement knobs only in a process that has opted in (include/dapol_hip.h, dapol_options): the
 # tests do -- they drive every strategy through those knobs and compare bytes -- and so do the child processes they start.
 os.environ.setdefault("DAPOL_ENV_KNOBS", "1")
+os.environ.setdefault("DAPOL_TEST_HOOKS", "1")        # the fault-injection / limit-override knobs need this second opt-in (dapol_hip.hip: test_knob)
 
 
 def pytest_configure(config):

@@ -26,6 +26,7 @@ static size_t ctx_hash_bytes(const dapol_ctx* c) { return c->unused == 64 ? 64 :
 #include "policy_plan.inc"
 #include "host_wire.inc"
 
+static int g_hb = 32;           // bytes of a node hash in the wires under test: 32, or 64 (a Blake2b context, DapolProofNode = C32 || H64)
 static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
 static uint64_t rnd() { rng_state ^= rng_state << 7; rng_state ^= rng_state >> 9; return rng_state * 0x2545F4914F6CDD1Dull; }
 
@@ -34,10 +35,10 @@ static uint64_t rnd() { rng_state ^= rng_state << 7; rng_state ^= rng_state >> 9
 static std::vector<uint8_t> good_wire(int height, size_t k, size_t S, int policy, int agg, int n_bits) {
     const size_t es = dapol_entity_proof_size((int32_t)S, policy, agg, n_bits);
     if (es == 0) { printf("bad shape\n"); exit(2); }
-    std::vector<uint8_t> blob(es, 0), C(S * 32 + 1, 0), H(S * 32 + 1, 7), out(dapol_proof_wire_size(height, k, S, policy, agg, n_bits));
+    std::vector<uint8_t> blob(es, 0), C(S * 32 + 1, 0), H(S * (size_t)g_hb + 1, 7), out(dapol_proof_wire_size_d(g_hb, height, k, S, policy, agg, n_bits));
     std::vector<uint64_t> leaves(k);
     for (size_t i = 0; i < k; i++) leaves[i] = i;
-    int32_t rc = dapol_proof_serialize(height, k, leaves.data(), S, C.data(), H.data(), policy, agg, n_bits, blob.data(), out.data());
+    int32_t rc = dapol_proof_serialize_d(g_hb, height, k, leaves.data(), S, C.data(), H.data(), policy, agg, n_bits, blob.data(), out.data());
     if (rc) { printf("serialize failed %d\n", rc); exit(2); }
     return out;
 }
@@ -46,14 +47,14 @@ static std::vector<uint8_t> good_wire(int height, size_t k, size_t S, int policy
 static int32_t parse(int policy, int n_bits, const uint8_t* wire_in, size_t len) {
     uint8_t* wire = (uint8_t*)malloc(len ? len : 1);              // exact-size copy: reads past `len` are caught
     memcpy(wire, wire_in, len);
-    dapol_ctx ctx{0};
+    dapol_ctx ctx{g_hb};
     int32_t h = 0, agg = 0;
     size_t k = 0, S = 0, bl = 0, cons = 0;
     int32_t rc = dapol_proof_deserialize(&ctx, policy, n_bits, wire, len, &h, &k, &S, &agg, &bl, nullptr, nullptr, nullptr, nullptr, &cons);
     if (rc == DAPOL_OK) {
         uint64_t* leaf = (uint64_t*)malloc(k * 8 ? k * 8 : 1);
         uint8_t* C = (uint8_t*)malloc(S * 32 ? S * 32 : 1);
-        uint8_t* H = (uint8_t*)malloc(S * 32 ? S * 32 : 1);
+        uint8_t* H = (uint8_t*)malloc(S * (size_t)g_hb ? S * (size_t)g_hb : 1);
         uint8_t* blob = (uint8_t*)malloc(bl ? bl : 1);
         rc = dapol_proof_deserialize(&ctx, policy, n_bits, wire, len, &h, &k, &S, &agg, &bl, leaf, C, H, blob, &cons);
         if (rc == DAPOL_OK) {
@@ -75,7 +76,10 @@ int main() {
     struct Shape { int h; size_t k, S; int policy, agg, n_bits; };
     const Shape shapes[] = {{8, 1, 8, DAPOL_POLICY_PADDING, 8, 8}, {8, 1, 8, DAPOL_POLICY_SPLITTING, 5, 8}, {32, 1, 32, DAPOL_POLICY_PADDING, 32, 64},
                             {8, 10, 13, DAPOL_POLICY_SPLITTING, 1, 8}, {6, 1, 6, DAPOL_POLICY_PADDING, 0, 16}, {24, 1, 24, DAPOL_POLICY_SPLITTING, 24, 64}};
+    for (int pass = 0; pass < 2; pass++)                  // 32-byte node hashes, then 64-byte ones (two of the shapes)
     for (const Shape& sh : shapes) {
+        g_hb = pass ? 64 : 32;
+        if (pass && &sh - shapes >= 2 && &sh - shapes != 3) continue;
         std::vector<uint8_t> w = good_wire(sh.h, sh.k, sh.S, sh.policy, sh.agg, sh.n_bits);
         expect("good wire", parse(sh.policy, sh.n_bits, w.data(), w.size()), DAPOL_OK);
         for (size_t cut = 0; cut < w.size(); cut += (w.size() > 4000 ? 7 : 1)) {          // every truncation: an error, never a crash
@@ -87,7 +91,7 @@ int main() {
             const int nmut = 1 + (int)(rnd() % 3);
             for (int j = 0; j < nmut; j++) {
                 size_t pos = (rnd() & 1) ? rnd() % (m.size() < 64 ? m.size() : 64) : rnd() % m.size();
-                if (rnd() % 4 == 0 && m.size() > 700) pos = m.size() - 64 * sh.S - 40 + rnd() % 40;      // the MerkleProof header
+                if (rnd() % 4 == 0 && m.size() > 700) pos = m.size() - (size_t)(32 + g_hb) * sh.S - 40 + rnd() % 40;      // the MerkleProof header
                 if (pos >= m.size()) pos = m.size() - 1;
                 m[pos] = (uint8_t)rnd();
             }
@@ -95,6 +99,7 @@ int main() {
             (void)parse(sh.policy, sh.n_bits, m.data(), m.size());                          // (parse() exits on an accepted inconsistent wire)
         }
     }
+    g_hb = 32;
     // the advisory's example: h = S = 32, no individual proofs, ONE 480-byte aggregated proof (an 8-bit one-party proof's size)
     {
         std::vector<uint8_t> w;

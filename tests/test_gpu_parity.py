@@ -802,7 +802,7 @@ def test_blake2s_dapol_like_the_reference_tests(hip_lib, pyref):
     n = pyref.node_merge(pt.levels[0][2], pt.levels[0][4], "blake2s")
     assert (mC[0].tobytes(), mH[0].tobytes(), int(mv[0])) == (n.C, n.H, 18)
     with pytest.raises(hip_lib.DapolError) as e:
-        hip_lib.Context(0, 8, digest=2)                                   # e.g. Blake2b: 64-byte output
+        hip_lib.Context(0, 8, digest=3)                                   # BLAKE3, Blake2s and (new_blank + build only, tests/test_gpu_blake2b.py) Blake2b
     assert e.value.code == 3                                              # DapolError::InvalidDigestSize
 
 
