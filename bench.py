@@ -268,6 +268,8 @@ def kernel_src_sha():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "dapol_amd", "csrc")
     for f in sorted(os.listdir(d)):
+        if f.startswith(".") or not os.path.isfile(os.path.join(d, f)):
+            continue                                  # (sources only: a stray cache directory is not part of the build)
         h.update(f.encode())
         h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]

@@ -534,7 +534,10 @@ class Tape:
 
 def pad_blinding(pad_seed: bytes, height_from_leaves: int, index: int) -> int:
     """Blinding of the padding node at (level above leaves, index in that level): positional, order-free.
-    Stands in for Scalar::random(thread_rng()) at src/dapol/node.rs:87."""
+    Stands in for Scalar::random(thread_rng()) at src/dapol/node.rs:87.  TAPE mode: pad_seed is a dict
+    {(level, index): the node's 64-byte draw} (dapol_tree_build_tape; what a harness around the real crate records)."""
+    if isinstance(pad_seed, dict):
+        return scalar_from_wide(pad_seed[(height_from_leaves, index)])
     return scalar_from_wide(seed_wide(pad_seed, DOMAIN_PAD, height_from_leaves, index))
 
 

@@ -18,6 +18,8 @@ def kernel_src_sha():
     h = hashlib.sha256()
     d = os.path.join(root, "dapol_amd", "csrc")
     for f in sorted(os.listdir(d)):
+        if f.startswith(".") or not os.path.isfile(os.path.join(d, f)):
+            continue                                  # (as bench.kernel_src_sha: sources only)
         h.update(f.encode())
         h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
