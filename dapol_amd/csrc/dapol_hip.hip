@@ -8,6 +8,7 @@
 #include <cstring>
 #include <algorithm>
 #include <atomic>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -111,6 +112,7 @@ struct dapol_ctx {
     hipStream_t stream = nullptr;
     hipStream_t side[3] = {nullptr, nullptr, nullptr};   // further pipelines of the range prover (several chunks in flight)
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_v[4] = {nullptr, nullptr, nullptr, nullptr};   // the verifier's commitments landing in column blocks (host_verify.inc: VArrival)
     // Opt-in experiment (DAPOL_MSM_SERIAL=1, measured slower): the generator-stationary MSMs of ALL chunks in flight through ONE
     // stream, one sweep at a time, the other chunks' scalar kernels beside it.  ev_msm_pre / _post[chunk lane] order a chunk's own
     // stream around its MSMs.
@@ -126,6 +128,8 @@ struct dapol_ctx {
     DevBuf<uint32_t> gens_comp;  // compressed base points of every row (for dapol_ctx_generator)
     TableView tv{};
     RangeScratch scratch;        // grown on demand by the range prover
+    RangeScratch vio;            // dapol_range_verify_batch's device copies of the caller's proofs / commitments / verdicts: kept between calls
+                                 // (a 34 MB hipMalloc + hipFree per call is a few hundred microseconds of a 7 ms pass; at most 1 GB is kept)
 };
 
 // Width of the context's node hash D: 8 words (BLAKE3, Blake2s) or 16 (Blake2b).  Every H buffer of the C ABI holds this many
@@ -326,6 +330,7 @@ int32_t dapol_ctx_create_opts(int32_t device, int32_t max_parties, int32_t diges
         HIPCHK(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
     }
     HIPCHK(hipStreamCreate(&c->msm_stream));
+    for (int i = 0; i < 4; i++) HIPCHK(hipEventCreateWithFlags(&c->ev_v[i], hipEventDisableTiming));
     for (int i = 0; i < 4; i++) {
         HIPCHK(hipEventCreateWithFlags(&c->ev_msm_pre[i], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->ev_msm_post[i], hipEventDisableTiming));
@@ -405,6 +410,7 @@ int32_t dapol_ctx_destroy(dapol_ctx* ctx) {
     if (ctx->refs.fetch_sub(1) > 1) return DAPOL_OK;          // trees / workloads still use it: the last of them frees it
     (void)hipSetDevice(ctx->device);
     ctx->scratch.release();
+    ctx->vio.release();
     ctx->table.release();
     ctx->gens_comp.release();
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -413,6 +419,7 @@ int32_t dapol_ctx_destroy(dapol_ctx* ctx) {
         if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
     }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    for (int i = 0; i < 4; i++) if (ctx->ev_v[i]) (void)hipEventDestroy(ctx->ev_v[i]);
     if (ctx->msm_stream) (void)hipStreamDestroy(ctx->msm_stream);
     for (int i = 0; i < 2; i++) {
         if (ctx->layout_lane[i]) (void)hipStreamDestroy(ctx->layout_lane[i]);

@@ -78,7 +78,11 @@ __device__ __forceinline__ bool words_zero(const uint32_t* w) {
 //    permutations (ds_bpermute) and a dozen ALU operations per round instead of ~500.
 // The state it leaves in vs.st / st_pos / st_pos_begin is bit for bit what the lane-per-proof loop would hold.
 enum { RV_V_BYTES = 41 };            // stream bytes per commitment
-__global__ __launch_bounds__(64) void k_rv_absorb_V(VerifyArgs V) {
+// PHASES (round 5): the kernel absorbs the stream blocks that lie entirely inside commitments [0, j1) and were not absorbed by the
+// phases before it (which had commitments [0, j0)), carrying the state through vs.st -- so that a host whose commitments are still
+// on their way over PCIe can start the replay on the first quarter of every proof's commitments while the next quarter is being
+// copied (dapol_range_verify_batch).  One phase (j0 = 0, j1 = m) is the whole thing.
+__global__ __launch_bounds__(64) void k_rv_absorb_V(VerifyArgs V, int j0, int j1) {
     __shared__ uint64_t sh[25];
     const RangeArgs& A = V.R;
     const size_t b = blockIdx.x;
@@ -93,11 +97,16 @@ __global__ __launch_bounds__(64) void k_rv_absorb_V(VerifyArgs V) {
     if (l == 0)
         for (int i = 0; i < 25; i++) sh[i] = s.s[i];
     __syncthreads();
-    uint64_t a = l < 25 ? sh[l] : 0;
+    VerifyState& vs = V.vs[b];
+    uint64_t a = l < 25 ? (j0 > 0 ? vs.st[l] : sh[l]) : 0;
     KeccakLanes K;
     keccak_lanes_init(K, l);
     const uint8_t* Vb = reinterpret_cast<const uint8_t*>(A.Vc + b * (size_t)A.m * 8);
     const uint32_t total = RV_V_BYTES * (uint32_t)A.m, end_abs = pos0 + total, nfull = end_abs / STROBE_R;
+    const bool last_phase = j1 >= A.m;
+    // blocks whose every byte belongs to a commitment below j: floor((41 j + pos0) / 166)
+    const uint32_t beta_begin = j0 > 0 ? (RV_V_BYTES * (uint32_t)j0 + pos0) / STROBE_R : 0u;
+    const uint32_t beta_end = last_phase ? nfull : (RV_V_BYTES * (uint32_t)j1 + pos0) / STROBE_R;
     // This lane's eight bytes of block beta, without branches: in-block position q = 8 l + i  <->  stream offset
     // k = 166 beta + q - pos0  <->  commitment j = k / 41, byte t = k mod 41 of its record.  The two position bytes: the
     // begin_op they belong to follows the previous one by d = 34 (t = 0) or 7 (t = 7) bytes, so STROBE's old pos_begin is
@@ -124,8 +133,8 @@ __global__ __launch_bounds__(64) void k_rv_absorb_V(VerifyArgs V) {
         }
         return w;
     };
-    uint64_t w = block_word(0);
-    for (uint32_t beta = 0; beta < nfull; beta++) {
+    uint64_t w = (beta_begin < beta_end || last_phase) ? block_word(beta_begin) : 0;
+    for (uint32_t beta = beta_begin; beta < beta_end; beta++) {
         a ^= w;
         if (l == 20) {                                            // run_f: pos_begin at byte 166, 0x04 and 0x80 at byte 167
             uint32_t k_end = beta * STROBE_R + (STROBE_R - 1) - pos0, je = k_end / RV_V_BYTES, te = k_end - je * RV_V_BYTES;
@@ -133,13 +142,12 @@ __global__ __launch_bounds__(64) void k_rv_absorb_V(VerifyArgs V) {
             uint32_t pbe = ab >= beta * STROBE_R ? ab % STROBE_R + 1 : (beta == 0 ? pb0 : 0u);
             a ^= ((uint64_t)pbe << 48) | (0x84ull << 56);
         }
-        w = block_word(beta + 1);                                 // the next block's bytes load while this one is permuted
-        a = keccak_f1600_wave(a, K, l);
+        if (beta + 1 < beta_end || last_phase) w = block_word(beta + 1);   // the next block's bytes load while this one is permuted
+        a = keccak_f1600_wave(a, K, l);                                    // (never a block this phase's commitments do not cover)
     }
-    a ^= w;                                                       // the bytes after the last permutation
-    VerifyState& vs = V.vs[b];
+    if (last_phase) a ^= w;                                       // the bytes after the last permutation
     if (l < 25) vs.st[l] = a;
-    if (l == 0) {
+    if (l == 0 && last_phase) {
         uint32_t kb = RV_V_BYTES * ((uint32_t)A.m - 1) + 7;       // the last begin_op
         vs.st_pos = end_abs % STROBE_R;
         vs.st_pos_begin = (pos0 + kb) / STROBE_R == nfull ? (pos0 + kb) % STROBE_R + 1 : 0u;
@@ -882,6 +890,42 @@ __global__ __launch_bounds__(64) void k_rvb_gh_reduce(RlcArgs R) {
     sc_zero(acc);
     for (int g = 0; g < R.G; g++) { ld_sc(t, R.partial + (size_t)g * A.TP + pos); sc_add(acc, acc, t); }
     write_digits(A, 0, pos, acc);
+}
+// The ONE generator MSM of a large batch without a doubling in its loop (round 5).  As k_rp_msm<0, .> with B = 1 it was 1,024
+// wavefronts walking 22 window steps of 12 shared doublings each for ~44 additions per lane: 252 doublings per lane, six times the
+// additions (0.97 ms, 1.8 ms beside the own-point branch).  Here a wavefront owns (window w, slice s of the 2N terms): additions only
+// (k_rvb_gen_sweep), the slices of a window are summed and scaled by 2^(W w) by one wavefront per window (k_rvb_gen_windows), and
+// k_rvb_finish adds the nwin window points like any other partial sums.  The doublings that remain are ONE chain of W (nwin - 1) on
+// a lone lane per window -- latency that runs beside the own-point branch, not work.  Same digits, same rows, same point.
+__global__ __launch_bounds__(64) void k_rvb_gen_sweep(RangeArgs A, TableView tbl, int NS, int32_t* part /* [nwin][NS][40] */) {
+    const int w = blockIdx.x / NS, s = blockIdx.x % NS, l = threadIdx.x;
+    const dig_t* dw = A.dig + (size_t)w * A.TP;
+    ge_p3 acc;
+    ge_identity(acc);
+#pragma nounroll
+    for (int t = s * 64 + l; t < 2 * A.N; t += NS * 64) {
+        const int side = t >= A.N ? 1 : 0, q = t - side * A.N;
+        const int d = dw[64 * (q >> 5) + (q & 31) + 32 * side];
+        bool isH;
+        const int j = term_generator(-1, A.N, A.lgN, side, q, isH);
+        tbl_madd(acc, tbl, gen_row(tbl, A.n, j, isH), d);
+    }
+    wave_reduce_point(acc, 64);
+    if (l == 0) st_p3(part + ((size_t)w * NS + s) * 40, acc);
+}
+__global__ __launch_bounds__(64) void k_rvb_gen_windows(RangeArgs A, int NS, const int32_t* part) {
+    const int w = blockIdx.x, l = threadIdx.x;
+    ge_p3 acc, p, t;
+    ge_identity(acc);
+    for (int i = l; i < NS; i += 64) { ld_p3(p, part + ((size_t)w * NS + i) * 40); ge_add(t, acc, p); acc = t; }
+    wave_reduce_point(acc, 64);
+    if (l == 0) {
+        const int nd = A.wbits * w;
+        for (int i = 0; i < nd; i++) { ge_dbl(t, acc, i == nd - 1); acc = t; }
+        st_p3(A.P0 + (size_t)w * 40, acc);
+        ge_identity(t);
+        st_p3(A.P1 + (size_t)w * 40, t);
+    }
 }
 // rho_p-weighted scalars of B_blinding and B (lane per proof).
 __global__ __launch_bounds__(64) void k_rvb_base_scalars(RlcArgs R) {

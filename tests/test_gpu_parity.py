@@ -1800,6 +1800,23 @@ def test_config4_1024_proofs_of_1024_parties_with_oracle_verdict(hip_lib, ref):
     bad[513, 64] ^= 1
     ok = ctx.range_verify_batch(64, m, bad, V)
     assert ok[0] == 0 and ok[513] == 0 and ok.sum() == b - 2
+    # Round 5: the commitments of such a batch travel in four column blocks while the transcript replay runs in four phases behind
+    # them (host_verify.inc: VArrival; k_rv_absorb_V(j0, j1)).  A commitment changed in any of the blocks -- first and last byte of a
+    # block included -- turns exactly its proof's verdict, and the one-copy path (DAPOL_VERIFY_NO_PIPELINE) gives the same vector.
+    import os
+    Vbad = V.copy()
+    hits = {3: (0, 0), 100: (255, 31), 400: (256, 0), 777: (600, 17), 1000: (1023, 31), 1023: (768, 5)}
+    for pi, (j, byte) in hits.items():
+        Vbad[pi, j, byte] ^= 0x10
+    ok_pipe = ctx.range_verify_batch(64, m, proofs, Vbad, verify_seed=SEED)
+    assert sorted(np.nonzero(ok_pipe == 0)[0].tolist()) == sorted(hits) and ok_pipe.sum() == b - len(hits)
+    os.environ["DAPOL_VERIFY_NO_PIPELINE"] = "1"
+    try:
+        ok_one = ctx.range_verify_batch(64, m, proofs, Vbad, verify_seed=SEED)
+        assert ctx.range_verify_batch(64, m, proofs, V).all()
+    finally:
+        del os.environ["DAPOL_VERIFY_NO_PIPELINE"]
+    assert ok_one.tolist() == ok_pipe.tolist()
     p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
     c32 = bytes(range(1, 33))
     V0 = np.ascontiguousarray(V[0])
