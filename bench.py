@@ -313,8 +313,11 @@ def rank_decomposition(per_rank, keys, world, exchange_path):
     a rank that finishes its build early waits in the all-gather) and, when the library's communicator carried them, the device
     microseconds from HIP events around ncclAllGather / the top-level merge / ncclAllReduce.  The all-gather's own latency is its
     MINIMUM over the ranks (the last rank to arrive waits for nobody); max - min is the arrival skew."""
+    import warnings
     a = np.asarray(per_rank, np.float64)                     # [R][S][K]
-    mean = np.nanmean(a, axis=1) if a.shape[1] else np.zeros((a.shape[0], len(keys)))
+    with warnings.catch_warnings():                          # (a column of NaNs -- no library communicator -- is a None in the line, not a warning)
+        warnings.simplefilter("ignore", category=RuntimeWarning)
+        mean = np.nanmean(a, axis=1) if a.shape[1] else np.zeros((a.shape[0], len(keys)))
     col = {k: mean[:, i] for i, k in enumerate(keys)}
 
     def spread(x):
