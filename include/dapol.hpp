@@ -59,18 +59,22 @@ struct DapolNode {
 
 class Context {                                // PedersenGens::default() + BulletproofGens::new(64, m), once
   public:
-    // digest = the node hash D of Dapol<D, R>: DAPOL_DIGEST_BLAKE3 or DAPOL_DIGEST_BLAKE2S
+    // digest = the node hash D of Dapol<D, R>: DAPOL_DIGEST_BLAKE3 or DAPOL_DIGEST_BLAKE2S.  This mirror's node types carry 32-byte
+    // hashes (Bytes32), like Dapol::new's DIGEST_SIZE check (src/dapol/mod.rs:101-103): the 64-byte DAPOL_DIGEST_BLAKE2B of the
+    // new_blank + build path is served by the C ABI itself (include/dapol_hip.h), and is refused HERE before any buffer could be too small.
     // max_parties = the largest aggregation a proof may need, rounded up to a power of two: 32 serves trees up to height 32
     // (aggregation_factor <= tree_height), 64 the reference's whole range (MAX_TREE_HEIGHT = 64, src/dapol/mod.rs:26)
-    explicit Context(int device = 0, int max_parties = 32, int digest = DAPOL_DIGEST_BLAKE3) { check(dapol_ctx_create(device, max_parties, digest, &h_)); }
+    explicit Context(int device = 0, int max_parties = 32, int digest = DAPOL_DIGEST_BLAKE3) { digest32(digest); check(dapol_ctx_create(device, max_parties, digest, &h_)); }
     // ... with settings (dapol_options: zeros = the library's own choices; options.struct_size is filled in here)
     Context(int device, int max_parties, int digest, dapol_options options) {
+        digest32(digest);
         options.struct_size = (int32_t)sizeof(dapol_options);
         check(dapol_ctx_create_opts(device, max_parties, digest, &options, &h_));
     }
     dapol_options options() const { dapol_options o{}; check(dapol_ctx_get_options(h_, &o)); return o; }
     void set_options(dapol_options o) { o.struct_size = (int32_t)sizeof(dapol_options); check(dapol_ctx_set_options(h_, &o)); }
     ~Context() { dapol_ctx_destroy(h_); }
+    static void digest32(int digest) { if (digest != DAPOL_DIGEST_BLAKE3 && digest != DAPOL_DIGEST_BLAKE2S) throw DapolError(DAPOL_ERR_INVALID_DIGEST_SIZE); }
     Context(const Context&) = delete;
     Context& operator=(const Context&) = delete;
     dapol_ctx* get() const { return h_; }
