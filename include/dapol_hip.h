@@ -191,7 +191,11 @@ int32_t dapol_tree_destroy(dapol_tree* tree);
  * an index outside the tree or the shard, an allocation that failed) leaves the tree unchanged.  Small batches are re-merged IN
  * PLACE on the device; a HIP failure between the first and the last write of such an update leaves upper levels that no longer
  * match the leaves: the tree is then marked invalid and every later call on it returns DAPOL_ERR_INVALID_ARGUMENT ("left
- * inconsistent ...") -- destroy it and build it again. */
+ * inconsistent ...") -- destroy it and build it again.  The same holds for a batch that mixes new and existing indexes once its
+ * inserts have been applied: whatever stops the replacements after that -- also an error before THEIR first write -- would leave a
+ * consistent but half-updated tree, so the tree is marked invalid too (never "unchanged" with half the batch in).
+ * On a context with a 64-byte digest the whole hash chain is laid again after the update; a tree built from a padding tape
+ * (dapol_tree_build_tape) cannot be updated. */
 int32_t dapol_tree_update(dapol_tree* tree, size_t k, const uint64_t* leaf_idx, const uint64_t* v, const uint8_t* r32);
 /* What the last dapol_tree_update on this tree did: 0 = rebuilt, 1 = replaced existing leaves in place, 2 = inserted new leaves in
  * place, 3 = both (diagnostics; the tree is the same whichever path ran). */

@@ -130,3 +130,28 @@ def test_library_communicator_and_agreement_group_beside_torch_rccl(hip_lib):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     out = subprocess.run([sys.executable, "-c", _ONE_RANK_RCCL % {"root": ROOT, "port": port}], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ONE-RANK-RCCL-OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+
+
+@pytest.mark.gpu
+def test_preflight_one_rccl_rank_and_two_gloo_ranks(hip_lib):
+    """`bench.py --gpus N --preflight`: < 30 s, no proving.  With the one rank a 1-GPU box has, over RCCL: the
+    library's communicator comes up non-blocking, ncclCommCount == 1, 100 rounds of the step's two collectives through the transport
+    (library call + agreement), the HIP-event timings are there.  With two ranks sharing the GPU over gloo: the same flow through
+    torch.distributed, every rank's global root equal and equal to the torch path's."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "DAPOL_BENCH_BACKEND")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--preflight"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["ok"] and d["n_gpus"] == 1 and d["backend"] == "nccl" and all(d["checks"].values())
+    assert d["checks"]["library_communicator_up"] and d["checks"]["nccl_comm_count_equals_n"] and d["rccl_ranks_in_library_communicator"] == 1
+    t = d["timings"]
+    assert t["exchange_host"]["iters"] == 100 and t["library_device_us"]["exchanges"] == 100 and t["library_device_us"]["reduces"] == 100
+    assert 0 < t["library_device_us"]["allgather_mean"] < 5000 and 0 < t["library_device_us"]["allreduce_mean"] < 5000
+    assert d["wall_s_since_process_start"] < 120                           # (the first `import torch` of a fresh box is most of it)
+    two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--preflight", "--preflight-iters", "20"], cwd=ROOT,
+                         env=dict(env, DAPOL_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=300)
+    assert two.returncode == 0, two.stderr[-2000:]
+    d2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    assert d2["ok"] and d2["n_gpus"] == 2 and all(d2["checks"].values()) and d2["checks"]["library_root_equals_torch_path_root"]
+    assert "gloo" in d2["exchange_path"] and d2["timings"]["exchange_host_torch"]["iters"] == 4

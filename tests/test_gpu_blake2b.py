@@ -169,3 +169,44 @@ def test_blake2b_is_refused_where_the_reference_refuses_it(hip_lib):
     assert e.value.code == 3
     tree = hip_lib.Tree(ctx, 8, idx, v, r, SEED)                         # new_blank + build: fine
     assert len(tree.root()[1]) == 64
+
+
+def test_blake2b_large_tree_levelwise_build(hip_lib, pyref):
+    """20,000 leaves at height 40 (indexes beyond 2^32; above 8,192 leaves the tree is built level by level, below by phases): the
+    64-byte chain over the level-wise build.  The root's hash recomputed with hashlib from the two nodes below it; for sampled leaves the
+    path hashes re-merged with hashlib from the leaf up (commitments from the library: the digest does not touch them) reach the root;
+    the sampled inclusion proofs verify; and the tree agrees with the BLAKE3 tree of the same leaves in everything but its hashes."""
+    ctx = hip_lib.Context(0, 64, digest=hip_lib.DIGEST_BLAKE2B)
+    ctx3 = hip_lib.Context(0, 64)
+    height, n = 40, 20000
+    rng = np.random.default_rng(40)
+    idx, v, r = _rand_leaves(rng, height, n)
+    n = len(idx)
+    tree, t3 = hip_lib.Tree(ctx, height, idx, v, r, SEED), hip_lib.Tree(ctx3, height, idx, v, r, SEED)
+    rC, rH, rv, rr = tree.root()
+    assert (rC, rv, rr) == (t3.root()[0], t3.root()[2], t3.root()[3]) and len(rH) == 64 and tree.node_count() == t3.node_count()
+    li, lv, lr, lC, lH, pad = tree.level_nodes(height - 1)
+    top = {int(i): (c.tobytes(), h.tobytes()) for i, c, h in zip(li, lC, lH)}
+    assert rH == H2B(top[0][0], top[1][0], top[0][1], top[1][1])
+    who = idx[:: n // 6][:6]
+    pos = np.searchsorted(idx, who)
+    lC, lH = ctx.commit_hash_batch(v[pos], r[pos])
+    pC, pH, proofs = tree.prove_entities(who, hip_lib.POLICY_SPLITTING, height, 64, SEED)
+    c3, h3, p3 = t3.prove_entities(who, hip_lib.POLICY_SPLITTING, height, 64, SEED)
+    assert pC.tobytes() == c3.tobytes() and proofs.tobytes() == p3.tobytes() and pH.shape == (6, height, 64)
+    # the ancestors' commitments are the BLAKE3 tree's (same points): take them from its Merkle re-merge, i.e. from pyref on the path
+    for e, leaf in enumerate(who):
+        C, Hh = pyref.decompress(lC[e].tobytes()), lH[e].tobytes()
+        assert Hh == H2B(lC[e].tobytes())
+        Cb = lC[e].tobytes()
+        for k in range(height):                                          # siblings are root side first: level k's sits at height - 1 - k
+            sC, sH = pC[e, height - 1 - k].tobytes(), pH[e, height - 1 - k].tobytes()
+            Hh = H2B(sC, Cb, sH, Hh) if (int(leaf) >> k) & 1 else H2B(Cb, sC, Hh, sH)
+            C = C + pyref.decompress(sC)
+            Cb = C.compress()
+        assert (Cb, Hh) == (rC, rH), e
+    assert ctx.verify_entities(height, who, lC, lH, pC, pH, rC, rH, hip_lib.POLICY_SPLITTING, height, 64, proofs).all()
+    bad = pH.copy()
+    bad[2, 17, 60] ^= 2
+    ok = ctx.verify_entities(height, who, lC, lH, pC, bad, rC, rH, hip_lib.POLICY_SPLITTING, height, 64, proofs)
+    assert ok.tolist() == [1, 1, 0, 1, 1, 1]
