@@ -891,6 +891,25 @@ __global__ __launch_bounds__(64) void k_rvb_gh_reduce(RlcArgs R) {
     for (int g = 0; g < R.G; g++) { ld_sc(t, R.partial + (size_t)g * A.TP + pos); sc_add(acc, acc, t); }
     write_digits(A, 0, pos, acc);
 }
+// acc (lane 0's point) <- 2^nd acc, with the wavefront's first four lanes doing every doubling TOGETHER (ge_quad.h: lane k holds
+// coordinate k; a doubling is one squaring + one product deep instead of 3 + 4 on a lone lane).  The window sums of the bucket method
+// and of the doubling-free generator MSM end in such chains -- up to 252 doublings on a lone lane of a lone wavefront, the serial
+// tail of a verification pass.  Every lane of the wavefront must call this (the other groups double copies; nobody reads them).
+__device__ __forceinline__ void wave_dbl_chain(ge_p3& acc, int nd, int l) {
+    if (nd <= 0) return;
+    const int ql = l & 3;
+    fe c;
+    for (int i = 0; i < FE_NL; i++) {
+        const int x = __shfl(acc.X.v[i], 0, 64), y = __shfl(acc.Y.v[i], 0, 64), z = __shfl(acc.Z.v[i], 0, 64), t = __shfl(acc.T.v[i], 0, 64);
+        c.v[i] = ql == 0 ? x : ql == 1 ? y : ql == 2 ? z : t;
+    }
+#pragma nounroll
+    for (int i = 0; i < nd; i++) quad_dbl(c, ql);
+    for (int i = 0; i < FE_NL; i++) {
+        acc.X.v[i] = __shfl(c.v[i], 0, 64); acc.Y.v[i] = __shfl(c.v[i], 1, 64);
+        acc.Z.v[i] = __shfl(c.v[i], 2, 64); acc.T.v[i] = __shfl(c.v[i], 3, 64);
+    }
+}
 // The ONE generator MSM of a large batch without a doubling in its loop (round 5).  As k_rp_msm<0, .> with B = 1 it was 1,024
 // wavefronts walking 22 window steps of 12 shared doublings each for ~44 additions per lane: 252 doublings per lane, six times the
 // additions (0.97 ms, 1.8 ms beside the own-point branch).  Here a wavefront owns (window w, slice s of the 2N terms): additions only
@@ -919,9 +938,8 @@ __global__ __launch_bounds__(64) void k_rvb_gen_windows(RangeArgs A, int NS, con
     ge_identity(acc);
     for (int i = l; i < NS; i += 64) { ld_p3(p, part + ((size_t)w * NS + i) * 40); ge_add(t, acc, p); acc = t; }
     wave_reduce_point(acc, 64);
+    wave_dbl_chain(acc, A.wbits * w, l);
     if (l == 0) {
-        const int nd = A.wbits * w;
-        for (int i = 0; i < nd; i++) { ge_dbl(t, acc, i == nd - 1); acc = t; }
         st_p3(A.P0 + (size_t)w * 40, acc);
         ge_identity(t);
         st_p3(A.P1 + (size_t)w * 40, t);
@@ -1139,8 +1157,9 @@ __global__ __launch_bounds__(64) void k_rvp_window(RlcArgs R) {
     if (l == 0) {
         for (int i = 1; i < L; i <<= 1) { ge_dbl(t, U, 2 * i >= L); U = t; }  // times L
         ge_add(t, aseg, U);
-        const int nd = RVP_C * w;
-        for (int i = 0; i < nd; i++) { ge_p3 d2; ge_dbl(d2, t, i == nd - 1); t = d2; }
+    }
+    wave_dbl_chain(t, RVP_C * w, l);                              // times 2^(C w): the four-lane doubling chain (lane 0's point)
+    if (l == 0) {
         st_p3(R.Q0 + (size_t)w * 40, t);
         ge_identity(t);
         st_p3(R.Q1 + (size_t)w * 40, t);
@@ -1169,12 +1188,27 @@ __global__ __launch_bounds__(64) void k_rvb_finish(RlcArgs R, TableView tbl) {
     }
     wave_reduce_sc(bb);
     wave_reduce_sc(bs);
+    // bb * B_blinding + bs * B: the low half-wavefront looks bb's windows up in B_blinding's per-window rows, the high half bs's in
+    // B's (tbl_fixed_mul_wave: one lookup and a five-deep shuffle tree per product, nwin <= 32 as W >= WBITS_MIN = 8) -- instead of
+    // 2 nwin dependent additions on lane 0.
+    {
+        sc sel;
+        for (int i = 0; i < 8; i++) {
+            const uint32_t b0 = (uint32_t)__shfl((int)bb.v[i], 0, 64), s0 = (uint32_t)__shfl((int)bs.v[i], 0, 64);
+            sel.v[i] = l < 32 ? b0 : s0;
+        }
+        uint32_t k8[8];
+        sc_from_mont(k8, sel);
+        ge_p3 term, other;
+        tbl_fixed_mul_wave(term, tbl, l < 32 ? tbl.row_Bb(0) : tbl.row_B(0), k8, l & 31);      // valid on lanes 0 and 32
+        for (int i = 0; i < FE_NL; i++) {
+            other.X.v[i] = __shfl(term.X.v[i], 32, 64); other.Y.v[i] = __shfl(term.Y.v[i], 32, 64);
+            other.Z.v[i] = __shfl(term.Z.v[i], 32, 64); other.T.v[i] = __shfl(term.T.v[i], 32, 64);
+        }
+        if (l == 0) { ge_add(t, acc, term); ge_add(acc, t, other); }
+    }
     if (l == 0) {
-        uint32_t k8[8], c8[8];
-        sc_from_mont(k8, bb);
-        tbl_fixed_mul_add(acc, tbl, tbl.row_Bb(0), k8);
-        sc_from_mont(k8, bs);
-        tbl_fixed_mul_add(acc, tbl, tbl.row_B(0), k8);
+        uint32_t c8[8];
         ge_compress(c8, acc);
         R.flag[0] = words_zero(c8) ? 1u : 0u;
     }

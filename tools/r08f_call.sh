@@ -11,9 +11,13 @@ python3 - "$f" >> $OUT/r08f_verify_timeline.txt <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "k_rv_absorb_V" in r["Kernel_Name"]]
-a, b = idx[-2], idx[-1]
-print("pass-to-pass (absorb_V start to next absorb_V start): %.3f ms" % ((int(rows[b]["Start_Timestamp"]) - int(rows[a]["Start_Timestamp"])) / 1e6))
+tr = [i for i, r in enumerate(rows) if "k_rv_transcript" in r["Kernel_Name"]]          # one per pass (k_rv_absorb_V runs once per column block)
+def first_absorb(before):
+    i = before
+    while i > 0 and not any(k in rows[i - 1]["Kernel_Name"] for k in ("k_rvb_verdicts", "copyBuffer")): i -= 1
+    return next(j for j in range(i, before + 1) if "k_rv_absorb_V" in rows[j]["Kernel_Name"])
+a, b = first_absorb(tr[-2]), first_absorb(tr[-1])
+print("pass-to-pass (first absorb_V start to the next pass's): %.3f ms" % ((int(rows[b]["Start_Timestamp"]) - int(rows[a]["Start_Timestamp"])) / 1e6))
 fin = [i for i in range(a, b) if "k_rvb_verdicts" in rows[i]["Kernel_Name"]][-1]
 print("absorb_V start -> verdicts end: %.3f ms" % ((int(rows[fin]["End_Timestamp"]) - int(rows[a]["Start_Timestamp"])) / 1e6))
 PY
