@@ -12,13 +12,13 @@ R=$(pwd); OUT=$R/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
 python3 bench.py --mode verify --steps 20 > $OUT/${tag}_verify_bench.json 2> $OUT/${tag}_verify_bench.err || { tail -5 $OUT/${tag}_verify_bench.err; exit 1; }
 tail -c 700 $OUT/${tag}_verify_bench.json; echo
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${tag}_vstats -o stats -- python3 $R/bench.py --mode verify --no-cpu-baseline --no-bad-proof-leg --warmup 1 --steps 20 > $OUT/${tag}_vstats.log 2>&1 || { tail -5 $OUT/${tag}_vstats.log; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${tag}_vstats -o stats -- python3 $R/bench.py --mode verify --no-cpu-baseline --no-bad-proof-leg --no-pinned-leg --warmup 1 --steps 20 > $OUT/${tag}_vstats.log 2>&1 || { tail -5 $OUT/${tag}_vstats.log; exit 1; }
 cp $(find $OUT/${tag}_vstats -name "*kernel_stats.csv" | head -1) $OUT/${tag}_verify_kernel_stats.csv
 rm -rf $OUT/${tag}_vstats
 echo "stats done"
 for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE"; do
   n=$(echo $c | cut -d' ' -f1)
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/${tag}_vpmc_$n -o pmc -- python3 $R/bench.py --mode verify --no-cpu-baseline --no-bad-proof-leg --warmup 1 --steps 5 > $OUT/${tag}_vpmc_$n.log 2>&1 || { tail -5 $OUT/${tag}_vpmc_$n.log; exit 1; }
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/${tag}_vpmc_$n -o pmc -- python3 $R/bench.py --mode verify --no-cpu-baseline --no-bad-proof-leg --no-pinned-leg --warmup 1 --steps 5 > $OUT/${tag}_vpmc_$n.log 2>&1 || { tail -5 $OUT/${tag}_vpmc_$n.log; exit 1; }
   echo "pmc $n done"
 done
 cd $R

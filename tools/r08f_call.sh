@@ -3,7 +3,7 @@
 set -o pipefail
 R=$(pwd); OUT=$R/gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT/r08f_vtrace -o t -- python3 $R/bench.py --mode verify --no-cpu-baseline --no-bad-proof-leg --warmup 1 --steps 5 > $OUT/r08f_vtrace.log 2>&1 || { tail -5 $OUT/r08f_vtrace.log; exit 1; }
+rocprofv3 --kernel-trace --output-format csv -d $OUT/r08f_vtrace -o t -- python3 $R/bench.py --mode verify --no-cpu-baseline --no-bad-proof-leg --no-pinned-leg --warmup 1 --steps 5 > $OUT/r08f_vtrace.log 2>&1 || { tail -5 $OUT/r08f_vtrace.log; exit 1; }
 cd $R
 f=$(find $OUT/r08f_vtrace -name "*kernel_trace.csv" | head -1)
 python3 tools/kernel_timeline.py $f k_rv_transcript 1 40 > $OUT/r08f_verify_timeline.txt
