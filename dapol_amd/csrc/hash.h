@@ -441,52 +441,73 @@ DAPOL_HD void strobe_reset(Strobe& st) {                   // the state before S
 
 #if defined(__HIPCC__)
 // The same STROBE state held by ONE WAVEFRONT: lane x + 5 y keeps word (x, y) of the Keccak state, the permutation is nine lane
-// permutations and a dozen ALU operations per round instead of ~500 instructions on a lane (kernels_verify.h, k_rv_absorb_V),
+// permutations and ~30 ALU operations per round instead of ~500 instructions on a lane (kernels_verify.h, k_rv_absorb_V),
 // and every lane follows the byte stream in step (all 64 lanes call every function below with the same arguments).  Used by the
 // calls of few proofs, where a lane's 23 us per permutation is what the caller waits for.
 __device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) {
     uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src, 64), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64);
     return ((uint64_t)hi << 32) | lo;
 }
-struct KeccakLanes {                 // per-lane source lanes of the round's permutations
-    int th1, th2, th3, th4, xp1, xp2, pi_src, cm_src, cp_src, rot_src;
+struct KeccakLanes {                 // per-lane sources of the round's permutations, as ds_bpermute byte addresses (lane << 2)
+    int th1, th2, th3, th4, xp1, xp2, pi_src, cm_src, cp_src;
+    uint32_t rot_sh;                 // rho: the source word's rotation amount mod 32 ...
+    bool rot_swap;                   // ... and whether it is >= 32 (the halves swap first)
 };
 __device__ __forceinline__ void keccak_lanes_init(KeccakLanes& K, int l) {
     const int ROT[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
-    if (l >= 25) { K.th1 = K.th2 = K.th3 = K.th4 = K.xp1 = K.xp2 = K.pi_src = K.cm_src = K.cp_src = l; K.rot_src = 0; return; }
+    if (l >= 25) { K.th1 = K.th2 = K.th3 = K.th4 = K.xp1 = K.xp2 = K.pi_src = K.cm_src = K.cp_src = l << 2; K.rot_sh = 0; K.rot_swap = false; return; }
     int x = l % 5, y = l / 5, row = 5 * y;
-    K.th1 = (l + 5) % 25; K.th2 = (l + 10) % 25; K.th3 = (l + 15) % 25; K.th4 = (l + 20) % 25;
-    K.xp1 = row + (x + 1) % 5; K.xp2 = row + (x + 2) % 5;
+    K.th1 = ((l + 5) % 25) << 2; K.th2 = ((l + 10) % 25) << 2; K.th3 = ((l + 15) % 25) << 2; K.th4 = ((l + 20) % 25) << 2;
+    K.xp1 = (row + (x + 1) % 5) << 2; K.xp2 = (row + (x + 2) % 5) << 2;
     // pi: B[x'][y'] = rot(A[x][y]) with (x', y') = (y, 2x + 3y): lane (x', y') pulls from y = x', x = 3 (y' - 3 x') mod 5
     int sy = x, sx = (3 * ((y - 3 * x) % 5 + 5)) % 5;
-    K.pi_src = sx + 5 * sy;
-    K.cm_src = (sx + 4) % 5;         // any lane of column sx - 1 / sx + 1 holds that column's parity: row 0
-    K.cp_src = (sx + 1) % 5;
+    const int src = sx + 5 * sy;
+    K.pi_src = src << 2;
+    K.cm_src = ((sx + 4) % 5) << 2;  // any lane of column sx - 1 / sx + 1 holds that column's parity: row 0
+    K.cp_src = ((sx + 1) % 5) << 2;
     int r = 0;
-    for (int i = 0; i < 25; i++) r = (i == K.pi_src) ? ROT[i] : r;
-    K.rot_src = r;
+    for (int i = 0; i < 25; i++) r = (i == src) ? ROT[i] : r;
+    K.rot_sh = (uint32_t)r & 31u;
+    K.rot_swap = r >= 32;
+}
+struct KeccakWord { uint32_t lo, hi; };
+__device__ __forceinline__ KeccakWord keccak_pull(int addr, KeccakWord v) {
+    return KeccakWord{(uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)v.lo), (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)v.hi)};
 }
 // Three dependent permutation stages per round: (1) the column parities and, alongside, every lane's pi source word;
 // (2) the two parities theta needs for the SOURCE's column -- theta, rho and pi are then applied at the destination;
-// (3) chi's two row neighbours.
-__device__ __forceinline__ uint64_t keccak_f1600_wave(uint64_t a, const KeccakLanes& K, int l) {
+// (3) chi's two row neighbours.  A wavefront that replays a transcript is alone on its SIMD, so a round costs its latency:
+// three ds_bpermute round trips + ~30 dependent ALU instructions = ~490 cycles (tools/ubench_keccak.hip,
+// profiles/r09b_keccak_ubench.txt: 4.9 us per permutation; 6.2 us before round 5, when the round constant was a scalar load
+// inside a lane-0 branch at the END of the round -- its latency on the critical path 24 times -- and rho two 64-bit shifts).
+// Now: the constant is loaded at the top of the round and applied through a lane mask, rho is two v_alignbit on (possibly
+// swapped) halves, and two rounds share a loop trip.
+__device__ __forceinline__ uint64_t keccak_f1600_wave(uint64_t a64, const KeccakLanes& K, int l) {
     const uint64_t RC[24] = {0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808Aull, 0x8000000080008000ull,
                              0x000000000000808Bull, 0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull,
                              0x000000000000008Aull, 0x0000000000000088ull, 0x0000000080008009ull, 0x000000008000000Aull,
                              0x000000008000808Bull, 0x800000000000008Bull, 0x8000000000008089ull, 0x8000000000008003ull,
                              0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800Aull, 0x800000008000000Aull,
                              0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+    KeccakWord a{(uint32_t)a64, (uint32_t)(a64 >> 32)};
+    const uint32_t lane0 = l == 0 ? 0xffffffffu : 0u;
+    const uint32_t s = (32u - K.rot_sh) & 31u;
+#pragma unroll 2
     for (int r = 0; r < 24; r++) {
-        uint64_t as = shfl64(a, K.pi_src);
-        uint64_t c = a ^ shfl64(a, K.th1) ^ shfl64(a, K.th2) ^ shfl64(a, K.th3) ^ shfl64(a, K.th4);    // C[x] on every lane of column x
-        uint64_t cm = shfl64(c, K.cm_src), cp = shfl64(c, K.cp_src);
-        as ^= cm ^ ((cp << 1) | (cp >> 63));
-        uint64_t b = K.rot_src ? ((as << K.rot_src) | (as >> (64 - K.rot_src))) : as;
-        uint64_t b1 = shfl64(b, K.xp1), b2 = shfl64(b, K.xp2);
-        a = b ^ (~b1 & b2);
-        if (l == 0) a ^= RC[r];
+        const uint64_t rc = RC[r];
+        KeccakWord as = keccak_pull(K.pi_src, a);
+        const KeccakWord t1 = keccak_pull(K.th1, a), t2 = keccak_pull(K.th2, a), t3 = keccak_pull(K.th3, a), t4 = keccak_pull(K.th4, a);
+        const KeccakWord c{a.lo ^ t1.lo ^ t2.lo ^ t3.lo ^ t4.lo, a.hi ^ t1.hi ^ t2.hi ^ t3.hi ^ t4.hi};       // C[x] on every lane of column x
+        const KeccakWord cm = keccak_pull(K.cm_src, c), cp = keccak_pull(K.cp_src, c);
+        as.lo ^= cm.lo ^ __builtin_amdgcn_alignbit(cp.lo, cp.hi, 31);                                      // D = C[x-1] ^ rotl(C[x+1], 1)
+        as.hi ^= cm.hi ^ __builtin_amdgcn_alignbit(cp.hi, cp.lo, 31);
+        const uint32_t l0 = K.rot_swap ? as.hi : as.lo, h0 = K.rot_swap ? as.lo : as.hi;                   // rotl by 32, then by rot_sh < 32
+        const KeccakWord b{K.rot_sh ? __builtin_amdgcn_alignbit(l0, h0, s) : l0, K.rot_sh ? __builtin_amdgcn_alignbit(h0, l0, s) : h0};
+        const KeccakWord b1 = keccak_pull(K.xp1, b), b2 = keccak_pull(K.xp2, b);
+        a.lo = b.lo ^ (~b1.lo & b2.lo) ^ ((uint32_t)rc & lane0);
+        a.hi = b.hi ^ (~b1.hi & b2.hi) ^ ((uint32_t)(rc >> 32) & lane0);
     }
-    return a;
+    return ((uint64_t)a.hi << 32) | a.lo;
 }
 struct WStrobe {
     uint64_t a;                      // this lane's state word (lanes 25-63 carry zeros that nothing reads)
@@ -513,9 +534,15 @@ __device__ __forceinline__ void strobe_absorb_byte(WStrobe& st, uint8_t b) {
     wstrobe_xor(st, st.pos, b);
     if (++st.pos == STROBE_R) strobe_run_f(st);
 }
+// (the position is the same on every lane: the word that holds it is READ from its lane -- v_readlane, a few cycles -- not pulled
+// through the LDS crossbar like a per-lane source would have to be)
+__device__ __forceinline__ uint64_t wstrobe_word(const WStrobe& st, uint32_t word) {
+    const int src = __builtin_amdgcn_readfirstlane((int)word);
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(st.a >> 32), src) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)st.a, src);
+}
 __device__ __forceinline__ uint8_t strobe_squeeze_byte(WStrobe& st) {
     const uint32_t sh = 8 * (st.pos & 7);
-    const uint8_t b = (uint8_t)(shfl64(st.a, (int)(st.pos >> 3)) >> sh);
+    const uint8_t b = (uint8_t)(wstrobe_word(st, st.pos >> 3) >> sh);
     if ((uint32_t)st.l == (st.pos >> 3)) st.a &= ~(0xffull << sh);
     if (++st.pos == STROBE_R) strobe_run_f(st);
     return b;
@@ -577,6 +604,25 @@ DAPOL_HD void merlin_append_words(S& st, const char* label, int label_len, const
     for (int i = 0; i < nwords; i++)
         for (int k = 0; k < 4; k++) strobe_absorb_byte(st, (uint8_t)(w[i] >> (8 * k)));
 }
+#if defined(__HIPCC__)
+// The wavefront's state takes a message word in one step when its four bytes end inside the block: the lane(s) whose state word
+// overlaps bytes [pos, pos + 4) XOR their part of it (a dozen instructions instead of four byte steps of as many each).
+__device__ __forceinline__ void strobe_absorb_word(WStrobe& st, uint32_t w) {
+    if (st.pos + 4 <= STROBE_R) {
+        const int s = 8 * (int)st.pos - 64 * st.l;                   // bit offset of the message word in this lane's state word
+        if (s > -32 && s < 64) st.a ^= s >= 0 ? (uint64_t)w << s : (uint64_t)w >> -s;
+        st.pos += 4;
+        if (st.pos == STROBE_R) strobe_run_f(st);
+    } else {
+        for (int k = 0; k < 4; k++) strobe_absorb_byte(st, (uint8_t)(w >> (8 * k)));
+    }
+}
+__device__ __forceinline__ void merlin_append_words(WStrobe& st, const char* label, int label_len, const uint32_t* w, int nwords) {
+    merlin_frame(st, label, label_len, (uint32_t)(4 * nwords));
+    strobe_begin_op(st, SF_A);
+    for (int i = 0; i < nwords; i++) strobe_absorb_word(st, w[i]);
+}
+#endif
 template <class S>
 DAPOL_HD void merlin_append_u64(S& st, const char* label, int label_len, uint64_t x) {
     uint32_t w[2] = {(uint32_t)x, (uint32_t)(x >> 32)};

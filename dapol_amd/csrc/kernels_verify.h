@@ -82,58 +82,99 @@ enum { RV_V_BYTES = 41 };            // stream bytes per commitment
 // phases before it (which had commitments [0, j0)), carrying the state through vs.st -- so that a host whose commitments are still
 // on their way over PCIe can start the replay on the first quarter of every proof's commitments while the next quarter is being
 // copied (dapol_range_verify_batch).  One phase (j0 = 0, j1 = m) is the whole thing.
-__global__ __launch_bounds__(64) void k_rv_absorb_V(VerifyArgs V, int j0, int j1) {
-    __shared__ uint64_t sh[25];
-    const RangeArgs& A = V.R;
-    const size_t b = blockIdx.x;
-    const int l = threadIdx.x;
-    // the transcript's head is the same for every proof of the call (it depends on n and m only): each lane replays it
+// The transcript's head -- Transcript::new, the range proof's domain separator, n and m -- is the same for every proof of a call:
+// the HOST replays it once (rv_transcript_head; hash.h's one-lane Strobe compiles for both sides) and hands the state over in the
+// kernel arguments (round 5: replayed by every wavefront of every phase it cost ~35 us a phase -- 23 for Strobe128::new's
+// permutation on a lone lane, the rest for byte-wise writes into a 25-word array indexed by a run-time position).
+struct VHead {
+    uint64_t st[25];
+    uint32_t pos, pos_begin;
+};
+inline VHead rv_transcript_head(int n, int m) {
     Strobe s;
     merlin_init(s, LBL_APP_TRANSCRIPT);
     merlin_append_bytes(s, LBL_DOM_SEP, LBL_RANGEPROOF_DOMAIN);
-    merlin_append_u64(s, LBL_N, (uint64_t)A.n);
-    merlin_append_u64(s, LBL_M, (uint64_t)A.m);
-    const uint32_t pos0 = s.pos, pb0 = s.pos_begin;
-    if (l == 0)
-        for (int i = 0; i < 25; i++) sh[i] = s.s[i];
-    __syncthreads();
+    merlin_append_u64(s, LBL_N, (uint64_t)n);
+    merlin_append_u64(s, LBL_M, (uint64_t)m);
+    VHead h;
+    for (int i = 0; i < 25; i++) h.st[i] = s.s[i];
+    h.pos = s.pos;
+    h.pos_begin = s.pos_begin;
+    return h;
+}
+__global__ __launch_bounds__(64) void k_rv_absorb_V(VerifyArgs V, VHead H, int j0, int j1) {
+    const RangeArgs& A = V.R;
+    const size_t b = blockIdx.x;
+    const int l = threadIdx.x;
+    // A latency chain on a lone wavefront, while the side stream's decode fills the same SIMDs with throughput work: ask the
+    // arbiter for the issue slots (alone on an idle chip a block costs 5.5 us, tools/ubench_absorb.hip; beside the decode, 7.3).
+    __builtin_amdgcn_s_setprio(3);
+    const uint32_t pos0 = H.pos, pb0 = H.pos_begin;
     VerifyState& vs = V.vs[b];
-    uint64_t a = l < 25 ? (j0 > 0 ? vs.st[l] : sh[l]) : 0;
+    uint64_t a = l < 25 ? (j0 > 0 ? vs.st[l] : H.st[l]) : 0;
     KeccakLanes K;
     keccak_lanes_init(K, l);
-    const uint8_t* Vb = reinterpret_cast<const uint8_t*>(A.Vc + b * (size_t)A.m * 8);
     const uint32_t total = RV_V_BYTES * (uint32_t)A.m, end_abs = pos0 + total, nfull = end_abs / STROBE_R;
     const bool last_phase = j1 >= A.m;
     // blocks whose every byte belongs to a commitment below j: floor((41 j + pos0) / 166)
     const uint32_t beta_begin = j0 > 0 ? (RV_V_BYTES * (uint32_t)j0 + pos0) / STROBE_R : 0u;
     const uint32_t beta_end = last_phase ? nfull : (RV_V_BYTES * (uint32_t)j1 + pos0) / STROBE_R;
-    // This lane's eight bytes of block beta, without branches: in-block position q = 8 l + i  <->  stream offset
-    // k = 166 beta + q - pos0  <->  commitment j = k / 41, byte t = k mod 41 of its record.  The two position bytes: the
-    // begin_op they belong to follows the previous one by d = 34 (t = 0) or 7 (t = 7) bytes, so STROBE's old pos_begin is
-    // (q - d) + 1 when that one lies in the same block (q >= d) and 0 after a run_f; the very first record inherits pb0.
-    auto block_word = [&](uint32_t beta) -> uint64_t {
-        const uint32_t q0 = 8 * (uint32_t)l, at0 = beta * STROBE_R + q0;
-        uint32_t k0 = at0 >= pos0 ? at0 - pos0 : 0u;             // (clamped: bytes before pos0 are masked out below)
-        uint32_t j = k0 / RV_V_BYTES, t = k0 - j * RV_V_BYTES;
-        if (at0 < pos0) { j = 0; t = 0; }
-        uint64_t w = 0;
-        for (int i = 0; i < 8; i++) {
-            const uint32_t q = q0 + i, at = at0 + i;
-            const bool live = q < STROBE_R && at >= pos0 && at < end_abs;
-            const uint32_t jc = j < (uint32_t)A.m ? j : (uint32_t)A.m - 1, tc = t >= 9 ? t - 9 : 0u;
-            const uint32_t data = Vb[32 * (size_t)jc + tc];
-            const uint32_t ob0 = j == 0 ? pb0 : (q >= 34 ? q - 33 : 0u), ob7 = q >= 7 ? q - 6 : 0u;
-            const uint32_t fixed = t == 0 ? ob0 : t == 7 ? ob7 : t == 8 ? (uint32_t)SF_A : ((0x20561200u >> (8 * (t & 3))) & (t < 4 ? 0xffu : 0u));
-            const uint32_t byte = t >= 9 ? data : fixed;
-            w |= (uint64_t)(live ? byte : 0u) << (8 * i);
-            if (live) {                                          // advance (j, t) only along the stream
-                t++;
-                if (t == RV_V_BYTES) { t = 0; j++; }
-            }
-        }
-        return w;
+    // This lane's eight bytes of block beta, without branches and without a loop over the bytes (round 5: the byte loop was ~200
+    // instructions and eight dependent byte loads per block on the replay's critical path).  The lane's window starts at stream
+    // offset k = 166 beta + 8 l - pos0 = 41 j + t; a record is 9 framing bytes [pos_begin, M|A, 'V', LE32(32), pos_begin', A] and
+    // 32 data bytes, both longer than the window, so the window is (data, framing), (framing, data), all data or all framing:
+    //   t >= 9: min(41 - t, 8) data bytes of commitment j from its byte t - 9, then the framing of record j + 1 from its byte 0;
+    //   t <  9: the framing of record j from its byte t (min(9 - t, 8) bytes), then commitment j from its byte 0.
+    // Data bytes are consecutive in memory even across commitments, so three aligned words hold the (at most) 8 of them:
+    // block_load issues those loads -- a block AHEAD, so that they travel while the block before is permuted -- and block_word
+    // puts the window together.  The two position bytes: the begin_op they belong to follows the previous one by 34 (t = 0) or 7
+    // (t = 7) bytes, so STROBE's old pos_begin is (q - d) + 1 when that one lies in the same block (q >= d) and 0 after a
+    // run_f; the very first record inherits pb0.  Dead bytes: before pos0 (block 0: the stream starts at pos0, i.e. the window
+    // is the stream's head shifted up), from byte 166 of the block on (lane 20's last two; lanes 21-24), and after the end.
+    struct Win { uint32_t lead, j, t; };
+    auto window = [&](uint32_t beta) -> Win {
+        const uint32_t at0 = beta * STROBE_R + 8 * (uint32_t)l;
+        const uint32_t lead = at0 < pos0 ? (pos0 - at0 < 8u ? pos0 - at0 : 8u) : 0u;
+        const uint32_t k = at0 + lead > pos0 ? at0 + lead - pos0 : 0u, j = k / RV_V_BYTES;    // (a window wholly before pos0: lead = 8, all dead)
+        return Win{lead, j, k - j * RV_V_BYTES};
     };
-    uint64_t w = (beta_begin < beta_end || last_phase) ? block_word(beta_begin) : 0;
+    struct Raw { uint32_t d0, d1, d2; };
+    const uint32_t* Vw = A.Vc + b * (size_t)A.m * 8;
+    const uint32_t last_w = 8 * (uint32_t)A.m - 1;
+    auto block_load = [&](uint32_t beta) -> Raw {
+        const Win W = window(beta);
+        const uint32_t m0 = 32 * W.j + (W.t >= 9 ? W.t - 9 : 0u), w0 = m0 >> 2;            // words past the proof's last one hold no live byte
+        return Raw{Vw[w0 < last_w ? w0 : last_w], Vw[w0 + 1 < last_w ? w0 + 1 : last_w], Vw[w0 + 2 < last_w ? w0 + 2 : last_w]};
+    };
+    auto shl_bytes = [](uint64_t x, uint32_t n) -> uint64_t { return n >= 8 ? 0ull : x << (8 * n); };
+    auto low_bytes = [](uint32_t n) -> uint64_t { return n >= 8 ? ~0ull : (1ull << (8 * n)) - 1; };
+    auto block_word = [&](uint32_t beta, const Raw& R) -> uint64_t {
+        const Win W = window(beta);
+        const uint32_t q0 = 8 * (uint32_t)l, at0 = beta * STROBE_R + q0, t = W.t;
+        const bool data_first = t >= 9;
+        const uint32_t sh = 8 * ((data_first ? t - 9 : 0u) & 3u);                            // (32 j is a multiple of 4)
+        const uint64_t raw = sh ? ((uint64_t)__builtin_amdgcn_alignbit(R.d2, R.d1, sh) << 32) | __builtin_amdgcn_alignbit(R.d1, R.d0, sh)
+                                : ((uint64_t)R.d1 << 32) | R.d0;
+        // the framing record in (or after) the window: number jf, its byte 0 at in-block position qf0 (negative: before the window)
+        const uint32_t jf = data_first ? W.j + 1 : W.j;
+        const int qf0 = (int)(q0 + W.lead) + (data_first ? (int)(RV_V_BYTES - t) : -(int)t), qf7 = qf0 + 7;
+        const uint32_t ob0 = jf == 0 ? pb0 : (qf0 >= 34 ? (uint32_t)(qf0 - 33) : 0u), ob7 = qf7 >= 7 ? (uint32_t)(qf7 - 6) : 0u;
+        const uint64_t fr = (uint64_t)ob0 | 0x20561200ull | ((uint64_t)ob7 << 56), f8 = (uint64_t)SF_A;    // bytes 0..7 of the record, byte 8
+        uint64_t sw;
+        if (data_first) {
+            const uint32_t nd = RV_V_BYTES - t;                                             // 1..32 data bytes left in commitment j
+            sw = (raw & low_bytes(nd)) | shl_bytes(fr, nd);
+        } else {
+            const uint64_t frs = t >= 8 ? f8 : (fr >> (8 * t)) | (t ? f8 << (8 * (8 - t)) : 0ull);
+            const uint32_t nf = 9 - t;                                                      // 1..9 framing bytes first
+            sw = (frs & low_bytes(nf)) | shl_bytes(raw, nf);
+        }
+        const uint32_t in_block = q0 < STROBE_R ? STROBE_R - q0 : 0u, in_stream = at0 < end_abs ? end_abs - at0 : 0u;
+        return shl_bytes(sw, W.lead) & low_bytes(in_block < in_stream ? in_block : in_stream);
+    };
+    const bool any = beta_begin < beta_end || last_phase;
+    Raw rw = any ? block_load(beta_begin) : Raw{0, 0, 0};
+    uint64_t w = any ? block_word(beta_begin, rw) : 0;
     for (uint32_t beta = beta_begin; beta < beta_end; beta++) {
         a ^= w;
         if (l == 20) {                                            // run_f: pos_begin at byte 166, 0x04 and 0x80 at byte 167
@@ -142,8 +183,10 @@ __global__ __launch_bounds__(64) void k_rv_absorb_V(VerifyArgs V, int j0, int j1
             uint32_t pbe = ab >= beta * STROBE_R ? ab % STROBE_R + 1 : (beta == 0 ? pb0 : 0u);
             a ^= ((uint64_t)pbe << 48) | (0x84ull << 56);
         }
-        if (beta + 1 < beta_end || last_phase) w = block_word(beta + 1);   // the next block's bytes load while this one is permuted
-        a = keccak_f1600_wave(a, K, l);                                    // (never a block this phase's commitments do not cover)
+        const bool more = beta + 1 < beta_end || last_phase;
+        if (more) rw = block_load(beta + 1);                      // the next block's words travel while this one is permuted
+        a = keccak_f1600_wave(a, K, l);                           // (never a block this phase's commitments do not cover)
+        if (more) w = block_word(beta + 1, rw);
     }
     if (last_phase) a ^= w;                                       // the bytes after the last permutation
     if (l < 25) vs.st[l] = a;
@@ -171,7 +214,10 @@ __global__ __launch_bounds__(64) void k_rv_transcript(VerifyArgs V) {
     bool ok = true;
     uint32_t w8[8];
     typename std::conditional<WAVE != 0, WStrobe, Strobe>::type s;
-    if constexpr (WAVE != 0) wstrobe_lanes(s, (int)threadIdx.x);
+    if constexpr (WAVE != 0) {
+        wstrobe_lanes(s, (int)threadIdx.x);
+        __builtin_amdgcn_s_setprio(3);                           // (a latency chain beside the side stream's throughput kernels, as k_rv_absorb_V)
+    }
     if (V.wave_transcript) {                                     // k_rv_absorb_V has done the head and the commitments
         rv_state_from_absorb(s, vs);
         s.pos = vs.st_pos;
