@@ -9,6 +9,9 @@
 //      instead of 18 ds_bpermute
 //   3-5  as 1 with the rounds in a loop (1 / 2 / 4 per trip): the round constant loaded at the top of the round, applied by mask
 //   6  keccak_f1600_wave of hash.h as the library runs it now (= 4)
+// Tried and dropped: rows of eight lanes with the column parities by DPP row_ror:8 + v_permlane32_swap / v_permlane16_swap and
+// theta's / chi's neighbours by DPP row shifts, leaving one ds_bpermute stage (rho/pi) per round -- 544 cycles per round against
+// 491: a lone wavefront pays ~8 cycles per DEPENDENT VALU instruction, so ~25 more of them cost what two crossbar trips did.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I dapol_amd/csrc tools/ubench_keccak.hip -o build/ubench_keccak
 #include <hip/hip_runtime.h>
 #include <cstdio>
