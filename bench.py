@@ -1144,7 +1144,7 @@ def mode_verify(args):
                                    "note": "per GPU and per PASS (one verification of this rank's proofs; the step is a chain of ~40 launches, none of which "
                                            "dominates): proof + commitment bytes / step time.  traffic = FETCH_SIZE x 2 + WRITE_SIZE summed over the verifier's "
                                            "kernels of one pass (tools/profile_verify.sh), set only from PMC passes of the running build.  The floor of a pass is "
-                                           "the serial transcript replay: 253 dependent Keccak-f per proof, ~2.3 ms whatever the batch size"},
+                                           "the serial transcript replay: 253 + 56 dependent Keccak-f per proof at ~5 us on a wavefront, ~1.6 ms whatever the batch size"},
                       "cpu_baseline": cpu}), flush=True)
     if dist is not None:
         dist.barrier()
