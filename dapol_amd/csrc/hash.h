@@ -481,7 +481,10 @@ __device__ __forceinline__ KeccakWord keccak_pull(int addr, KeccakWord v) {
 // profiles/r09b_keccak_ubench.txt: 4.9 us per permutation; 6.2 us before round 5, when the round constant was a scalar load
 // inside a lane-0 branch at the END of the round -- its latency on the critical path 24 times -- and rho two 64-bit shifts).
 // Now: the constant is loaded at the top of the round and applied through a lane mask, rho is two v_alignbit on (possibly
-// swapped) halves, and two rounds share a loop trip.
+// swapped) halves, and TRIP rounds share a loop trip.
+// TRIP = rounds per loop trip: 2 where the permutation is inlined at many places of a transcript replay, 24 (no loop: 4 % fewer
+// cycles per round) where one call site is the whole kernel (k_rv_absorb_V).
+template <int TRIP = 2>
 __device__ __forceinline__ uint64_t keccak_f1600_wave(uint64_t a64, const KeccakLanes& K, int l) {
     const uint64_t RC[24] = {0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808Aull, 0x8000000080008000ull,
                              0x000000000000808Bull, 0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull,
@@ -492,7 +495,7 @@ __device__ __forceinline__ uint64_t keccak_f1600_wave(uint64_t a64, const Keccak
     KeccakWord a{(uint32_t)a64, (uint32_t)(a64 >> 32)};
     const uint32_t lane0 = l == 0 ? 0xffffffffu : 0u;
     const uint32_t s = (32u - K.rot_sh) & 31u;
-#pragma unroll 2
+#pragma unroll TRIP
     for (int r = 0; r < 24; r++) {
         const uint64_t rc = RC[r];
         KeccakWord as = keccak_pull(K.pi_src, a);
@@ -555,6 +558,73 @@ __device__ __forceinline__ void strobe_reset(WStrobe& st) {
 __device__ __forceinline__ void strobe_permute_raw(WStrobe& st) { st.a = keccak_f1600_wave(st.a, st.K, st.l); }
 #endif
 DAPOL_HD void strobe_permute_raw(Strobe& st) { keccak_f1600(st.s); }
+
+// ---------------------------------------------------------------- the m commitments of a proof as a closed-form byte stream
+// append_message(b"V", commitment) m times adds m records of 41 bytes to the STROBE stream, nothing in between squeezes, and
+// STROBE's two position bytes are functions of the offset alone -- so word `lane` of 166-byte block `beta` can be put together
+// without looking at any other (k_rv_absorb_V, kernels_verify.h: one wavefront per proof, lane = state word).  Written for both
+// sides: the kernel calls these, and tests/host_shim.cpp replays a whole stream with them against the byte-wise Strobe.
+//   record j = [pos_begin, M|A, 'V', LE32(32), pos_begin', A, 32 data bytes]  (merlin_frame + strobe_begin_op above)
+// A lane's window (8 bytes) starts at stream offset k = 166 beta + 8 lane - pos0 = 41 j + t; the framing (9 bytes) and the data
+// (32 bytes) are both longer than the window, so it is (data, framing), (framing, data), all data or all framing:
+//   t >= 9: min(41 - t, 8) data bytes of commitment j from its byte t - 9, then the framing of record j + 1 from its byte 0;
+//   t <  9: the framing of record j from its byte t (min(9 - t, 8) bytes), then commitment j from its byte 0.
+// Data bytes are consecutive in memory even across commitments, so three aligned 32-bit words hold the (at most) 8 of them.
+// The two position bytes: the begin_op they belong to follows the previous one by 34 (t = 0) or 7 (t = 7) bytes, so STROBE's old
+// pos_begin is (q - d) + 1 when that one lies in the same block (q >= d) and 0 after a run_f; the very first record inherits
+// pb0.  Dead bytes: before pos0 (block 0: the stream starts at pos0, i.e. the window is the stream's head shifted up), from
+// byte 166 of the block on (lane 20's last two; lanes 21-24), and after the end of the stream.
+enum { RV_V_BYTES = 41 };            // stream bytes per commitment
+struct AbsorbWindow { uint32_t lead, j, t; };                       // dead leading bytes; record and byte of the first live one
+DAPOL_HD AbsorbWindow absorb_window(uint32_t beta, uint32_t lane, uint32_t pos0) {
+    const uint32_t at0 = beta * STROBE_R + 8 * lane;
+    const uint32_t lead = at0 < pos0 ? (pos0 - at0 < 8u ? pos0 - at0 : 8u) : 0u;
+    const uint32_t k = at0 + lead > pos0 ? at0 + lead - pos0 : 0u, j = k / RV_V_BYTES;    // (a window wholly before pos0: lead = 8, all dead)
+    return AbsorbWindow{lead, j, k - j * RV_V_BYTES};
+}
+// index of the first of the three aligned words of the proof's commitments ([m][8] words) the window's data bytes lie in
+DAPOL_HD uint32_t absorb_first_word(const AbsorbWindow& W) { return (32 * W.j + (W.t >= 9 ? W.t - 9 : 0u)) >> 2; }
+DAPOL_HD uint64_t absorb_shl_bytes(uint64_t x, uint32_t n) { return n >= 8 ? 0ull : x << (8 * n); }
+DAPOL_HD uint64_t absorb_low_bytes(uint32_t n) { return n >= 8 ? ~0ull : (1ull << (8 * n)) - 1; }
+// word `lane` of block `beta`: d0..d2 = the words at absorb_first_word() + 0, 1, 2 (any value where they lie past the last
+// commitment: no live byte comes from there); end_abs = pos0 + 41 m
+DAPOL_HD uint64_t absorb_block_word(uint32_t beta, uint32_t lane, uint32_t pos0, uint32_t pb0, uint32_t end_abs, uint32_t d0, uint32_t d1, uint32_t d2) {
+    const AbsorbWindow W = absorb_window(beta, lane, pos0);
+    const uint32_t q0 = 8 * lane, at0 = beta * STROBE_R + q0, t = W.t;
+    const bool data_first = t >= 9;
+    const uint32_t sh = 8 * ((data_first ? t - 9 : 0u) & 3u);                               // (32 j is a multiple of 4)
+    const uint64_t w01 = ((uint64_t)d1 << 32) | d0, w12 = ((uint64_t)d2 << 32) | d1;
+    const uint64_t raw = ((uint64_t)(uint32_t)(w12 >> sh) << 32) | (uint32_t)(w01 >> sh);   // two funnel shifts (v_alignbit)
+    // the framing record in (or after) the window: number jf, its byte 0 at in-block position qf0 (negative: before the window)
+    const uint32_t jf = data_first ? W.j + 1 : W.j;
+    const int qf0 = (int)(q0 + W.lead) + (data_first ? (int)(RV_V_BYTES - t) : -(int)t), qf7 = qf0 + 7;
+    const uint32_t ob0 = jf == 0 ? pb0 : (qf0 >= 34 ? (uint32_t)(qf0 - 33) : 0u), ob7 = qf7 >= 7 ? (uint32_t)(qf7 - 6) : 0u;
+    const uint64_t fr = (uint64_t)ob0 | 0x20561200ull | ((uint64_t)ob7 << 56), f8 = (uint64_t)SF_A;   // bytes 0..7 of the record, byte 8
+    uint64_t sw;
+    if (data_first) {
+        const uint32_t nd = RV_V_BYTES - t;                                                 // 1..32 data bytes left in commitment j
+        sw = (raw & absorb_low_bytes(nd)) | absorb_shl_bytes(fr, nd);
+    } else {
+        const uint64_t frs = t >= 8 ? f8 : (fr >> (8 * t)) | (t ? f8 << (8 * (8 - t)) : 0ull);
+        const uint32_t nf = 9 - t;                                                          // 1..9 framing bytes first
+        sw = (frs & absorb_low_bytes(nf)) | absorb_shl_bytes(raw, nf);
+    }
+    const uint32_t in_block = q0 < STROBE_R ? STROBE_R - q0 : 0u, in_stream = at0 < end_abs ? end_abs - at0 : 0u;
+    return absorb_shl_bytes(sw, W.lead) & absorb_low_bytes(in_block < in_stream ? in_block : in_stream);
+}
+// what run_f adds to word 20 after block beta: pos_begin at byte 166, 0x04 and 0x80 at byte 167
+DAPOL_HD uint64_t absorb_runf_word(uint32_t beta, uint32_t pos0, uint32_t pb0) {
+    const uint32_t k_end = beta * STROBE_R + (STROBE_R - 1) - pos0, je = k_end / RV_V_BYTES, te = k_end - je * RV_V_BYTES;
+    const uint32_t kb = RV_V_BYTES * je + (te >= 7 ? 7u : 0u), ab = pos0 + kb;               // the last begin_op at or before the block's end
+    const uint32_t pbe = ab >= beta * STROBE_R ? ab % STROBE_R + 1 : (beta == 0 ? pb0 : 0u);
+    return ((uint64_t)pbe << 48) | (0x84ull << 56);
+}
+// position state after the whole stream (what the lane-per-proof replay holds in pos / pos_begin)
+DAPOL_HD void absorb_end_position(uint32_t pos0, uint32_t m, uint32_t& pos, uint32_t& pos_begin) {
+    const uint32_t end_abs = pos0 + RV_V_BYTES * m, nfull = end_abs / STROBE_R, kb = RV_V_BYTES * (m - 1) + 7;   // the last begin_op
+    pos = end_abs % STROBE_R;
+    pos_begin = (pos0 + kb) / STROBE_R == nfull ? (pos0 + kb) % STROBE_R + 1 : 0u;
+}
 
 // Everything above the byte level is written once for both holders of the state (S = Strobe: one lane; S = WStrobe: a wavefront).
 template <class S>

@@ -77,7 +77,6 @@ __device__ __forceinline__ bool words_zero(const uint32_t* w) {
 //  * the permutation runs with one 64-bit state word per lane (lane = x + 5 y): theta, rho/pi and chi are nine lane
 //    permutations (ds_bpermute) and a dozen ALU operations per round instead of ~500.
 // The state it leaves in vs.st / st_pos / st_pos_begin is bit for bit what the lane-per-proof loop would hold.
-enum { RV_V_BYTES = 41 };            // stream bytes per commitment
 // PHASES (round 5): the kernel absorbs the stream blocks that lie entirely inside commitments [0, j1) and were not absorbed by the
 // phases before it (which had commitments [0, j0)), carrying the state through vs.st -- so that a host whose commitments are still
 // on their way over PCIe can start the replay on the first quarter of every proof's commitments while the next quarter is being
@@ -120,80 +119,35 @@ __global__ __launch_bounds__(64) void k_rv_absorb_V(VerifyArgs V, VHead H, int j
     const uint32_t beta_begin = j0 > 0 ? (RV_V_BYTES * (uint32_t)j0 + pos0) / STROBE_R : 0u;
     const uint32_t beta_end = last_phase ? nfull : (RV_V_BYTES * (uint32_t)j1 + pos0) / STROBE_R;
     // This lane's eight bytes of block beta, without branches and without a loop over the bytes (round 5: the byte loop was ~200
-    // instructions and eight dependent byte loads per block on the replay's critical path).  The lane's window starts at stream
-    // offset k = 166 beta + 8 l - pos0 = 41 j + t; a record is 9 framing bytes [pos_begin, M|A, 'V', LE32(32), pos_begin', A] and
-    // 32 data bytes, both longer than the window, so the window is (data, framing), (framing, data), all data or all framing:
-    //   t >= 9: min(41 - t, 8) data bytes of commitment j from its byte t - 9, then the framing of record j + 1 from its byte 0;
-    //   t <  9: the framing of record j from its byte t (min(9 - t, 8) bytes), then commitment j from its byte 0.
-    // Data bytes are consecutive in memory even across commitments, so three aligned words hold the (at most) 8 of them:
-    // block_load issues those loads -- a block AHEAD, so that they travel while the block before is permuted -- and block_word
-    // puts the window together.  The two position bytes: the begin_op they belong to follows the previous one by 34 (t = 0) or 7
-    // (t = 7) bytes, so STROBE's old pos_begin is (q - d) + 1 when that one lies in the same block (q >= d) and 0 after a
-    // run_f; the very first record inherits pb0.  Dead bytes: before pos0 (block 0: the stream starts at pos0, i.e. the window
-    // is the stream's head shifted up), from byte 166 of the block on (lane 20's last two; lanes 21-24), and after the end.
-    struct Win { uint32_t lead, j, t; };
-    auto window = [&](uint32_t beta) -> Win {
-        const uint32_t at0 = beta * STROBE_R + 8 * (uint32_t)l;
-        const uint32_t lead = at0 < pos0 ? (pos0 - at0 < 8u ? pos0 - at0 : 8u) : 0u;
-        const uint32_t k = at0 + lead > pos0 ? at0 + lead - pos0 : 0u, j = k / RV_V_BYTES;    // (a window wholly before pos0: lead = 8, all dead)
-        return Win{lead, j, k - j * RV_V_BYTES};
-    };
+    // instructions and eight dependent byte loads per block on the replay's critical path): absorb_block_word (hash.h, where the
+    // stream's form is written down and from where the host-side test replays it) from three aligned words, which block_load
+    // requests a block AHEAD, so that they travel while the block before is permuted.
     struct Raw { uint32_t d0, d1, d2; };
     const uint32_t* Vw = A.Vc + b * (size_t)A.m * 8;
     const uint32_t last_w = 8 * (uint32_t)A.m - 1;
     auto block_load = [&](uint32_t beta) -> Raw {
-        const Win W = window(beta);
-        const uint32_t m0 = 32 * W.j + (W.t >= 9 ? W.t - 9 : 0u), w0 = m0 >> 2;            // words past the proof's last one hold no live byte
+        const uint32_t w0 = absorb_first_word(absorb_window(beta, (uint32_t)l, pos0));        // words past the proof's last one hold no live byte
         return Raw{Vw[w0 < last_w ? w0 : last_w], Vw[w0 + 1 < last_w ? w0 + 1 : last_w], Vw[w0 + 2 < last_w ? w0 + 2 : last_w]};
     };
-    auto shl_bytes = [](uint64_t x, uint32_t n) -> uint64_t { return n >= 8 ? 0ull : x << (8 * n); };
-    auto low_bytes = [](uint32_t n) -> uint64_t { return n >= 8 ? ~0ull : (1ull << (8 * n)) - 1; };
-    auto block_word = [&](uint32_t beta, const Raw& R) -> uint64_t {
-        const Win W = window(beta);
-        const uint32_t q0 = 8 * (uint32_t)l, at0 = beta * STROBE_R + q0, t = W.t;
-        const bool data_first = t >= 9;
-        const uint32_t sh = 8 * ((data_first ? t - 9 : 0u) & 3u);                            // (32 j is a multiple of 4)
-        const uint64_t raw = sh ? ((uint64_t)__builtin_amdgcn_alignbit(R.d2, R.d1, sh) << 32) | __builtin_amdgcn_alignbit(R.d1, R.d0, sh)
-                                : ((uint64_t)R.d1 << 32) | R.d0;
-        // the framing record in (or after) the window: number jf, its byte 0 at in-block position qf0 (negative: before the window)
-        const uint32_t jf = data_first ? W.j + 1 : W.j;
-        const int qf0 = (int)(q0 + W.lead) + (data_first ? (int)(RV_V_BYTES - t) : -(int)t), qf7 = qf0 + 7;
-        const uint32_t ob0 = jf == 0 ? pb0 : (qf0 >= 34 ? (uint32_t)(qf0 - 33) : 0u), ob7 = qf7 >= 7 ? (uint32_t)(qf7 - 6) : 0u;
-        const uint64_t fr = (uint64_t)ob0 | 0x20561200ull | ((uint64_t)ob7 << 56), f8 = (uint64_t)SF_A;    // bytes 0..7 of the record, byte 8
-        uint64_t sw;
-        if (data_first) {
-            const uint32_t nd = RV_V_BYTES - t;                                             // 1..32 data bytes left in commitment j
-            sw = (raw & low_bytes(nd)) | shl_bytes(fr, nd);
-        } else {
-            const uint64_t frs = t >= 8 ? f8 : (fr >> (8 * t)) | (t ? f8 << (8 * (8 - t)) : 0ull);
-            const uint32_t nf = 9 - t;                                                      // 1..9 framing bytes first
-            sw = (frs & low_bytes(nf)) | shl_bytes(raw, nf);
-        }
-        const uint32_t in_block = q0 < STROBE_R ? STROBE_R - q0 : 0u, in_stream = at0 < end_abs ? end_abs - at0 : 0u;
-        return shl_bytes(sw, W.lead) & low_bytes(in_block < in_stream ? in_block : in_stream);
-    };
+    auto block_word = [&](uint32_t beta, const Raw& R) -> uint64_t { return absorb_block_word(beta, (uint32_t)l, pos0, pb0, end_abs, R.d0, R.d1, R.d2); };
     const bool any = beta_begin < beta_end || last_phase;
     Raw rw = any ? block_load(beta_begin) : Raw{0, 0, 0};
     uint64_t w = any ? block_word(beta_begin, rw) : 0;
     for (uint32_t beta = beta_begin; beta < beta_end; beta++) {
         a ^= w;
-        if (l == 20) {                                            // run_f: pos_begin at byte 166, 0x04 and 0x80 at byte 167
-            uint32_t k_end = beta * STROBE_R + (STROBE_R - 1) - pos0, je = k_end / RV_V_BYTES, te = k_end - je * RV_V_BYTES;
-            uint32_t kb = RV_V_BYTES * je + (te >= 7 ? 7u : 0u), ab = pos0 + kb;
-            uint32_t pbe = ab >= beta * STROBE_R ? ab % STROBE_R + 1 : (beta == 0 ? pb0 : 0u);
-            a ^= ((uint64_t)pbe << 48) | (0x84ull << 56);
-        }
+        if (l == 20) a ^= absorb_runf_word(beta, pos0, pb0);       // run_f: pos_begin at byte 166, 0x04 and 0x80 at byte 167
         const bool more = beta + 1 < beta_end || last_phase;
         if (more) rw = block_load(beta + 1);                      // the next block's words travel while this one is permuted
-        a = keccak_f1600_wave(a, K, l);                           // (never a block this phase's commitments do not cover)
+        a = keccak_f1600_wave<24>(a, K, l);                       // (never a block this phase's commitments do not cover)
         if (more) w = block_word(beta + 1, rw);
     }
     if (last_phase) a ^= w;                                       // the bytes after the last permutation
     if (l < 25) vs.st[l] = a;
     if (l == 0 && last_phase) {
-        uint32_t kb = RV_V_BYTES * ((uint32_t)A.m - 1) + 7;       // the last begin_op
-        vs.st_pos = end_abs % STROBE_R;
-        vs.st_pos_begin = (pos0 + kb) / STROBE_R == nfull ? (pos0 + kb) % STROBE_R + 1 : 0u;
+        uint32_t pe, pbe;
+        absorb_end_position(pos0, (uint32_t)A.m, pe, pbe);
+        vs.st_pos = pe;
+        vs.st_pos_begin = pbe;
     }
 }
 

@@ -153,6 +153,45 @@ void t_merlin(const char* app, int app_len, const char* label, int ll, const cha
     merlin_challenge_wide(s, cl, cll, w);
     st(out64, w, 16);
 }
+// The m commitments of a proof through the block-parallel form k_rv_absorb_V uses (hash.h: absorb_block_word & co., the same
+// functions the kernel calls; the 25 "lanes" are a loop here and the permutation is the one-lane one), in `phases` phases like
+// dapol_range_verify_batch, and through the byte-wise Strobe.  app / extra: a transcript head of any length before the
+// commitments (the stream then starts at another offset of the 166-byte block).  out: 25 state words + pos + pos_begin, twice.
+void t_absorb_v(int m, const uint32_t* Vw, int phases, const char* extra, int extra_len, uint64_t* out_block, uint64_t* out_bytes) {
+    Strobe s;
+    merlin_init(s, LBL_APP_TRANSCRIPT);
+    merlin_append_bytes(s, LBL_DOM_SEP, extra, extra_len);
+    merlin_append_u64(s, LBL_M, (uint64_t)m);
+    const uint32_t pos0 = s.pos, pb0 = s.pos_begin, end_abs = pos0 + RV_V_BYTES * (uint32_t)m, nfull = end_abs / STROBE_R;
+    uint64_t a[25];
+    for (int i = 0; i < 25; i++) a[i] = s.s[i];
+    const uint32_t last_w = 8 * (uint32_t)m - 1;
+    auto word = [&](uint32_t beta, uint32_t l) {
+        const uint32_t w0 = absorb_first_word(absorb_window(beta, l, pos0));
+        return absorb_block_word(beta, l, pos0, pb0, end_abs, Vw[w0 < last_w ? w0 : last_w], Vw[w0 + 1 < last_w ? w0 + 1 : last_w],
+                                 Vw[w0 + 2 < last_w ? w0 + 2 : last_w]);
+    };
+    for (int k = 0; k < phases; k++) {
+        const int j0 = k * (m / phases), j1 = k == phases - 1 ? m : (k + 1) * (m / phases);
+        const bool last_phase = j1 >= m;
+        const uint32_t beta_begin = j0 > 0 ? (RV_V_BYTES * (uint32_t)j0 + pos0) / STROBE_R : 0u;
+        const uint32_t beta_end = last_phase ? nfull : (RV_V_BYTES * (uint32_t)j1 + pos0) / STROBE_R;
+        for (uint32_t beta = beta_begin; beta < beta_end; beta++) {
+            for (uint32_t l = 0; l < 25; l++) a[l] ^= word(beta, l);
+            a[20] ^= absorb_runf_word(beta, pos0, pb0);
+            keccak_f1600(a);
+        }
+        if (last_phase)
+            for (uint32_t l = 0; l < 25; l++) a[l] ^= word(beta_end, l);
+    }
+    uint32_t pe, pbe;
+    absorb_end_position(pos0, (uint32_t)m, pe, pbe);
+    for (int i = 0; i < 25; i++) out_block[i] = a[i];
+    out_block[25] = pe; out_block[26] = pbe;
+    for (int j = 0; j < m; j++) merlin_append_words(s, LBL_V, Vw + 8 * j, 8);
+    for (int i = 0; i < 25; i++) out_bytes[i] = s.s[i];
+    out_bytes[25] = s.pos; out_bytes[26] = s.pos_begin;
+}
 void t_digest(int kind, const uint8_t* in, int n, uint8_t* out) {
     Digest d;
     uint32_t stack[B3_STACK_DEPTH * 8];

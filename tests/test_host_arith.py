@@ -172,3 +172,27 @@ def test_hashes_and_transcript(host_shim, pyref):
     t = R.Transcript(b"")
     t.append_message(b"dom-sep", b"rangeproof v1")
     assert o.raw == t.challenge_bytes(b"y", 64)
+
+
+def test_commitment_stream_in_blocks_equals_bytewise_strobe(host_shim):
+    """k_rv_absorb_V's closed form of the STROBE stream of m commitments (hash.h: absorb_window / absorb_block_word /
+    absorb_runf_word / absorb_end_position -- the functions the kernel itself calls, compiled for the host) leaves the state and
+    the two positions the byte-wise Strobe leaves, for every party count, for transcript heads of every length (the stream then
+    starts at every offset of the 166-byte block) and in 1, 2 or 4 phases like dapol_range_verify_batch's column blocks."""
+    import ctypes
+    import numpy as np
+    rng = np.random.default_rng(11)
+    u64 = ctypes.POINTER(ctypes.c_uint64)
+    cases = 0
+    for m in (1, 2, 3, 4, 5, 8, 16, 31, 32, 64, 128, 256, 1024):
+        V = rng.integers(0, 2**32, size=8 * m, dtype=np.uint32)
+        for extra_len in list(range(0, 170, 7)) + [165, 166, 167]:
+            extra = bytes(rng.integers(0, 256, size=extra_len, dtype=np.uint8))
+            for phases in (1, 2, 4):
+                if m % phases:
+                    continue
+                a, b = np.zeros(27, np.uint64), np.zeros(27, np.uint64)
+                host_shim.t_absorb_v(m, V.ctypes.data_as(ctypes.c_void_p), phases, extra, extra_len, a.ctypes.data_as(u64), b.ctypes.data_as(u64))
+                assert (a == b).all(), (m, extra_len, phases, np.nonzero(a != b)[0])
+                cases += 1
+    assert cases > 500
