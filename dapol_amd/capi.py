@@ -86,6 +86,8 @@ _SIG = {
     "dapol_tree_update": (ctypes.c_int32, [_P, ctypes.c_size_t, _P, _P, _P]),
     "dapol_tree_last_update_path": (ctypes.c_int32, [_P, _P]),
     "dapol_diag_fork_guard_waits": (ctypes.c_int32, [_P]),
+    "dapol_diag_verify_fallbacks": (ctypes.c_int32, [_P]),
+    "dapol_diag_range_prove_ms": (ctypes.c_int32, [_P]),
     "dapol_tree_level_size": (ctypes.c_int32, [_P, ctypes.c_int32, _P, _P]),
     "dapol_tree_level_nodes": (ctypes.c_int32, [_P, ctypes.c_int32, _P, _P, _P, _P, _P, _P]),
     "dapol_tree_paths": (ctypes.c_int32, [_P, ctypes.c_size_t, _P, _P, _P, _P, _P]),

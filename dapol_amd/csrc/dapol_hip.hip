@@ -260,6 +260,23 @@ struct ForkGuard {
         if (e_ && !strcmp(e_, site)) return fail(DAPOL_ERR_HIP, "injected failure after the fork at " site " (test knob)"); \
     } while (0)
 
+// Combined (random-linear-combination) verification checks that FAILED and went on to bisection / the proof-by-proof check.  On
+// batches of valid proofs this stays 0; a test that verifies two different all-valid batches back to back asserts exactly that
+// (a stale-scratch dependence between passes shows up as a spurious failure here long before it shows up in a verdict).
+static std::atomic<unsigned long long> g_verify_fallbacks{0};
+int32_t dapol_diag_verify_fallbacks(uint64_t* count) {
+    if (!count) return fail(DAPOL_ERR_INVALID_ARGUMENT, "null argument");
+    *count = g_verify_fallbacks.load(std::memory_order_relaxed);
+    return DAPOL_OK;
+}
+// Device time of the proving pipeline of the last dapol_range_prove_batch (HIP events on the context's stream around
+// range_prove_device: inputs already in HBM, proofs not yet copied back) -- what tools/bench_small_parties.py quotes.
+static std::atomic<double> g_last_range_prove_ms{0.0};
+int32_t dapol_diag_range_prove_ms(double* ms) {
+    if (!ms) return fail(DAPOL_ERR_INVALID_ARGUMENT, "null argument");
+    *ms = g_last_range_prove_ms.load(std::memory_order_relaxed);
+    return DAPOL_OK;
+}
 int32_t dapol_diag_fork_guard_waits(uint64_t* count) {
     if (!count) return fail(DAPOL_ERR_INVALID_ARGUMENT, "null argument");
     *count = g_fork_guard_waits.load(std::memory_order_relaxed);

@@ -35,10 +35,16 @@ struct RangeArgs {
     const uint32_t* Vc;         // [B][m][8]   compressed value commitments
     // nonce source
     const uint32_t* seed;       // [8] device
-    const uint64_t* stream_id;  // [B]
-    uint64_t slot_base;
-    const uint32_t* tape;       // [B][tape_stride][16] or null: the proof's slots start at its row's head
-    uint32_t tape_stride;       // draws per proof in `tape`: m(2n+4) for a lone proof, the whole entity's slots when the sub-proofs of a policy share one stream
+    // Which proof is chunk-local proof b?  A call proves `sub_k` equal-sized sub-proofs per ROW (an entity of a policy's plan: its
+    // individual proofs, or the equal parts of a split -- src/range/padding.rs:104-112, splitting.rs:110-123; 1 for a lone proof per
+    // row): proof g = p0 + b of the call is sub-proof j = g % sub_k of row e = g / sub_k (proof_row below).  The row owns the RNG
+    // stream and the tape row; the sub-proof's draws start sub_slots = m(2n+4) after its predecessor's.
+    const uint64_t* stream_id;  // [rows] of the CALL (not of the chunk)
+    uint64_t slot_base;         // first slot of sub-proof 0
+    const uint32_t* tape;       // [rows][tape_stride][16] or null; sub-proof 0's slots start at the pointer
+    uint32_t tape_stride;       // draws per row in `tape`: m(2n+4) for a lone proof, the whole entity's slots when the sub-proofs of a policy share one stream
+    uint32_t sub_k, sub_slots;
+    size_t p0;                  // call-wide index of this chunk's first proof
     // scratch
     sc* a; sc* b; sc* s1; sc* s2;       // [B][N] each
     // Coefficient TABLES (null: the s-vectors themselves are folded every round, as before round 3).  The coefficient of
@@ -58,7 +64,8 @@ struct RangeArgs {
     int tail_n;                         // T = length of the tail argument (32 / 64 / 128): 2T generators are materialised
     int32_t* tailT;                     // [B][2T][TAIL_ENTRIES][32]  per-proof window tables of the materialised folded generators
     sc* tail_a; sc* tail_b; sc* tail_s1; sc* tail_s2;   // [B][T] each: the vectors / coefficients of the tail argument
-    uint32_t* out;                      // [B][out_words]
+    uint32_t* out;                      // of the CALL: row e's sub-proof j at out + e * out_stride + j * out_words
+    size_t out_stride;                  // words between rows (= out_words for a lone proof per row)
     int out_words;
     int out_round0;                     // rounds already written before this argument's round 0 (tail: lgN - 5)
 };
@@ -73,14 +80,27 @@ enum { TAIL_WBITS = DAPOL_TAIL_WBITS, TAIL_NWIN = 253 / TAIL_WBITS + 1, TAIL_ENT
 enum { MSM_PLAIN = 0, MSM_MATERIALIZE = 1, MSM_TAIL = 2 };
 enum { STAB_ROUNDS = 6, STAB_N = 1 << STAB_ROUNDS };      // coefficient tables serve arguments that need at most TG_6 (64 entries)
 
+__device__ __forceinline__ void proof_row(const RangeArgs& A, size_t b, size_t& e, uint32_t& j) {
+    const size_t g = A.p0 + b;
+    if (A.sub_k <= 1) { e = g; j = 0; }
+    else { e = g / A.sub_k; j = (uint32_t)(g - e * A.sub_k); }
+}
+__device__ __forceinline__ uint32_t* proof_out(const RangeArgs& A, size_t b) {
+    size_t e; uint32_t j;
+    proof_row(A, b, e, j);
+    return A.out + e * A.out_stride + (size_t)j * (size_t)A.out_words;
+}
 __device__ __forceinline__ void tape_wide(uint32_t* w16, const RangeArgs& A, size_t b, uint32_t slot) {
+    size_t e; uint32_t j;
+    proof_row(A, b, e, j);
+    const uint32_t first = j * A.sub_slots;
     if (A.tape) {
-        const uint4* p = reinterpret_cast<const uint4*>(A.tape + ((size_t)b * (size_t)A.tape_stride + slot) * 16);
+        const uint4* p = reinterpret_cast<const uint4*>(A.tape + (e * (size_t)A.tape_stride + first + slot) * 16);
         for (int i = 0; i < 4; i++) { uint4 q = p[i]; w16[4 * i] = q.x; w16[4 * i + 1] = q.y; w16[4 * i + 2] = q.z; w16[4 * i + 3] = q.w; }
     } else {
         uint32_t key[8];
         for (int i = 0; i < 8; i++) key[i] = A.st[b].nkey[i];
-        seed_wide(w16, key, 2u, A.stream_id[b], A.slot_base + slot);
+        seed_wide(w16, key, 2u, A.stream_id[e], A.slot_base + first + slot);
     }
 }
 // Seed mode: the key of one proof's nonce stream.  The reference's prover draws fresh thread_rng randomness on every call;
@@ -93,7 +113,9 @@ __global__ __launch_bounds__(64) void k_rp_nonce_key(RangeArgs A) {
     if (b >= A.B || A.tape) return;
     uint32_t key[8], w[16];
     for (int i = 0; i < 8; i++) key[i] = A.seed[i];
-    seed_wide(w, key, 6u, A.stream_id[b], A.slot_base);
+    size_t e; uint32_t sj;
+    proof_row(A, b, e, sj);
+    seed_wide(w, key, 6u, A.stream_id[e], A.slot_base + (uint64_t)sj * A.sub_slots);
     for (int i = 0; i < 8; i++) key[i] = w[i];
     seed_wide(w, key, 7u, (uint64_t)A.n, (uint64_t)A.m);
     for (int i = 0; i < 8; i++) key[i] = w[i];
@@ -708,7 +730,7 @@ __global__ __launch_bounds__(64) void k_rp_finish1(RangeArgs A, TableView tbl) {
     }
     F.share(Ac, Sc);
     if (!F.owns_transcript()) return;
-    uint32_t* out = A.out + b * A.out_words;
+    uint32_t* out = proof_out(A, b);
     if (F.writes()) { st8(out, Ac); st8(out + 8, Sc); }
     typename FsShape<MODE>::strobe_t s;
     F.begin(s);
@@ -826,7 +848,7 @@ __global__ __launch_bounds__(64) void k_rp_finish2(RangeArgs A, TableView tbl) {
     }
     F.share(T1c, T2c);
     if (!F.owns_transcript()) return;
-    uint32_t* out = A.out + b * A.out_words;
+    uint32_t* out = proof_out(A, b);
     if (F.writes()) { st8(out + 16, T1c); st8(out + 24, T2c); }
     typename FsShape<MODE>::strobe_t s;
     F.begin(s);
@@ -919,7 +941,7 @@ __global__ __launch_bounds__(64) void k_rp_finish3(RangeArgs A) {
     sc_from_mont(c_tx, t_x);
     sc_from_mont(c_tau, tau);
     sc_from_mont(c_mu, mu);
-    uint32_t* out = A.out + b * A.out_words;
+    uint32_t* out = proof_out(A, b);
     if (writes) {
         st8(out + 32, c_tx);
         st8(out + 40, c_tau);
@@ -1003,7 +1025,7 @@ __global__ __launch_bounds__(64) void k_rp_round_finish(RangeArgs A, TableView t
     }
     F.share(Lc, Rc);
     if (!F.owns_transcript()) return;
-    uint32_t* out = A.out + b * A.out_words + 56 + 16 * (A.out_round0 + round);
+    uint32_t* out = proof_out(A, b) + 56 + 16 * (A.out_round0 + round);
     if (F.writes()) { st8(out, Lc); st8(out + 8, Rc); }
     typename FsShape<MODE>::strobe_t s;
     F.begin(s);
@@ -1107,7 +1129,7 @@ __global__ __launch_bounds__(64) void k_rp_final(RangeArgs A, uint32_t* err_flag
     uint32_t c[8];
     ld_sc(a, A.a + b * A.N);
     ld_sc(bb, A.b + b * A.N);
-    uint32_t* out = A.out + b * A.out_words + 56 + 16 * (A.out_round0 + A.lgN);
+    uint32_t* out = proof_out(A, b) + 56 + 16 * (A.out_round0 + A.lgN);
     sc_from_mont(c, a);
     st8(out, c);
     sc_from_mont(c, bb);

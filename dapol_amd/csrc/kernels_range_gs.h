@@ -144,10 +144,62 @@ __global__ __launch_bounds__(64, DAPOL_GS_OCC) void k_rp_msm_gs(RangeArgs A, Tab
     }
 }
 
+// The sweep of SHORT lists (round 6: large batches of proofs of few parties -- a policy's individual proofs, 64 generators a side).
+// With so few terms per list the Horner combine is no longer small change (252 addition-equivalents against 64 x 15 additions), so
+// the lane owns (proof, window w < LW = TableView::hi_split) and looks every term up TWICE -- digit w in the generator's row, digit
+// w + LW in its 2^(W LW) row, as k_rp_msm does for small calls -- which halves the window sums to combine (119 doublings + 7
+// additions per list).  Same digit matrix (L_dig = B * nwin lanes), accumulators SoA over Ltot = B * LW * gridDim.y lanes.  A copy
+// of the kernel above rather than a flag in it: that one is the headline's and stays as measured.
+__global__ __launch_bounds__(64, DAPOL_GS_OCC) void k_rp_msm_gs_hi(RangeArgs A, TableView tbl, int round, int side, int q0, int nq, int first, int32_t* __restrict__ accs,
+                                                                  int slice_rows, int LW) {
+    const size_t L = A.B * (size_t)LW, Ltot = L * gridDim.y, Ld = A.B * (size_t)A.nwin;
+    const size_t lane = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (lane >= L) return;
+    q0 += (int)blockIdx.y * slice_rows;
+    const int w = (int)(lane / A.B);
+    const bool has_hi = w + LW < A.nwin;                                     // (15 windows, LW = 8: window 7 has no partner)
+    ge_p3 acc;
+    int32_t* ap = accs + (size_t)blockIdx.y * L + lane;
+    if (first) ge_identity(acc);
+    else {
+#pragma unroll
+        for (int i = 0; i < FE_NL; i++) {
+            acc.X.v[i] = ap[(size_t)i * Ltot]; acc.Y.v[i] = ap[(size_t)(FE_NL + i) * Ltot];
+            acc.Z.v[i] = ap[(size_t)(2 * FE_NL + i) * Ltot]; acc.T.v[i] = ap[(size_t)(3 * FE_NL + i) * Ltot];
+        }
+    }
+    const dapol_v4i* dg = reinterpret_cast<const dapol_v4i*>(A.dig) + ((size_t)(side * A.N + q0) >> 2) * Ld + lane;
+    const dapol_v4i* dh = dg + (has_hi ? (size_t)LW * A.B : 0);
+    dapol_v4i d4 = dg[0], h4 = dh[0], dn = d4, hn = h4;
+    // ONE copy of the addition (instruction cache): a term's two lookups are two trips
+#pragma nounroll
+    for (int i2 = 0; i2 < 2 * nq; i2++) {
+        const int i = i2 >> 1, hi = i2 & 1;
+        if (!hi && (i & 3) == 0 && i + 4 < nq) { dn = dg[(size_t)((i >> 2) + 1) * Ld]; hn = dh[(size_t)((i >> 2) + 1) * Ld]; }
+        int d;
+        if (!hi) { d = d4.x; d4.x = d4.y; d4.y = d4.z; d4.z = d4.w; }
+        else {
+            d = h4.x;
+            h4.x = h4.y; h4.y = h4.z; h4.z = h4.w;
+            if ((i & 3) == 3) { d4 = dn; h4 = hn; }
+            if (!has_hi) continue;                                           // (uniform over a wavefront but for the one that straddles two windows)
+        }
+        bool isH;
+        const int j = term_generator(round, A.N, A.lgN, side, q0 + i, isH);      // (uniform over a block)
+        const int row = gen_row(tbl, A.n, j, isH);
+        tbl_madd(acc, tbl, hi ? tbl.row_hi(row) : row, d);
+    }
+#pragma unroll
+    for (int i = 0; i < FE_NL; i++) {
+        ap[(size_t)i * Ltot] = acc.X.v[i]; ap[(size_t)(FE_NL + i) * Ltot] = acc.Y.v[i];
+        ap[(size_t)(2 * FE_NL + i) * Ltot] = acc.Z.v[i]; ap[(size_t)(3 * FE_NL + i) * Ltot] = acc.T.v[i];
+    }
+}
+
 // Slices of a sweep -> slice 0: one lane per (side, window, proof), nslice - 1 additions.  accs: both sides' accumulators,
 // side_words apart, each SoA over Ltot = L * nslice lanes.
-__global__ __launch_bounds__(64) void k_rp_gs_sum_slices(RangeArgs A, int32_t* __restrict__ accs, size_t side_words, int nslice) {
-    const size_t L = A.B * (size_t)A.nwin, Ltot = L * (size_t)nslice;
+__global__ __launch_bounds__(64) void k_rp_gs_sum_slices(RangeArgs A, int32_t* __restrict__ accs, size_t side_words, int nslice, int LW) {
+    const size_t L = A.B * (size_t)LW, Ltot = L * (size_t)nslice;
     const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (t >= 2 * L) return;
     const int side = t >= L ? 1 : 0;
@@ -175,8 +227,9 @@ __global__ __launch_bounds__(64) void k_rp_gs_sum_slices(RangeArgs A, int32_t* _
 
 // P_side[p] = sum_w 2^(W w) * acc_side[w * cb + p]: Horner from the top window, one lane per (side, proof) -- both lists of a
 // round in one launch (accs: the two sides' accumulators, side_words apart; SoA over L * nslice lanes, the sums in slice 0).
-__global__ __launch_bounds__(64) void k_rp_gs_combine(RangeArgs A, const int32_t* __restrict__ accs, size_t side_words, int nslice) {
-    const size_t Ltot = A.B * (size_t)A.nwin * (size_t)nslice;
+// LW = window sums per list: nwin, or TableView::hi_split when the sweep looked every term up twice (k_rp_msm_gs_hi).
+__global__ __launch_bounds__(64) void k_rp_gs_combine(RangeArgs A, const int32_t* __restrict__ accs, size_t side_words, int nslice, int LW) {
+    const size_t Ltot = A.B * (size_t)LW * (size_t)nslice;
     const size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
     if (t >= 2 * A.B) return;
     const int side = t >= A.B ? 1 : 0;
@@ -190,9 +243,9 @@ __global__ __launch_bounds__(64) void k_rp_gs_combine(RangeArgs A, const int32_t
         }
     };
     ge_p3 acc, t2, r;
-    load(acc, A.nwin - 1);
+    load(acc, LW - 1);
 #pragma nounroll
-    for (int w = A.nwin - 2; w >= 0; w--) {
+    for (int w = LW - 2; w >= 0; w--) {
 #pragma nounroll
         for (int d = 0; d < A.wbits; d++) ge_dbl(acc, acc, d == A.wbits - 1);
         load(t2, w);

@@ -127,6 +127,12 @@ const char* dapol_last_error(void);
 /* Diagnostics: how many times a call was left between a fork onto one of the context's side streams and the matching join (an error
  * return) and therefore waited for that stream before returning, process-wide.  0 in a healthy run. */
 int32_t dapol_diag_fork_guard_waits(uint64_t* count);
+/* Diagnostics: combined (random-linear-combination) checks of dapol_range_verify_batch / dapol_verify_* that failed and went on to
+ * bisection or the proof-by-proof check, process-wide.  Stays 0 while every proof handed in is valid. */
+int32_t dapol_diag_verify_fallbacks(uint64_t* count);
+/* Diagnostics: device milliseconds of the proving pipeline of the last dapol_range_prove_batch in this process (HIP events on the
+ * context's stream: inputs already in HBM, proofs not yet copied back). */
+int32_t dapol_diag_range_prove_ms(double* ms);
 
 /* DapolNode::new (src/dapol/node.rs:29-45), batched: C_i = v_i*B + r_i*B_blinding (compressed), H_i = D(C_i).
  * r may be an unreduced Scalar::from_bits value (bit 255 clear; src/dapol/mod.rs:385). */

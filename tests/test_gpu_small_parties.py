@@ -1,0 +1,167 @@
+"""Proofs of FEW parties in batches (round 6): the individual proofs a policy leaves per sibling beyond aggregation_factor
+(/root/reference/src/range/padding.rs:104-112, splitting.rs:118-123, src/range/mod.rs:48-62) are proved as ONE grouped call per run of
+equal-sized sub-proofs (host_range.inc: prove_policy_device, RangeArgs::sub_k), and large batches of short lists are swept
+generator-stationary with two lookups per term (k_rp_msm_gs_hi).  Bytes must not move: against the C oracle sub-proof by sub-proof
+(same stream, same first slot), against the ungrouped path, and under every arrangement of the sweep."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+SEED = bytes(range(32))
+
+
+def _plan(policy, height, agg):
+    """(start, count, m) per sub-proof -- policy_plan.inc restated for the checker."""
+    np2 = lambda x: 1 << max(0, (x - 1).bit_length())
+    plan = []
+    if policy == 0:
+        plan.append((0, agg, np2(agg) if agg else 1))
+    else:
+        base, pos = np2(agg) if agg else 1, 0
+        while pos < agg:
+            if agg & base:
+                plan.append((pos, base, base))
+                pos += base
+            base >>= 1
+    plan += [(i, 1, 1) for i in range(agg, height)]
+    return plan
+
+
+def _with_env(env, fn):
+    os.environ.update(env)
+    try:
+        return fn()
+    finally:
+        for k in env:
+            os.environ.pop(k, None)
+
+
+def _leaves(rng, height, n):
+    idx = np.sort(rng.choice(1 << height, size=n, replace=False).astype(np.uint64))
+    v = rng.integers(0, 2**40, size=n, dtype=np.uint64)
+    r = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    r[:, 31] &= 0x0F
+    return idx, v, r
+
+
+@pytest.mark.parametrize("height,policy,agg,n_bits", [(12, 0, 4, 64), (12, 1, 7, 64), (10, 0, 0, 64), (11, 1, 6, 32), (9, 0, 8, 64), (10, 1, 10, 64)])
+def test_grouped_policy_proofs_vs_c_oracle(gpu_ctx, hip_lib, ref, height, policy, agg, n_bits):
+    """Every sub-proof of every entity against ref_range_prove_batch with the entity's stream and the sub-proof's first slot; the
+    grouped call (default), the one-call-per-sub-proof path (DAPOL_NO_GROUP) and the short-list sweep forced onto this batch
+    (DAPOL_GS_SMALL_MIN) give the same bytes."""
+    rng = np.random.default_rng(height * 100 + agg)
+    n = 24
+    idx, v, r = _leaves(rng, height, n)
+    tr = hip_lib.Tree(gpu_ctx, height, idx, v, r, SEED)
+    pC, pH, got = tr.prove_entities(idx, policy, agg, n_bits, SEED)
+    # siblings' secrets from the C oracle's own tree (also checks the paths the prover saw)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    t = ctypes.c_void_p(ref.ref_tree_build(height, ctypes.c_size_t(n), p(idx), p(v), p(r), SEED, 0))
+    plan = _plan(policy, height, agg)
+    for e in range(0, n, 5):
+        sC, sH = ctypes.create_string_buffer(32 * height), ctypes.create_string_buffer(32 * height)
+        svv, srr = (ctypes.c_uint64 * height)(), ctypes.create_string_buffer(32 * height)
+        assert ref.ref_tree_path(t, ctypes.c_uint64(int(idx[e])), sC, sH, svv, srr) == 1
+        assert pC[e].tobytes() == sC.raw
+        want, slot = b"", 0
+        for start, count, m in plan:
+            vv = np.zeros(m, np.uint64)
+            rr = np.zeros((m, 32), np.uint8)
+            rr[:, 0] = 1                                        # pad parties: (0, Scalar::one())
+            for j in range(count):
+                vv[j] = svv[start + j]
+                rr[j] = np.frombuffer(srr.raw[32 * (start + j):32 * (start + j + 1)], np.uint8)
+            ps = ref.ref_range_proof_size(n_bits, m)
+            out = ctypes.create_string_buffer(ps)
+            sid = np.array([idx[e]], np.uint64)
+            assert ref.ref_range_prove_batch(n_bits, m, ctypes.c_size_t(1), p(vv), p(rr), SEED, p(sid), ctypes.c_uint64(slot), None, 0, out) == 0
+            want += out.raw
+            slot += m * (2 * n_bits + 4)
+        assert got[e].tobytes() == want, (e, "entity differs from the oracle")
+    ref.ref_tree_free(t)
+    for env in ({"DAPOL_NO_GROUP": "1"}, {"DAPOL_GS_SMALL_MIN": "64"}, {"DAPOL_GS_SMALL_MIN": "64", "DAPOL_NO_GS_HI": "1"},
+                {"DAPOL_GS_SMALL_MIN": "64", "DAPOL_CHUNK": "67"}, {"DAPOL_CHUNK": "5"}, {"DAPOL_CHUNK": "13", "DAPOL_STREAMS": "3"}):
+        again = _with_env(env, lambda: tr.prove_entities(idx, policy, agg, n_bits, SEED)[2])
+        assert again.tobytes() == got.tobytes(), env
+
+
+@pytest.mark.parametrize("n_bits,m", [(64, 1), (64, 2), (64, 4), (64, 8), (32, 2), (8, 8), (16, 16)])
+def test_short_list_sweep_gives_the_same_bytes(gpu_ctx, ref, n_bits, m):
+    """dapol_range_prove_batch of proofs of 64 ... 512 generators a side: the proof-stationary default of a batch this small against the
+    generator-stationary sweep (two lookups per term, plain, sliced, other tiles, ragged chunks), and the first proofs against the
+    C oracle."""
+    b = 150
+    rng = np.random.default_rng(n_bits + 7 * m)
+    v = rng.integers(0, 2**n_bits if n_bits < 64 else 2**63, size=(b, m), dtype=np.uint64)
+    r = rng.integers(0, 256, size=(b, m, 32), dtype=np.uint8)
+    r[:, :, 31] &= 0x0F
+    sid = rng.integers(0, 2**62, size=b, dtype=np.uint64)
+    base = gpu_ctx.range_prove_batch(n_bits, m, v, r, nonce_seed=SEED, stream_id=sid, slot_base=3)
+    k = 6
+    ps = ref.ref_range_proof_size(n_bits, m)
+    out = ctypes.create_string_buffer(ps * k)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    assert ref.ref_range_prove_batch(n_bits, m, ctypes.c_size_t(k), p(v), p(r), SEED, p(sid), ctypes.c_uint64(3), None, 0, out) == 0
+    assert base[:k].tobytes() == out.raw
+    G = {"DAPOL_GS_SMALL_MIN": "64"}
+    for extra in ({}, {"DAPOL_NO_GS_HI": "1"}, {"DAPOL_GS_SLICES": "2"}, {"DAPOL_GS_SLICES": "1", "DAPOL_GS_TILE": "4"}, {"DAPOL_GS_TILE": "64"},
+                  {"DAPOL_CHUNK": "64"}, {"DAPOL_CHUNK": "70", "DAPOL_STREAMS": "2"}, {"DAPOL_FS_SHAPE": "0"}, {"DAPOL_FS_SHAPE": "1"},
+                  {"DAPOL_NO_STAB": "1"}, {"DAPOL_TAIL_N": "32"}, {"DAPOL_TAIL_N": "64", "DAPOL_NO_GS_HI": "1"}):
+        env = dict(G, **extra)
+        got = _with_env(env, lambda: gpu_ctx.range_prove_batch(n_bits, m, v, r, nonce_seed=SEED, stream_id=sid, slot_base=3))
+        assert got.tobytes() == base.tobytes(), env
+
+
+def test_grouped_tape_mode_equals_seed_mode(gpu_ctx, hip_lib, pyref):
+    """Tape mode through a grouped plan: the draws of entity e's sub-proof j sit at the row's slots slot_base + j m (2n + 4) ... --
+    replaying the seed mode's own draws must give the seed mode's bytes (dapol_prove_entities_tape, RangeArgs::sub_slots)."""
+    height, agg, n_bits, n = 6, 3, 8, 7
+    rng = np.random.default_rng(11)
+    idx = np.sort(rng.choice(1 << height, size=n, replace=False).astype(np.uint64))
+    v = rng.integers(0, 8, size=n, dtype=np.uint64)
+    r = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    r[:, 31] &= 0x0F
+    tr = hip_lib.Tree(gpu_ctx, height, idx, v, r, SEED)
+    for policy in (0, 1):
+        pC, pH, seed_mode = tr.prove_entities(idx, policy, agg, n_bits, SEED)
+        plan = _plan(policy, height, agg)
+        Bb = gpu_ctx.generator(1)
+        rows = []
+        for e in range(n):
+            row, slot = b"", 0
+            for start, count, m in plan:
+                Vs = [pC[e, start + j].tobytes() if j < count else Bb for j in range(m)]
+                key = pyref.nonce_key(SEED, int(idx[e]), slot, n_bits, m, Vs)
+                row += b"".join(pyref.seed_wide(key, 2, int(idx[e]), slot + k) for k in range(m * (2 * n_bits + 4)))
+                slot += m * (2 * n_bits + 4)
+            rows.append(row)
+        tape = np.frombuffer(b"".join(rows), np.uint8)
+        got = tr.prove_entities(idx, policy, agg, n_bits, None, tape=tape)[2]
+        assert got.tobytes() == seed_mode.tobytes(), policy
+        again = _with_env({"DAPOL_NO_GROUP": "1"}, lambda: tr.prove_entities(idx, policy, agg, n_bits, None, tape=tape)[2])
+        assert again.tobytes() == seed_mode.tobytes()
+
+
+def test_large_batch_of_individual_proofs_round_trip(gpu_ctx, hip_lib):
+    """Size-independent property at a size the oracle cannot reach: 2^11 entities at aggregation 0 on a height-16 tree = 34,816
+    individual proofs through the default path (the short-list sweep, chunks of whole rounds) verify on the GPU, and a grouped call
+    equals the ungrouped one on a sample."""
+    height, n = 16, 1 << 11
+    rng = np.random.default_rng(3)
+    idx, v, r = _leaves(rng, height, n)
+    tr = hip_lib.Tree(gpu_ctx, height, idx, v, r, SEED)
+    pC, pH, proofs = tr.prove_entities(idx, 0, 0, 64, SEED)
+    root = tr.root()
+    lC, lH = gpu_ctx.commit_hash_batch(v, r)
+    ok = gpu_ctx.verify_entities(height, idx, lC, lH, pC, pH, root[0], root[1], 0, 0, 64, proofs, verify_seed=SEED)
+    assert ok.all()
+    sel = idx[::97]
+    small = tr.prove_entities(sel, 0, 0, 64, SEED)[2]                  # 22 entities: 374 proofs, proof-stationary
+    assert small.tobytes() == proofs[::97].tobytes()
+    bad = proofs.copy()
+    bad[5, 700] ^= 1                                                   # inside the first individual proof of entity 5
+    ok = gpu_ctx.verify_entities(height, idx, lC, lH, pC, pH, root[0], root[1], 0, 0, 64, bad, verify_seed=SEED)
+    assert not ok[5] and ok.sum() == n - 1
