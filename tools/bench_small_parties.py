@@ -30,7 +30,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--entities", type=int, default=14)
     ap.add_argument("--proofs", type=int, default=17)
-    ap.add_argument("--only", choices=("policy", "batch"), default=None)
+    ap.add_argument("--only", choices=("policy", "batch", "verify"), default=None)
+    ap.add_argument("--verify-entities", type=int, default=13)
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--aggs", default="32,24,8,0")
     ap.add_argument("--ms", default="1,2,4,8")
@@ -40,6 +41,34 @@ def main():
     ctx = capi.Context(0, 32)
     rng = np.random.default_rng(5)
     out = {}
+    if args.only == "verify":
+        # DapolProof::verify (src/proof/mod.rs:41-47) of entities whose range proofs are mostly individual ones: host-inclusive wall time
+        n = 1 << args.verify_entities
+        idx = np.arange(n, dtype=np.uint64) * np.uint64((1 << height) // n)
+        v = rng.integers(0, 2**32, size=n, dtype=np.uint64)
+        r = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+        r[:, 31] &= 0x0F
+        tree = capi.Tree(ctx, height, idx, v, r, seed)
+        rC, rH, _, _ = tree.root()
+        lC, lH = ctx.commit_hash_batch(v, r)
+        fb = ctypes.c_uint64()
+        for agg in [int(a) for a in args.aggs.split(",")]:
+            pC, pH, proofs = tree.prove_entities(idx, capi.POLICY_PADDING, agg, n_bits, seed)
+            vargs = (height, idx, lC, lH, pC, pH, rC, rH, capi.POLICY_PADDING, agg, n_bits)
+            ctx.verify_entities(*[a[:64] if isinstance(a, np.ndarray) else a for a in vargs], proofs[:64], verify_seed=seed)
+            best = None
+            for _ in range(args.reps):
+                t0 = time.perf_counter()
+                ok = ctx.verify_entities(*vargs, proofs, verify_seed=seed)
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            capi.lib().dapol_diag_verify_fallbacks(ctypes.byref(fb))
+            row = {"entities": n, "verify_s": best, "entities_per_s": n / best, "all_verified": bool(ok.all()), "fallbacks_so_far": int(fb.value),
+                   "mb_in": (pC.nbytes + pH.nbytes + proofs.nbytes) / 1e6}
+            out["verify_padding_agg%d" % agg] = row
+            print("verify", agg, json.dumps(row), flush=True)
+        print(json.dumps(out), flush=True)
+        return
     if args.only != "batch":
         n = 1 << args.entities
         idx = np.arange(n, dtype=np.uint64) * np.uint64((1 << height) // n)
