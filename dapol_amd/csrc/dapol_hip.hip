@@ -559,7 +559,7 @@ static int32_t tree_build_device_core(dapol_ctx* ctx, int index_bits, int shard_
     t->levels.resize((size_t)height + 1);
     t->n_pad = 0;
     t->n_real = 0;
-    DevBuf<uint32_t> bad, seed, flag, pos, head, bsums, cnt;
+    DevBuf<uint32_t> bad, seed, cnt;
     HIPCHK(bad.alloc(1)); HIPCHK(seed.alloc(8)); HIPCHK(cnt.alloc((size_t)height + 2));
     HIPCHK(hipMemsetAsync(bad.p, 0, 4, st));
     HIPCHK(hipMemcpyAsync(seed.p, pad_seed32, 32, hipMemcpyHostToDevice, st));
@@ -608,7 +608,6 @@ static int32_t tree_build_device_core(dapol_ctx* ctx, int index_bits, int shard_
     }
     const uint32_t n32 = (uint32_t)n;
     HIPCHK(hipMemcpyAsync(cnt.p, &n32, 4, hipMemcpyHostToDevice, st));
-    DevBuf<int32_t> ext_a, ext_b;
     const bool phased = n <= (size_t)TREE_SMALL_MAX && height >= 1 && !knob("DAPOL_TREE_LEVELWISE") && !d_tape;     // (tape mode: the level-wise kernel reads the tape)
     DevBuf<uint32_t> tape_short;
     HIPCHK(tape_short.alloc(1));
@@ -659,24 +658,45 @@ static int32_t tree_build_device_core(dapol_ctx* ctx, int index_bits, int shard_
             LAUNCH_CHECK();
         }
     } else {
-    HIPCHK(flag.alloc(n)); HIPCHK(pos.alloc(n)); HIPCHK(head.alloc(n)); HIPCHK(bsums.alloc(nblk(n, 1024) + 1));
-    HIPCHK(ext_a.alloc(n * 40)); HIPCHK(ext_b.alloc(n * 40));
-    hipLaunchKernelGGL(k_commit_hash, dim3(nblk(n, 256)), dim3(256), 0, st, ctx->tv, n, d_v, d_r, t->levels[0].C.p, t->levels[0].H.p, ext_a.p);
+    // The padding children of a level are made in a launch of their own (k_tree_pad_level) and the merge reads them back
+    // (k_tree_merge<1>): fused, the kernel needed 262 VGPRs + 6 AGPRs and 624 bytes of scratch per lane -- one wavefront per SIMD --;
+    // apart, 178 and 226 VGPRs, two wavefronts each: 2^20 leaves x height 32 in 36.0 ms instead of 43.8, same root
+    // (profiles/r6_tree_split_ab.txt).  Tape mode keeps the fused kernel (it reads the tape by rank); DAPOL_TREE_SPLIT=0 restores it.
+    const bool split_pad = !d_tape && !(knob("DAPOL_TREE_SPLIT") && atoi(knob("DAPOL_TREE_SPLIT")) == 0);
+    // temporaries out of the context's scratch (as the phased path): seven hipMalloc / hipFree pairs per build otherwise, and a
+    // hipFree waits for the device
+    struct { uint32_t *flag, *pos, *head, *bsums; int32_t *ext_a, *ext_b, *ext_pad; } tmp;
+    {
+        size_t need = 0;
+        auto take = [&](size_t bytes) { size_t o = need; need += align_up(bytes, 256); return o; };
+        const size_t o_flag = take(n * 4), o_pos = take(n * 4), o_head = take(n * 4), o_bs = take((nblk(n, 1024) + 1) * 4), o_a = take(n * 160), o_b = take(n * 160),
+                     o_p = take(split_pad ? n * 160 : 16);
+        HIPCHK(ctx->scratch.ensure(need));
+        uint8_t* b = (uint8_t*)ctx->scratch.p;
+        tmp.flag = (uint32_t*)(b + o_flag); tmp.pos = (uint32_t*)(b + o_pos); tmp.head = (uint32_t*)(b + o_head); tmp.bsums = (uint32_t*)(b + o_bs);
+        tmp.ext_a = (int32_t*)(b + o_a); tmp.ext_b = (int32_t*)(b + o_b); tmp.ext_pad = (int32_t*)(b + o_p);
+    }
+    hipLaunchKernelGGL(k_commit_hash, dim3(nblk(n, 256)), dim3(256), 0, st, ctx->tv, n, d_v, d_r, t->levels[0].C.p, t->levels[0].H.p, tmp.ext_a);
     LAUNCH_CHECK();
-    int32_t* ext_cur = ext_a.p;
-    int32_t* ext_nxt = ext_b.p;
+    int32_t* ext_cur = tmp.ext_a;
+    int32_t* ext_nxt = tmp.ext_b;
     for (int k = 0; k < height; k++) {                    // launches only: nothing here waits for the device
         LevelView cur = t->view(k, ext_cur);
-        hipLaunchKernelGGL(k_tree_flags, dim3(nblk(bound[k], 256)), dim3(256), 0, st, cnt.p + k, cur.idx, flag.p);
+        hipLaunchKernelGGL(k_tree_flags, dim3(nblk(bound[k], 256)), dim3(256), 0, st, cnt.p + k, cur.idx, tmp.flag);
         LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_scan_block, dim3(nblk(bound[k], 1024)), dim3(256), 0, st, cnt.p + k, flag.p, pos.p, bsums.p);
+        hipLaunchKernelGGL(k_scan_block, dim3(nblk(bound[k], 1024)), dim3(256), 0, st, cnt.p + k, tmp.flag, tmp.pos, tmp.bsums);
         LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, st, cnt.p + k, bsums.p, cnt.p + k + 1);
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, st, cnt.p + k, tmp.bsums, cnt.p + k + 1);
         LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_scan_finish, dim3(nblk(bound[k], 256)), dim3(256), 0, st, cnt.p + k, flag.p, pos.p, bsums.p, head.p);
+        hipLaunchKernelGGL(k_scan_finish, dim3(nblk(bound[k], 256)), dim3(256), 0, st, cnt.p + k, tmp.flag, tmp.pos, tmp.bsums, tmp.head);
         LAUNCH_CHECK();
         LevelView nxt = t->view(k + 1, k + 1 < height ? ext_nxt : nullptr);
-        hipLaunchKernelGGL(k_tree_merge, dim3(nblk(bound[k + 1], 256)), dim3(256), 0, st, ctx->tv, cur, nxt, head.p, k, seed.p, cnt.p, ptape);
+        if (split_pad) {
+            hipLaunchKernelGGL(k_tree_pad_level, dim3(nblk(bound[k + 1], 256)), dim3(256), 0, st, ctx->tv, cur, tmp.head, k, seed.p, cnt.p, tmp.ext_pad);
+            LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_tree_merge<1>, dim3(nblk(bound[k + 1], 256)), dim3(256), 0, st, ctx->tv, cur, nxt, tmp.head, k, seed.p, cnt.p, ptape, tmp.ext_pad);
+        } else
+            hipLaunchKernelGGL(k_tree_merge<0>, dim3(nblk(bound[k + 1], 256)), dim3(256), 0, st, ctx->tv, cur, nxt, tmp.head, k, seed.p, cnt.p, ptape, (const int32_t*)nullptr);
         LAUNCH_CHECK();
         std::swap(ext_cur, ext_nxt);
     }

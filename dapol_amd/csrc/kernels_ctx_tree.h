@@ -255,8 +255,13 @@ struct PadTape {
     uint32_t n_draws;
     uint32_t* short_flag;      // set when the tree needs more draws than the tape holds
 };
+// SPLIT = 1 (round 6 experiment, DAPOL_TREE_SPLIT=1): the padding children of the level were made by k_tree_pad_level just before --
+// their records are read from padC / padH / padr and their points from extpad[q] -- so that neither kernel holds a fixed-base
+// product, two encodings and three hashes in one register allocation.
+template <int SPLIT>
 __global__ __launch_bounds__(256) void k_tree_merge(TableView tbl, LevelView cur, LevelView nxt, const uint32_t* head, int level,
-                                                    const uint32_t* pad_seed /*8 words*/, const uint32_t* cnt /*[levels + 1], device*/, PadTape tape) {
+                                                    const uint32_t* pad_seed /*8 words*/, const uint32_t* cnt /*[levels + 1], device*/, PadTape tape,
+                                                    const int32_t* extpad) {
     size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t cur_n = cnt[level], nxt_n = cnt[level + 1];           // (cur.n / nxt.n are only host-side bounds during the build)
     if (q >= nxt_n) return;
@@ -279,6 +284,12 @@ __global__ __launch_bounds__(256) void k_tree_merge(TableView tbl, LevelView cur
         cur.has_pad[i] = 0;
         cur.has_pad[i + 1] = 0;
         cur.parent[i + 1] = (uint32_t)q;
+    } else if (SPLIT) {
+        ld8(cB, cur.padC + i * 8);
+        ld8(hB, cur.padH + i * 8);
+        ld8(rB, cur.padr + i * 8);
+        ld_p3(pB, extpad + q * 40);
+        cur.has_pad[i] = 1;
     } else {
         uint32_t seed[8], wide[16];
         if (tape.draws) {
@@ -322,6 +333,32 @@ __global__ __launch_bounds__(256) void k_tree_merge(TableView tbl, LevelView cur
     st8(nxt.C + q * 8, cp);
     st8(nxt.H + q * 8, hp);
     if (nxt.ext) st_p3(nxt.ext + q * 40, pp);
+}
+
+// The padding children of one level on their own (seed mode): Paddable::padding for every parent q whose second child is not real.
+__global__ __launch_bounds__(256) void k_tree_pad_level(TableView tbl, LevelView cur, const uint32_t* head, int level, const uint32_t* pad_seed,
+                                                        const uint32_t* cnt, int32_t* extpad) {
+    size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t cur_n = cnt[level], nxt_n = cnt[level + 1];
+    if (q >= nxt_n) return;
+    size_t i = head[q];
+    uint64_t my_idx = cur.idx[i];
+    if ((i + 1 < cur_n) && (cur.idx[i + 1] == (my_idx ^ 1ull))) return;
+    uint32_t seed[8], wide[16], rB[8], cB[8], hB[8];
+    for (int k = 0; k < 8; k++) seed[k] = pad_seed[k];
+    seed_wide(wide, seed, 1u, (uint64_t)level, my_idx ^ 1ull);
+    sc rm;
+    sc_from_wide(rm, wide);
+    sc_from_mont(rB, rm);
+    ge_p3 pB;
+    ge_identity(pB);
+    tbl_fixed_mul_add(pB, tbl, tbl.row_Bb(0), rB);
+    ge_compress(cB, pB);
+    node_hash32(tbl.digest, hB, cB);
+    st8(cur.padC + i * 8, cB);
+    st8(cur.padH + i * 8, hB);
+    st8(cur.padr + i * 8, rB);
+    st_p3(extpad + q * 40, pB);
 }
 
 // ------------------------------------------------------------------------------------- incremental update

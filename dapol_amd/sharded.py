@@ -67,7 +67,11 @@ def agreement_group(dist, comm_device, torch=None):
     ride the transport that may have just failed: when the default group is RCCL (comm_device "cuda") this is a side group over
     gloo / TCP with CPU tensors; a default group that already is gloo serves as it is (None).  Collective: every rank calls it at
     the same point.  If the side group cannot be made (a torch build without gloo), the agreement rides the default group with
-    device tensors -- weaker (torch's own RCCL communicator, not the library's, carries it) but never a rank deciding alone."""
+    device tensors -- weaker (torch's own RCCL communicator, not the library's, carries it) but never a rank deciding alone.
+    Precondition: dist.new_group is itself collective -- every rank must RETURN from it, with a group or with an
+    exception, for the all-reduce below to be reached by all of them; a rank that dies inside new_group leaves its peers in torch's
+    own rendezvous timeout, which nothing at this level can shorten.  What is handled here is the case that it returns everywhere
+    but raised on some ranks (no gloo in the build, a port it could not bind)."""
     if comm_device != "cuda":
         return None, "cpu"
     group = None
@@ -182,8 +186,18 @@ class ShardTransport:
         res, err = None, None
         try:
             res = call()
-        except BaseException as e:      # ANY failure on this rank (a ctypes / numpy error, an interrupt) must reach the agreement: the
-            err = e                     # peers are about to wait in it, and would sit there until gloo's own timeout
+        except Exception as e:          # ANY error on this rank (a ctypes / numpy error, not only a DapolError) must reach the
+            err = e                     # agreement: the peers are about to wait in it, and would sit there until gloo's own timeout
+        except BaseException:
+            # KeyboardInterrupt / SystemExit: this rank is LEAVING.  It must not enter another collective on its way out (it would
+            # block in it until the peers arrive or the timeout fires -- ADVICE r5): abort the communicator, which the peers' next
+            # library collective notices by its deadline, and go.
+            try:
+                self.comm.abort()
+            except Exception:
+                pass
+            self.comm, self.comm_ranks = None, None
+            raise
         agreed = self.agree(err is None)
         if err is not None and not isinstance(err, capi.DapolError):
             self.drop_comm(err)         # the peers have just learnt that this rank failed and drop theirs; this rank does not go on
