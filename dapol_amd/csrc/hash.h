@@ -155,12 +155,17 @@ DAPOL_HD void blake2s_hash128(uint32_t* out8, const uint32_t* cl, const uint32_t
 }
 // The node hash of the context's digest D (DG_BLAKE3 / DG_BLAKE2S): leaf = D(C) (src/dapol/node.rs:34-36),
 // parent = D(C_L || C_R || H_L || H_R) (node.rs:66-77, src/proof/node.rs:58-64).
+// On a 64-byte-digest context (DG_BLAKE2B) the 8-word hash arrays are NOT the node hashes -- the chain is laid over the built tree by
+// tree_hash_wide, 16 words per node -- so the kernels that fill them as they go write a recognisable poison instead of hashing with
+// some other digest: no work for a value nobody may read, and a kernel that consumed the wrong array would stand out.
 DAPOL_HD void node_hash32(int kind, uint32_t* out8, const uint32_t* c8) {
     if (kind == DG_BLAKE2S) blake2s_hash32(out8, c8);
+    else if (kind == DG_BLAKE2B) { for (int i = 0; i < 8; i++) out8[i] = 0xB2B2B2B2u; }
     else blake3_hash32(out8, c8);
 }
 DAPOL_HD void node_hash128(int kind, uint32_t* out8, const uint32_t* cl, const uint32_t* cr, const uint32_t* hl, const uint32_t* hr) {
     if (kind == DG_BLAKE2S) blake2s_hash128(out8, cl, cr, hl, hr);
+    else if (kind == DG_BLAKE2B) { for (int i = 0; i < 8; i++) out8[i] = 0xB2B2B2B2u; }
     else blake3_hash128(out8, cl, cr, hl, hr);
 }
 
