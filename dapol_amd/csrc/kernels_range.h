@@ -315,6 +315,26 @@ __global__ __launch_bounds__(64) void k_rp_A(RangeArgs A, TableView tbl) {
     if (l == 0) st_p3(A.PA + b * 40, acc);
 }
 
+// The same sum on ONE lane per proof (round 6: large batches of short proofs).  A wavefront per proof spends 6 shuffle-additions on
+// all 64 lanes to add up N / 64 terms per lane -- 448 lane-additions for the 64 terms of an individual proof; a lane walking its
+// proof's N terms does N.  All lanes of a wavefront read the same two table entries per step (entry 1 of G_i's row or of H_i's).
+__global__ __launch_bounds__(64) void k_rp_A_lane(RangeArgs A, TableView tbl) {
+    const size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (b >= A.B) return;
+    ge_p3 acc;
+    ge_identity(acc);
+#pragma nounroll
+    for (int j = 0; j < A.m; j++) {
+        const uint64_t v = A.vals[b * A.m + j];
+#pragma nounroll
+        for (int ii = 0; ii < A.n; ii++) {
+            const int bit = (int)((v >> ii) & 1ull);
+            tbl_madd(acc, tbl, bit ? tbl.row_G(j, ii) : tbl.row_H(j, ii), bit ? 1 : -1);
+        }
+    }
+    st_p3(A.PA + b * 40, acc);
+}
+
 // ------------------------------------------------------------------- K2: the fixed-base MSM, proof-stationary form
 // A list (L or R of one proof) is owned by LPL lanes; a lane walks the nwin signed W-bit windows from the top with W shared
 // doublings per window (Straus) and, per window, its terms of the list: digit -> one 128-byte entry of the generator's table row
