@@ -1323,6 +1323,31 @@ __global__ void k_gather_commitments(size_t b, int height, int start, int count,
     else for (int i = 0; i < 8; i++) c[i] = Bb_comp[i];
     st8(Vc + t * 8, c);
 }
+// Grouped sub-proofs (round 6, host_verify.inc: verify_policy_device): proof g = e * k + j of a group takes the commitments
+// start + j * m ... of its entity (all m of them real: a group's sub-proofs are full), its words are gathered from the entity's
+// blob into a contiguous batch, and the entity's verdict is the AND over its k sub-proofs.
+__global__ void k_gather_commitments_grouped(size_t b, int height, int start, int m, int k, const uint32_t* pC, uint32_t* Vc) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= b * (size_t)k * (size_t)m) return;
+    const size_t g = t / m, e = g / k;
+    const int jj = (int)(t - g * m), j = (int)(g - e * k);
+    uint32_t c[8];
+    ld8(c, pC + (e * (size_t)height + (size_t)(start + j * m + jj)) * 8);
+    st8(Vc + t * 8, c);
+}
+__global__ void k_gather_words_grouped(size_t b, int k, size_t pw, size_t entity_words, size_t word_off, const uint32_t* in, uint32_t* out) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= b * (size_t)k * pw) return;
+    const size_t g = t / pw, w = t - g * pw, e = g / k, j = g - e * k;
+    out[t] = in[e * entity_words + word_off + j * pw + w];
+}
+__global__ void k_and_bytes_grouped(size_t b, int k, uint8_t* acc, const uint8_t* x) {
+    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= b) return;
+    uint8_t a = acc[e];
+    for (int j = 0; j < k; j++) a &= x[e * (size_t)k + j];
+    acc[e] = a;
+}
 __global__ void k_and_bytes(size_t n, uint8_t* acc, const uint8_t* x) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) acc[i] = acc[i] & x[i];

@@ -165,3 +165,31 @@ def test_large_batch_of_individual_proofs_round_trip(gpu_ctx, hip_lib):
     bad[5, 700] ^= 1                                                   # inside the first individual proof of entity 5
     ok = gpu_ctx.verify_entities(height, idx, lC, lH, pC, pH, root[0], root[1], 0, 0, 64, bad, verify_seed=SEED)
     assert not ok[5] and ok.sum() == n - 1
+    # the grouped check (one batch of n * 16 individual proofs) and one check per sub-proof give the same verdict vector, also when the bad
+    # proof is the LAST sub-proof of the last entity and when two entities are bad
+    bad[n - 1, -3] ^= 4
+    for env in ({}, {"DAPOL_NO_GROUP": "1"}):
+        ok = _with_env(env, lambda: gpu_ctx.verify_entities(height, idx, lC, lH, pC, pH, root[0], root[1], 0, 0, 64, bad, verify_seed=SEED))
+        assert not ok[5] and not ok[n - 1] and ok.sum() == n - 2, env
+
+
+@pytest.mark.parametrize("height,policy,agg", [(9, 0, 4), (9, 1, 7), (8, 1, 5), (7, 0, 0)])
+def test_grouped_verification_equals_per_sub_proof_verification(gpu_ctx, hip_lib, height, policy, agg):
+    """dapol_verify_entities over plans with runs of equal-sized sub-proofs: all valid -> all ones; one byte flipped in every region of
+    one entity's blob (the aggregated part, the first, a middle and the last individual proof) -> exactly that entity, grouped or not."""
+    rng = np.random.default_rng(height + 31 * agg)
+    n = 40
+    idx, v, r = _leaves(rng, height, n)
+    tr = hip_lib.Tree(gpu_ctx, height, idx, v, r, SEED)
+    pC, pH, proofs = tr.prove_entities(idx, policy, agg, 64, SEED)
+    root = tr.root()
+    lC, lH = gpu_ctx.commit_hash_batch(v, r)
+    args = (height, idx, lC, lH, pC, pH, root[0], root[1], policy, agg, 64)
+    assert gpu_ctx.verify_entities(*args, proofs, verify_seed=SEED).all()
+    es = proofs.shape[1]
+    for e, off in ((3, 40), (11, es - 672 + 100), (17, es - 2 * 672 + 5), (39, es - 1)):
+        bad = proofs.copy()
+        bad[e, off] ^= 0x10
+        for env in ({}, {"DAPOL_NO_GROUP": "1"}):
+            ok = _with_env(env, lambda: gpu_ctx.verify_entities(*args, bad, verify_seed=SEED))
+            assert not ok[e] and ok.sum() == n - 1, (e, off, env)
