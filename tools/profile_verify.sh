@@ -18,11 +18,11 @@ rm -rf $OUT/${tag}_vstats
 echo "stats done"
 for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE"; do
   n=$(echo $c | cut -d' ' -f1)
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/${tag}_vpmc_$n -o pmc -- python3 $R/bench.py --mode verify --no-cpu-baseline --no-bad-proof-leg --no-pinned-leg --warmup 1 --steps 5 > $OUT/${tag}_vpmc_$n.log 2>&1 || { tail -5 $OUT/${tag}_vpmc_$n.log; exit 1; }
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/${tag}_vpmc_$n -o pmc -- python3 $R/bench.py --mode verify --no-cpu-baseline --no-bad-proof-leg --no-pinned-leg --warmup 2 --steps 5 > $OUT/${tag}_vpmc_$n.log 2>&1 || { tail -5 $OUT/${tag}_vpmc_$n.log; exit 1; }
   echo "pmc $n done"
 done
 cd $R
-# 6 verification passes per run: 1 warm-up + 5 timed (the untimed pass with a bad proof, whose per-proof re-check is another path, is skipped)
-python3 tools/pmc_all_summary.py --only k_rv --passes 6 --json $OUT/${tag}_verify_pmc.json $(ls -d $OUT/${tag}_vpmc_*/ ) > $OUT/${tag}_verify_pmc.txt
+# 7 verification passes per run: 2 warm-ups (one per alternating batch) + 5 timed (the untimed pass with a bad proof, whose per-proof re-check is another path, is skipped)
+python3 tools/pmc_all_summary.py --only k_rv --passes 7 --json $OUT/${tag}_verify_pmc.json $(ls -d $OUT/${tag}_vpmc_*/ ) > $OUT/${tag}_verify_pmc.txt
 for d in $(ls -d $OUT/${tag}_vpmc_*/); do rm -rf $d; done
 cat $OUT/${tag}_verify_pmc.txt
