@@ -130,6 +130,13 @@ struct dapol_ctx {
     RangeScratch scratch;        // grown on demand by the range prover
     RangeScratch vio;            // dapol_range_verify_batch's device copies of the caller's proofs / commitments / verdicts: kept between calls
                                  // (a 34 MB hipMalloc + hipFree per call is a few hundred microseconds of a 7 ms pass; at most 1 GB is kept)
+    // LANES for the sub-proofs of ONE small call (round 6, host_range.inc: prove_policy_device): a policy's plan with several groups
+    // of sub-proofs -- splitting at height 24 is a 16-party and an 8-party proof, benches/dapol.rs:71-78 -- is latency-bound, and its
+    // groups are independent statements; each extra group runs on a lane of its own: a shallow context that shares the tables (tv)
+    // and owns its streams, events and scratch.  Made on first use, freed with the context.
+    dapol_ctx* aux[3] = {nullptr, nullptr, nullptr};
+    uint32_t* h_pinned = nullptr;    // 16 page-locked words: a device-to-host copy into pageable memory blocks the host until the stream has
+                                     // drained, which would serialise the lanes; into this it is queued like a kernel
 };
 
 // Width of the context's node hash D: 8 words (BLAKE3, Blake2s) or 16 (Blake2b).  Every H buffer of the C ABI holds this many
@@ -234,6 +241,60 @@ static int32_t ensure_stream_layout(dapol_ctx* c, const char* name) {
 // running while the caller's next call reuses the scratch, or after the call's buffers are freed.  This guard, one per forking
 // function, waits for every side stream that was forked and not yet joined when the function is left.  (Nothing to wait for on the
 // normal path: the join has closed it.)
+static int32_t ctx_make_streams(dapol_ctx* c) {
+    HIPCHK(hipHostMalloc((void**)&c->h_pinned, 64, hipHostMallocDefault));
+    HIPCHK(hipStreamCreate(&c->stream));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    for (int i = 0; i < 3; i++) {
+        HIPCHK(hipStreamCreate(&c->side[i]));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+    }
+    HIPCHK(hipStreamCreate(&c->msm_stream));
+    for (int i = 0; i < 4; i++) HIPCHK(hipEventCreateWithFlags(&c->ev_v[i], hipEventDisableTiming));
+    for (int i = 0; i < 4; i++) {
+        HIPCHK(hipEventCreateWithFlags(&c->ev_msm_pre[i], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_msm_post[i], hipEventDisableTiming));
+    }
+    return DAPOL_OK;
+}
+static void ctx_free_streams(dapol_ctx* ctx) {
+    if (ctx->h_pinned) { (void)hipHostFree(ctx->h_pinned); ctx->h_pinned = nullptr; }
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    for (int i = 0; i < 3; i++) {
+        if (ctx->side[i]) (void)hipStreamDestroy(ctx->side[i]);
+        if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
+    }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    for (int i = 0; i < 4; i++) if (ctx->ev_v[i]) (void)hipEventDestroy(ctx->ev_v[i]);
+    if (ctx->msm_stream) (void)hipStreamDestroy(ctx->msm_stream);
+    for (int i = 0; i < 2; i++) {
+        if (ctx->layout_lane[i]) (void)hipStreamDestroy(ctx->layout_lane[i]);
+        if (ctx->layout_ev[i]) (void)hipEventDestroy(ctx->layout_ev[i]);
+    }
+    if (ctx->layout_msm) (void)hipStreamDestroy(ctx->layout_msm);
+    for (int i = 0; i < 4; i++) {
+        if (ctx->ev_msm_pre[i]) (void)hipEventDestroy(ctx->ev_msm_pre[i]);
+        if (ctx->ev_msm_post[i]) (void)hipEventDestroy(ctx->ev_msm_post[i]);
+    }
+}
+// Lane i (0 = the context itself) for one group of a small call's sub-proofs: see dapol_ctx::aux.
+static int32_t ctx_lane(dapol_ctx* ctx, int i, dapol_ctx** out) {
+    if (i == 0) { *out = ctx; return DAPOL_OK; }
+    dapol_ctx*& a = ctx->aux[i - 1];
+    if (!a) {
+        dapol_ctx* n = new dapol_ctx();
+        n->opt = ctx->opt; n->device = ctx->device; n->max_parties = ctx->max_parties; n->n_cu = ctx->n_cu;
+        n->msm_waves_per_cu = ctx->msm_waves_per_cu; n->msm_dyn_lds = ctx->msm_dyn_lds;
+        n->tv = ctx->tv;                                  // the same tables: only the primary owns (and frees) them
+        int32_t rc = ctx_make_streams(n);
+        if (rc) { ctx_free_streams(n); delete n; return rc; }
+        a = n;
+    }
+    a->opt = ctx->opt;                                    // (dapol_ctx_set_options may have changed since the lane was made)
+    *out = a;
+    return DAPOL_OK;
+}
+
 struct ForkGuard {
     dapol_ctx* c;
     bool open[3] = {false, false, false};
@@ -340,18 +401,7 @@ int32_t dapol_ctx_create_opts(int32_t device, int32_t max_parties, int32_t diges
         else (void)hipGetLastError();
     }
     struct Guard { dapol_ctx* c; ~Guard() { if (c) dapol_ctx_destroy(c); } } guard{c};
-    HIPCHK(hipStreamCreate(&c->stream));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    for (int i = 0; i < 3; i++) {
-        HIPCHK(hipStreamCreate(&c->side[i]));
-        HIPCHK(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
-    }
-    HIPCHK(hipStreamCreate(&c->msm_stream));
-    for (int i = 0; i < 4; i++) HIPCHK(hipEventCreateWithFlags(&c->ev_v[i], hipEventDisableTiming));
-    for (int i = 0; i < 4; i++) {
-        HIPCHK(hipEventCreateWithFlags(&c->ev_msm_pre[i], hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&c->ev_msm_post[i], hipEventDisableTiming));
-    }
+    { int32_t rc_ = ctx_make_streams(c); if (rc_) return rc_; }
     const int P = max_parties;
     // window width: the widest (<= 17 bits: wider measured slower, profiles/r01_wbits_ab4.txt) whose tables fit the budget --
     // DAPOL_TABLE_GB if set, else 40 GB but never more than 30 % of the memory that is free right now (a second context on
@@ -426,27 +476,19 @@ int32_t dapol_ctx_destroy(dapol_ctx* ctx) {
     if (!ctx) return DAPOL_OK;
     if (ctx->refs.fetch_sub(1) > 1) return DAPOL_OK;          // trees / workloads still use it: the last of them frees it
     (void)hipSetDevice(ctx->device);
+    for (int i = 0; i < 3; i++)
+        if (ctx->aux[i]) {
+            ctx->aux[i]->scratch.release();
+            ctx->aux[i]->vio.release();
+            ctx_free_streams(ctx->aux[i]);
+            delete ctx->aux[i];
+            ctx->aux[i] = nullptr;
+        }
     ctx->scratch.release();
     ctx->vio.release();
     ctx->table.release();
     ctx->gens_comp.release();
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
-    for (int i = 0; i < 3; i++) {
-        if (ctx->side[i]) (void)hipStreamDestroy(ctx->side[i]);
-        if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]);
-    }
-    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-    for (int i = 0; i < 4; i++) if (ctx->ev_v[i]) (void)hipEventDestroy(ctx->ev_v[i]);
-    if (ctx->msm_stream) (void)hipStreamDestroy(ctx->msm_stream);
-    for (int i = 0; i < 2; i++) {
-        if (ctx->layout_lane[i]) (void)hipStreamDestroy(ctx->layout_lane[i]);
-        if (ctx->layout_ev[i]) (void)hipEventDestroy(ctx->layout_ev[i]);
-    }
-    if (ctx->layout_msm) (void)hipStreamDestroy(ctx->layout_msm);
-    for (int i = 0; i < 4; i++) {
-        if (ctx->ev_msm_pre[i]) (void)hipEventDestroy(ctx->ev_msm_pre[i]);
-        if (ctx->ev_msm_post[i]) (void)hipEventDestroy(ctx->ev_msm_post[i]);
-    }
+    ctx_free_streams(ctx);
     delete ctx;
     return DAPOL_OK;
 }

@@ -193,3 +193,64 @@ def test_grouped_verification_equals_per_sub_proof_verification(gpu_ctx, hip_lib
         for env in ({}, {"DAPOL_NO_GROUP": "1"}):
             ok = _with_env(env, lambda: gpu_ctx.verify_entities(*args, bad, verify_seed=SEED))
             assert not ok[e] and ok.sum() == n - 1, (e, off, env)
+
+
+@pytest.mark.parametrize("height,policy,agg,n_bits", [(24, 1, 24, 64), (12, 1, 7, 64), (12, 0, 4, 64), (9, 1, 9, 32), (31, 1, 31, 64), (6, 0, 0, 8)])
+def test_groups_of_a_small_call_on_lanes_give_the_same_bytes(gpu_ctx, hip_lib, ref, height, policy, agg, n_bits):
+    """A small call whose plan has several groups (splitting at height 24 = a 16-party + an 8-party proof, the reference's own
+    `prove` case, benches/dapol.rs:71-78) runs them side by side on lanes of their own (dapol_ctx::aux): the bytes are those of the
+    one-after-the-other path (DAPOL_NO_LANES=1), of the ungrouped path, and of the C oracle; a second, different call on the same
+    context right after is clean; the proofs verify."""
+    rng = np.random.default_rng(height * 7 + agg)
+    n = 40
+    idx = np.sort(np.unique(rng.integers(0, 1 << height, size=n, dtype=np.uint64)))
+    n = len(idx)
+    v = rng.integers(0, min(2**20, (2**n_bits - 1) // n) + 1, size=n, dtype=np.uint64)      # every subtree sum stays inside n_bits
+    r = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    r[:, 31] &= 0x0F
+    tr = hip_lib.Tree(gpu_ctx, height, idx, v, r, SEED)
+    root = tr.root()
+    lC, lH = gpu_ctx.commit_hash_batch(v, r)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    t = ctypes.c_void_p(ref.ref_tree_build(height, ctypes.c_size_t(n), p(idx), p(v), p(r), SEED, 0))
+    plan = _plan(policy, height, agg)
+    for who in (idx[:1], idx[5:7], idx[3:4]):
+        pC, pH, got = tr.prove_entities(who, policy, agg, n_bits, SEED)
+        for env in ({"DAPOL_NO_LANES": "1"}, {"DAPOL_NO_GROUP": "1", "DAPOL_NO_LANES": "1"}, {"DAPOL_NO_GROUP": "1"}):
+            again = _with_env(env, lambda: tr.prove_entities(who, policy, agg, n_bits, SEED)[2])
+            assert again.tobytes() == got.tobytes(), env
+        sv, sr = (ctypes.c_uint64 * height)(), ctypes.create_string_buffer(32 * height)
+        sC, sH = ctypes.create_string_buffer(32 * height), ctypes.create_string_buffer(32 * height)
+        assert ref.ref_tree_path(t, ctypes.c_uint64(int(who[0])), sC, sH, sv, sr) == 1
+        want, slot = b"", 0
+        for start, count, m in plan:
+            vv = np.zeros(m, np.uint64)
+            rr = np.zeros((m, 32), np.uint8)
+            rr[:, 0] = 1
+            for j in range(count):
+                vv[j] = sv[start + j]
+                rr[j] = np.frombuffer(sr.raw[32 * (start + j):32 * (start + j + 1)], np.uint8)
+            ps = ref.ref_range_proof_size(n_bits, m)
+            out = ctypes.create_string_buffer(ps)
+            sid = np.array([who[0]], np.uint64)
+            assert ref.ref_range_prove_batch(n_bits, m, ctypes.c_size_t(1), p(vv), p(rr), SEED, p(sid), ctypes.c_uint64(slot), None, 0, out) == 0
+            want += out.raw
+            slot += m * (2 * n_bits + 4)
+        assert got[0].tobytes() == want
+        pos = np.searchsorted(idx, who)
+        ok = gpu_ctx.verify_entities(height, who, lC[pos], lH[pos], pC, pH, root[0], root[1], policy, agg, n_bits, got, verify_seed=SEED)
+        assert ok.all()
+        # the verifier's groups run on lanes too: a byte flipped in the FIRST and in the LAST sub-proof of the first entity turns its verdict,
+        # lanes or not, and leaves the other entity's alone
+        for off in (7, got.shape[1] - 9):
+            bad = got.copy()
+            bad[0, off] ^= 2
+            for env in ({}, {"DAPOL_NO_LANES": "1"}):
+                okb = _with_env(env, lambda: gpu_ctx.verify_entities(height, who, lC[pos], lH[pos], pC, pH, root[0], root[1], policy, agg, n_bits, bad, verify_seed=SEED))
+                assert not okb[0] and okb[1:].all(), (off, env)
+    ref.ref_tree_free(t)
+    # the batched inclusion proof of several leaves (one proof over the deduplicated siblings) takes the same path with b = 1
+    leaves = idx[:3]
+    a = tr.prove_batch(leaves, policy, min(agg, 4), n_bits, SEED)
+    b_ = _with_env({"DAPOL_NO_LANES": "1"}, lambda: tr.prove_batch(leaves, policy, min(agg, 4), n_bits, SEED))
+    assert a[-1] == b_[-1]
