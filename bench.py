@@ -375,6 +375,7 @@ def inline_preflight(tr, root, rank, world, dist, torch, comm_device, ctx, iters
     t0 = time.perf_counter()
     lib_comm = tr.comm is not None
     checks = {}
+    allow_fallback = allow_fallback or os.environ.get("DAPOL_EXCHANGE", "").lower() == "torch"      # (an explicit choice of the torch transport)
     if comm_device == "cuda" and not allow_fallback:
         checks["library_communicator_up"] = lib_comm
         checks["nccl_comm_count_equals_n"] = bool(lib_comm and tr.comm_ranks == world)
@@ -391,6 +392,7 @@ def inline_preflight_reduce(tr, rank, world, dist, torch, comm_device, iters=10,
     t0 = time.perf_counter()
     lib_comm = tr.comm is not None
     checks = {}
+    allow_fallback = allow_fallback or os.environ.get("DAPOL_EXCHANGE", "").lower() == "torch"
     if comm_device == "cuda" and not allow_fallback:
         checks["library_communicator_up"] = lib_comm
         checks["nccl_comm_count_equals_n"] = bool(lib_comm and tr.comm_ranks == world)
