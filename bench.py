@@ -694,7 +694,7 @@ def mode_prove(args):
     elif world == 1 and not args.no_secondary and prover.w is not None:
         log("secondary legs (splitting policy, API layout, host-buffer entry points)")
         try:
-            secondary = secondary_legs(ctx, capi, prover, height, n_bits, idx, v, r, n_per_gpu, host_leg_deadline=deadline + 15.0, t_step_hint=ms_per_step / 1e3)
+            secondary = secondary_legs(ctx, capi, prover, height, n_bits, idx, v, r, n_per_gpu, host_leg_deadline=deadline - 30.0, t_step_hint=ms_per_step / 1e3)      # (the full-size host-buffer leg only if it ends 60 s before the driver's 600 s)
         except Exception as e:                                   # the headline line must not die with a secondary leg
             secondary = {"error": repr(e)}
     print(json.dumps(make_line(cpu, parity, secondary, True)), flush=True)
