@@ -254,3 +254,38 @@ def test_groups_of_a_small_call_on_lanes_give_the_same_bytes(gpu_ctx, hip_lib, r
     a = tr.prove_batch(leaves, policy, min(agg, 4), n_bits, SEED)
     b_ = _with_env({"DAPOL_NO_LANES": "1"}, lambda: tr.prove_batch(leaves, policy, min(agg, 4), n_bits, SEED))
     assert a[-1] == b_[-1]
+
+
+def test_two_different_large_batches_back_to_back_need_no_fallback(gpu_ctx, hip_lib):
+    """the forked own-points branch of the batched verifier read k_rv_tables' entries without being ordered behind
+    it; with the SAME proofs in every pass the retained scratch still held the right values, so nothing showed.  Two independently
+    proven batches large enough for the bucket method and its side stream (2,048 proofs x 40 own points = 81,920 >= 32,768),
+    verified in turn on one context under fresh seeds: every verdict 1 and NOT ONE combined check falling back to bisection
+    (dapol_diag_verify_fallbacks); a tampered proof then moves the counter and turns exactly its verdict."""
+    n_bits, m, b = 64, 16, 2048
+    batches = []
+    for k in range(2):
+        rng = np.random.default_rng(900 + k)
+        v = rng.integers(0, 2**63, size=(b, m), dtype=np.uint64)
+        r = rng.integers(0, 256, size=(b, m, 32), dtype=np.uint8)
+        r[:, :, 31] &= 0x0F
+        proofs = gpu_ctx.range_prove_batch(n_bits, m, v, r, nonce_seed=SEED, stream_id=np.arange(k * b, (k + 1) * b, dtype=np.uint64))
+        C, _ = gpu_ctx.commit_hash_batch(v.reshape(-1), r.reshape(-1, 32))
+        batches.append((proofs, C.reshape(b, m, 32)))
+    fb = ctypes.c_uint64()
+    L = hip_lib.lib()
+    assert L.dapol_diag_verify_fallbacks(ctypes.byref(fb)) == 0
+    before = fb.value
+    for i in range(6):
+        proofs, Vs = batches[i & 1]
+        ok = gpu_ctx.range_verify_batch(n_bits, m, proofs, Vs, verify_seed=os.urandom(32))
+        assert ok.all(), i
+    L.dapol_diag_verify_fallbacks(ctypes.byref(fb))
+    assert fb.value == before, "a combined check of an all-valid batch fell back to bisection"
+    bad = batches[1][0].copy()
+    bad[777, 40] ^= 1
+    ok = gpu_ctx.range_verify_batch(n_bits, m, bad, batches[1][1], verify_seed=os.urandom(32))
+    L.dapol_diag_verify_fallbacks(ctypes.byref(fb))
+    assert not ok[777] and ok.sum() == b - 1 and fb.value > before
+    ok = gpu_ctx.range_verify_batch(n_bits, m, batches[0][0], batches[0][1], verify_seed=os.urandom(32))      # and the context is clean afterwards
+    assert ok.all()
