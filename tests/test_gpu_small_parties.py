@@ -107,7 +107,7 @@ def test_short_list_sweep_gives_the_same_bytes(gpu_ctx, ref, n_bits, m):
     assert ref.ref_range_prove_batch(n_bits, m, ctypes.c_size_t(k), p(v), p(r), SEED, p(sid), ctypes.c_uint64(3), None, 0, out) == 0
     assert base[:k].tobytes() == out.raw
     G = {"DAPOL_GS_SMALL_MIN": "64"}
-    for extra in ({}, {"DAPOL_NO_GS_HI": "1"}, {"DAPOL_GS_SLICES": "2"}, {"DAPOL_GS_SLICES": "1", "DAPOL_GS_TILE": "4"}, {"DAPOL_GS_TILE": "64"},
+    for extra in ({}, {"DAPOL_NO_GS_HI": "1"}, {"DAPOL_GS_SLICES": "2"}, {"DAPOL_GS_SLICES": "16"}, {"DAPOL_GS_SLICES": "8", "DAPOL_NO_GS_HI": "1"},   # (more slices than a short list has accumulator slots for: clamped) {"DAPOL_GS_SLICES": "1", "DAPOL_GS_TILE": "4"}, {"DAPOL_GS_TILE": "64"},
                   {"DAPOL_CHUNK": "64"}, {"DAPOL_CHUNK": "70", "DAPOL_STREAMS": "2"}, {"DAPOL_FS_SHAPE": "0"}, {"DAPOL_FS_SHAPE": "1"},
                   {"DAPOL_NO_STAB": "1"}, {"DAPOL_TAIL_N": "32"}, {"DAPOL_TAIL_N": "64", "DAPOL_NO_GS_HI": "1"}):
         env = dict(G, **extra)
