@@ -40,14 +40,19 @@ def _with_env(env, fn):
 
 
 def _leaves(rng, height, n):
-    idx = np.sort(rng.choice(1 << height, size=n, replace=False).astype(np.uint64))
+    if height > 22:
+        idx = np.sort(np.unique(rng.integers(0, 1 << height, size=n, dtype=np.uint64)))
+        n = len(idx)
+    else:
+        idx = np.sort(rng.choice(1 << height, size=n, replace=False).astype(np.uint64))
     v = rng.integers(0, 2**40, size=n, dtype=np.uint64)
     r = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
     r[:, 31] &= 0x0F
     return idx, v, r
 
 
-@pytest.mark.parametrize("height,policy,agg,n_bits", [(12, 0, 4, 64), (12, 1, 7, 64), (10, 0, 0, 64), (11, 1, 6, 32), (9, 0, 8, 64), (10, 1, 10, 64)])
+@pytest.mark.parametrize("height,policy,agg,n_bits", [(12, 0, 4, 64), (12, 1, 7, 64), (10, 0, 0, 64), (11, 1, 6, 32), (9, 0, 8, 64), (10, 1, 10, 64),
+                                                      (32, 0, 24, 64), (32, 1, 24, 64)])          # (the last two: bench.py's small_parties / splitting legs)
 def test_grouped_policy_proofs_vs_c_oracle(gpu_ctx, hip_lib, ref, height, policy, agg, n_bits):
     """Every sub-proof of every entity against ref_range_prove_batch with the entity's stream and the sub-proof's first slot; the
     grouped call (default), the one-call-per-sub-proof path (DAPOL_NO_GROUP) and the short-list sweep forced onto this batch
@@ -55,6 +60,7 @@ def test_grouped_policy_proofs_vs_c_oracle(gpu_ctx, hip_lib, ref, height, policy
     rng = np.random.default_rng(height * 100 + agg)
     n = 24
     idx, v, r = _leaves(rng, height, n)
+    n = len(idx)
     tr = hip_lib.Tree(gpu_ctx, height, idx, v, r, SEED)
     pC, pH, got = tr.prove_entities(idx, policy, agg, n_bits, SEED)
     # siblings' secrets from the C oracle's own tree (also checks the paths the prover saw)
