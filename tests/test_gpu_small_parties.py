@@ -88,7 +88,7 @@ def test_grouped_policy_proofs_vs_c_oracle(gpu_ctx, hip_lib, ref, height, policy
             slot += m * (2 * n_bits + 4)
         assert got[e].tobytes() == want, (e, "entity differs from the oracle")
     ref.ref_tree_free(t)
-    for env in ({"DAPOL_NO_GROUP": "1"}, {"DAPOL_GS_SMALL_MIN": "64"}, {"DAPOL_GS_SMALL_MIN": "64", "DAPOL_NO_GS_HI": "1"},
+    for env in ({"DAPOL_NO_GROUP": "1"}, {"DAPOL_NO_LANES": "1"}, {"DAPOL_NO_LANES": "1", "DAPOL_NO_GROUP": "1"}, {"DAPOL_LANES_MAX": "2"}, {"DAPOL_GS_SMALL_MIN": "64"}, {"DAPOL_GS_SMALL_MIN": "64", "DAPOL_NO_GS_HI": "1"},
                 {"DAPOL_GS_SMALL_MIN": "64", "DAPOL_CHUNK": "67"}, {"DAPOL_CHUNK": "5"}, {"DAPOL_CHUNK": "13", "DAPOL_STREAMS": "3"}):
         again = _with_env(env, lambda: tr.prove_entities(idx, policy, agg, n_bits, SEED)[2])
         assert again.tobytes() == got.tobytes(), env
