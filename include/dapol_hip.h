@@ -93,15 +93,19 @@ typedef struct {
     int32_t window_bits;              /* creation: width of the fixed-base windows, 8..20 (0: widest <= 17 whose tables fit table_gb) */
     double  table_gb;                 /* creation: budget of the window tables in GB (0: 40 GB, at most 30 % of the free memory) */
     int32_t high_half_rows;           /* creation: 0 auto, 1 on, -1 off: second table row per generator (halves the window steps of lanes that cannot share doublings) */
-    int32_t generator_stationary;     /* 0 auto (calls of at least 1,024 proofs over >= 1,024 generators a side that are not small calls), 1 every call that is not a small one, -1 never */
+    int32_t generator_stationary;     /* 0 auto (calls of at least 1,024 proofs over >= 1,024 generators a side that are not small calls; batches of shorter proofs --
+                                         a policy's individual proofs, 2 ... 8 parties -- from 2,048 / 1,024 / 512 proofs at 64 / 128 / 256-512 generators a side),
+                                         1 every call that is not a small one, -1 never */
     int32_t gs_tile_rows;             /* rows per launch of the generator-stationary sweep (multiple of 4; 0: 16) */
     int32_t streams;                  /* chunks in flight, 1..4 (0: 1 -- one chunk of two rounds of resident wavefronts; more only share the chip) */
     int64_t chunk_proofs;             /* proofs per chunk (0: whole rounds of resident wavefronts, 65,536 on MI355X) */
     double  scratch_gb;               /* scratch budget of the range prover / verifier in GB (0: 130 GB, at most what is free beyond 8 GB) */
-    int32_t tail_length;              /* length T of the hybrid inner-product argument's tail: 32 / 64 / 128 / 256, -1 = no tail (0: 64) */
+    int32_t tail_length;              /* length T of the hybrid inner-product argument's tail: 32 / 64 / 128 / 256, -1 = no tail (0: 64; swept batches of short
+                                         proofs: 32 at 512 generators a side, none below) */
     int32_t small_call_max;           /* calls of up to this many proofs take the latency shapes.  0: 1,023 for proofs of >= 1,024 generators a side (the sweep
-                                         takes over at 1,024 proofs unless generator_stationary = -1), 8,191 for smaller proofs.  An explicit value is taken as it
-                                         is: 8191 keeps the latency shapes up to 8,191 proofs for every proof size */
+                                         takes over at 1,024 proofs unless generator_stationary = -1), 8,191 for smaller proofs -- where the short-list sweep
+                                         takes over earlier (see generator_stationary; it yields only to generator_stationary = -1).  An explicit value is
+                                         taken as it is for proofs of >= 1,024 generators a side */
     int32_t verify_batch_min;         /* fewest proofs the verifier checks as ONE random linear combination (0: 112) */
     int64_t update_incremental_max;   /* dapol_tree_update: most replaced leaves re-merged in place (0: 65,536; -1: always rebuild) */
     int32_t gs_slices;                /* slices of a list swept side by side by the generator-stationary MSM: 1, 2, 4, 8, 16 (0: as many as fill the chip) */
