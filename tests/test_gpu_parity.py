@@ -1450,7 +1450,7 @@ def _forged_cancelling_pair(pyref, seed):
 @pytest.mark.gpu
 def test_cancelling_pair_is_rejected(hip_lib, pyref):
     """batch weights that ignore the proof bytes let a crafted pair of invalid proofs pass the combined check
-    (the round-1 library returns [1, 1] for this pair: profiles/r02_forged_pair_old_vs_new.txt).  The weights are now derived
+    (the round-1 library returns [1, 1] for this pair: profiles/archive/r02_forged_pair_old_vs_new.txt).  The weights are now derived
     from the digest of every proof and commitment of the batch, so the pair is rejected under the seed it was crafted for,
     under any other seed, under the library's own OS-random seed, and inside a larger batch of honest proofs."""
     import os

@@ -1,5 +1,5 @@
 """dapol_build_leaf_nodes near the sparsity bound Dapol::new allows (2^height = 2 n) and far from it: host-inclusive time, second of two
-calls (profiles/r04l_leaf_bound.txt: the one-lane collision resolution; r04m_leaf_bound.txt: the claim / settle rounds that replaced it)."""
+calls (profiles/archive/r04l_leaf_bound.txt: the one-lane collision resolution; r04m_leaf_bound.txt: the claim / settle rounds that replaced it)."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

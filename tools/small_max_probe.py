@@ -1,5 +1,5 @@
 """Which shape for calls of 4,096-8,000 proofs?  One dapol_range_prove_batch call (64-bit, 32 parties), best of 3: the library's defaults,
-the latency shapes extended to 8,191 proofs, the generator-stationary sweep from 4,097 proofs (64-row tiles).  (profiles/r04h_small_max_probe.txt
+the latency shapes extended to 8,191 proofs, the generator-stationary sweep from 4,097 proofs (64-row tiles).  (profiles/archive/r04h_small_max_probe.txt
 was taken with the default bound at 4,096.)"""
 import os, sys, time
 os.environ.setdefault("DAPOL_ENV_KNOBS", "1")
